@@ -1,0 +1,146 @@
+"""ctypes binding of libsegengine.so (the C ABI declared in include/segengine.h).
+
+This is the only place the Python host touches native code.  There is NO CPU fallback: if the shared library
+is missing, or no gfx950 device is visible when a context is requested, the import / call fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsegengine.so")
+
+SG_F32, SG_BF16 = 0, 1
+SG_EPI_BIAS, SG_EPI_RELU = 1, 2
+SG_ACT_RELU, SG_ACT_SIGMOID = 0, 1
+SG_LOSS_CE2, SG_LOSS_FOCAL, SG_LOSS_EDGE_FOCAL = 0, 1, 2
+
+
+class SgError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """Mirror of `sg_conv_desc` (include/segengine.h)."""
+
+    _fields_ = [(n, C.c_int32) for n in (
+        "N", "H", "W", "Cin", "Cout", "KH", "KW", "stride", "dilation", "pad_t", "pad_l", "Ho", "Wo",
+        "x_ld", "y_ld")]
+
+
+_vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+_dp = C.POINTER(ConvDesc)
+_pp = C.POINTER(C.c_void_p)
+
+# name -> (restype, argtypes).  Kept in the order of include/segengine.h.
+_SIGNATURES = {
+    "sg_abi_version": (_i, []),
+    "sg_last_error": (C.c_char_p, []),
+    "sg_create": (_i, [_i, _pp]),
+    "sg_destroy": (_i, [_vp]),
+    "sg_num_cus": (_i, [_vp]),
+    "sg_conv2d_fwd": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i]),
+    "sg_conv2d_dgrad_ws_bytes": (_sz, [_dp]),
+    "sg_conv2d_dgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "sg_conv2d_wgrad_ws_bytes": (_sz, [_vp, _dp]),
+    "sg_conv2d_wgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "sg_dwconv2d_fwd": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _i]),
+    "sg_dwconv2d_dgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i]),
+    "sg_dwconv2d_wgrad_ws_bytes": (_sz, [_vp, _dp]),
+    "sg_dwconv2d_wgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "sg_dense_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i]),
+    "sg_bn_ws_bytes": (_sz, [_vp, _i64, _i]),
+    "sg_bn_train_fwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _sz]),
+    "sg_bn_train_bwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "sg_bn_infer": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i]),
+    "sg_act_fwd": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),
+    "sg_act_bwd": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _i]),
+    "sg_add_n": (_i, [_vp, _vp, _i, _i, _pp, _i64, _vp, _i]),
+    "sg_copy_channels": (_i, [_vp, _vp, _i, _i64, _i, _vp, _i, _i, _vp, _i, _i, _i]),
+    "sg_softmax2_fwd": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
+    "sg_softmax2_bwd": (_i, [_vp, _vp, _i, _i64, _vp, _vp, _vp]),
+    "sg_softmax_branch_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sg_softmax_branch_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sg_bcast_mul_fwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _i]),
+    "sg_bcast_mul_bwd_ws_bytes": (_sz, [_vp, _i, _i64, _i, _i]),
+    "sg_bcast_mul_bwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "sg_scse_fwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    "sg_scse_bwd_ws_bytes": (_sz, [_vp, _i, _i64, _i]),
+    "sg_scse_bwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "sg_bam_fwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp]),
+    "sg_bam_bwd_ws_bytes": (_sz, [_vp, _i, _i64, _i]),
+    "sg_bam_bwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "sg_maxpool_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
+    "sg_maxpool_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sg_avgpool_ws_bytes": (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
+    "sg_avgpool_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz]),
+    "sg_avgpool_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),
+    "sg_upsample_nearest_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),
+    "sg_upsample_nearest_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i]),
+    "sg_loss_ws_bytes": (_sz, [_vp, _i64]),
+    "sg_loss_fwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _sz]),
+    "sg_loss_bwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _f]),
+    "sg_confusion_counts": (_i, [_vp, _vp, _i64, _i, _vp, _vp, _vp]),
+    "sg_adam_step": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f]),
+    "sg_argmax_accumulate_i8": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i]),
+    "sg_vote_ge": (_i, [_vp, _vp, _i, _pp, _i64, _i, _vp]),
+    "sg_fill_f32": (_i, [_vp, _vp, _vp, _i64, _f]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def load():
+    """dlopen libsegengine.so (once) and attach the signatures.  Raises SgError if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise SgError(
+                f"{LIB_PATH} is missing - build it with `make -C building_detection_amd/csrc` "
+                "(or __graft_entry__.build()).  There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI and the binding diverge
+            fn.restype = res
+            fn.argtypes = args
+        if lib.sg_abi_version() != 1:
+            raise SgError(f"libsegengine ABI {lib.sg_abi_version()} != binding ABI 1")
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().sg_last_error().decode("utf-8", "replace")
+        raise SgError(f"{what or 'libsegengine'} failed (rc={rc}): {msg}")
+
+
+class Context:
+    """One `sg_ctx` per device (creation fails without a gfx950 GPU)."""
+
+    def __init__(self, device: int = 0):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.sg_create(device, C.byref(h)), "sg_create")
+        self.handle = h
+        self.device = device
+        self.num_cus = lib.sg_num_cus(h)
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                load().sg_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass

@@ -1,0 +1,73 @@
+// libsegengine: context, error reporting and small utility entry points of the C ABI (include/segengine.h).
+#include "sg_common.h"
+#include <string.h>
+
+static thread_local char g_err[512] = "";
+
+void sg_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+namespace {
+__global__ void fill_f32_kernel(float* __restrict__ p, int64_t n, float v) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] = v;
+}
+}  // namespace
+
+extern "C" {
+
+int sg_abi_version(void) { return SG_ABI_VERSION; }
+
+const char* sg_last_error(void) { return g_err; }
+
+int sg_create(int device, sg_ctx** out) {
+  SG_CHECK_ARG(out != nullptr, "sg_create: null out");
+  *out = nullptr;
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) {
+    sg_set_error("sg_create: no HIP device visible (%s); libsegengine has no CPU fallback",
+                 e != hipSuccess ? hipGetErrorString(e) : "device count 0");
+    return e != hipSuccess ? (int)e : SG_EUNSUPPORTED;
+  }
+  SG_CHECK_ARG(device >= 0 && device < count, "sg_create: device %d out of range [0,%d)", device, count);
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) {
+    sg_set_error("sg_create: hipGetDeviceProperties: %s", hipGetErrorString(e));
+    return (int)e;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    sg_set_error("sg_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return SG_EUNSUPPORTED;
+  }
+  sg_ctx* c = new sg_ctx();
+  c->device = device;
+  c->num_cus = prop.multiProcessorCount;
+  *out = c;
+  return 0;
+}
+
+int sg_destroy(sg_ctx* ctx) {
+  delete ctx;
+  return 0;
+}
+
+int sg_num_cus(const sg_ctx* ctx) { return ctx ? ctx->num_cus : 0; }
+
+int sg_fill_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float value) {
+  SG_CHECK_ARG(ctx && (p || n == 0), "sg_fill_f32: null argument");
+  if (n <= 0) return 0;
+  int64_t blocks = sg_cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)p, n, value);
+  SG_LAUNCH_CHECK("fill_f32_kernel");
+  return 0;
+}
+
+}  // extern "C"

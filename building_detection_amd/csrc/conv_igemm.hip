@@ -1,0 +1,721 @@
+// Implicit-GEMM NHWC convolution on the gfx950 matrix cores (fp32-in / fp32-acc MFMA 32x32x2).
+//
+//   forward  y[M = N*Ho*Wo][Cout]  = A[M][K = KH*KW*Cin] * W[K][Cout]      A gathered from x (im2col on the fly)
+//   dgrad    dx[M = N*H*W][Cin]    = A'[M][K' = KH*KW*Cout] * Wt[K'][Cin]  A' gathered from dy, Wt = per-tap
+//                                                                         transpose of W (built in workspace)
+//   wgrad    dw[K][Cout]           = sum_p A[p][K]^T * dy[p][Cout]         reduction over p = N*Ho*Wo, split
+//                                                                         over workgroups, fixed-order reduce
+//
+// One gather formula serves forward and dgrad (and therefore Conv2DTranspose forward):
+//     ih = (oh * a_mul + kh * k_mul + off_h);  valid iff ih % div == 0 and 0 <= ih/div < H
+//   forward: a_mul = stride, k_mul = dilation,  off = -pad_before, div = 1
+//   dgrad  : a_mul = 1,      k_mul = -dilation, off = +pad_before, div = stride
+//
+// Tiling (wave64, 4 waves / 256 threads per workgroup, BK = 32):
+//   128x128 (waves 2x2, 64x64 each = 2x2 MFMA tiles), 128x64 (waves 2x2, 64x32), 128x32 (waves 4x1, 32x32).
+//   A slab [128][32] is staged k-contiguous in LDS with a 36-float row stride (ds_read_b128 conflict-free:
+//   16-B slot = 9*row mod 16), the B slab [32][BN] n-contiguous (ds_read_b32, lanes = consecutive dwords).
+//   The k index inside a group of 8 is split across the two lane halves (lanes 0-31: k..k+3, lanes 32-63:
+//   k+4..k+7) so one ds_read_b128 feeds four MFMAs; A and B use the same split, so the GEMM is unchanged.
+//   Global loads for slab s+1 are issued before the MFMAs of slab s and written to the other LDS buffer
+//   after them: one barrier per slab (guide §5.5 T3 "minimum 2-phase").  fp32 MFMA is 64 cycles/instr, so a
+//   slab is 64 MFMAs = 4096 cycles per wave against ~32 KB of staging: the loop is MFMA-bound by design.
+//   Block ids are remapped so each XCD owns a contiguous run of M-tiles (shared halo / weights hit one L2).
+#include "sg_common.h"
+
+namespace {
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDA = BK + 4;  // floats; 144-byte rows
+
+struct IgemmParams {
+  const float* __restrict__ x;
+  const float* __restrict__ w;
+  const float* __restrict__ bias;
+  float* __restrict__ y;
+  int H, W, C, x_ld;
+  int OH, OW;
+  int Nout, y_ld;
+  int a_mul, k_mul, off_h, off_w, div;
+  int K, M;
+  int flags;
+  FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
+};
+
+template <int BN, int WGM, int WGN, bool VEC>
+__global__ __launch_bounds__(256, 2) void igemm_conv_kernel(const IgemmParams p) {
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDB = BN;
+  constexpr int NB = (BK * BN / 4) / 256;  // float4 B chunks per thread
+  static_assert(WGM * WGN == 4, "4 waves");
+  static_assert(NB >= 1, "tile too small");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);  // [2][BM*LDA]
+  float* Bs = As + 2 * BM * LDA;                // [2][BK*LDB]
+
+  const int t = threadIdx.x;
+  const uint32_t ntn = (p.Nout + BN - 1) / BN;
+  const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- per-thread A rows: 4 rows (r0 + 32 j), one 4-wide k chunk (kc) -------------------------------
+  const int kc = t & 7, r0 = t >> 3;
+  int row_base[4], row_oh[4], row_ow[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int m = m0 + r0 + 32 * j;
+    if (m < p.M) {
+      uint32_t n, rem, oh, ow;
+      fd_divmod((uint32_t)m, p.fd_ohow, n, rem);
+      fd_divmod(rem, p.fd_ow, oh, ow);
+      row_base[j] = n * p.H * p.W;
+      row_oh[j] = (int)oh * p.a_mul + p.off_h;
+      row_ow[j] = (int)ow * p.a_mul + p.off_w;
+    } else {
+      row_base[j] = 0;
+      row_oh[j] = -(1 << 28);
+      row_ow[j] = -(1 << 28);
+    }
+  }
+
+  f32x4 ra[4];
+  f32x4 rb[NB];
+
+  auto gather_elem_addr = [&](int j, int dh, int dw, bool kvalid, int64_t& off) -> bool {
+    int ih = row_oh[j] + dh, iw = row_ow[j] + dw;
+    bool v = kvalid;
+    if (p.div == 2) {  // only strides 1 and 2 occur on this path (host rejects others for dgrad)
+      v = v && (((ih | iw) & 1) == 0);
+      ih >>= 1;
+      iw >>= 1;
+    }
+    v = v && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+    off = (int64_t)(row_base[j] + ih * p.W + iw) * p.x_ld;
+    return v;
+  };
+
+  auto load_A = [&](int k0) {
+    if constexpr (VEC) {
+      const int k = k0 + 4 * kc;
+      const bool kvalid = k < p.K;
+      uint32_t tap, ci, kh, kw;
+      fd_divmod((uint32_t)k, p.fd_c, tap, ci);
+      fd_divmod(tap, p.fd_kw, kh, kw);
+      const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int64_t off;
+        const bool v = gather_elem_addr(j, dh, dw, kvalid, off);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ra[j] = v ? *reinterpret_cast<const f32x4*>(p.x + off + ci) : z;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int k = k0 + 4 * kc + e;
+        const bool kvalid = k < p.K;
+        uint32_t tap, ci, kh, kw;
+        fd_divmod((uint32_t)k, p.fd_c, tap, ci);
+        fd_divmod(tap, p.fd_kw, kh, kw);
+        const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          int64_t off;
+          const bool v = gather_elem_addr(j, dh, dw, kvalid, off);
+          ra[j][e] = v ? p.x[off + ci] : 0.f;
+        }
+      }
+    }
+  };
+
+  auto load_B = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + 256 * i;
+      const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+      const int k = k0 + kr, n = n0 + 4 * c4;
+      if constexpr (VEC) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        rb[i] = (k < p.K && n < p.Nout) ? *reinterpret_cast<const f32x4*>(p.w + (int64_t)k * p.Nout + n) : z;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          rb[i][e] = (k < p.K && n + e < p.Nout) ? p.w[(int64_t)k * p.Nout + n + e] : 0.f;
+      }
+    }
+  };
+
+  auto store_AB = [&](int buf) {
+    float* a = As + buf * BM * LDA;
+    float* b = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(a + (r0 + 32 * j) * LDA + 4 * kc) = ra[j];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + 256 * i;
+      const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+      *reinterpret_cast<f32x4*>(b + kr * LDB + 4 * c4) = rb[i];
+    }
+  };
+
+  // ---- MFMA side -------------------------------------------------------------------------------------
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nslab = (p.K + BK - 1) / BK;
+  load_A(0);
+  load_B(0);
+  store_AB(0);
+  __syncthreads();
+
+  for (int s = 0; s < nslab; ++s) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) {
+      load_A((s + 1) * BK);
+      load_B((s + 1) * BK);
+    }
+    const float* a = As + buf * BM * LDA;
+    const float* b = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      f32x4 af[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        af[i] = *reinterpret_cast<const f32x4*>(a + (wm + 32 * i + lr) * LDA + kk * 8 + 4 * lh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float bf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = b[(kk * 8 + 4 * lh + e) * LDB + wn + 32 * j + lr];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (s + 1 < nslab) store_AB(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, relu, store (each store: 2 x 128 contiguous bytes per wave) -------------------
+  const bool has_bias = (p.flags & SG_EPI_BIAS) != 0;
+  const bool do_relu = (p.flags & SG_EPI_RELU) != 0;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn + 32 * j + lr;
+    const bool cv = col < p.Nout;
+    const float bv = (has_bias && cv) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (cv && row < p.M) {
+          float v = acc[i][j][r] + bv;
+          if (do_relu) v = fmaxf(v, 0.f);
+          p.y[(int64_t)row * p.y_ld + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// ---- per-tap transpose of the kernel: w[tap][ci][co] -> wt[tap][co][ci] ------------------------------
+__global__ void transpose_taps_kernel(const float* __restrict__ w, float* __restrict__ wt, int Cin, int Cout) {
+  __shared__ float tile[32][33];
+  const int tap = blockIdx.z;
+  const float* src = w + (int64_t)tap * Cin * Cout;
+  float* dst = wt + (int64_t)tap * Cin * Cout;
+  const int ci0 = blockIdx.y * 32, co0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows at a time
+  for (int r = ty; r < 32; r += 8) {
+    const int ci = ci0 + r, co = co0 + tx;
+    tile[r][tx] = (ci < Cin && co < Cout) ? src[(int64_t)ci * Cout + co] : 0.f;
+  }
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int co = co0 + r, ci = ci0 + tx;
+    if (co < Cout && ci < Cin) dst[(int64_t)co * Cin + ci] = tile[tx][r];
+  }
+}
+
+// ---- wgrad --------------------------------------------------------------------------------------------
+struct WgradParams {
+  const float* __restrict__ x;
+  const float* __restrict__ dy;
+  float* __restrict__ out;  // [S][K][Cout] partials (or dw itself when S == 1)
+  int H, W, Cin, x_ld;
+  int OH, OW, Cout, y_ld;
+  int stride, dil, pad_t, pad_l;
+  int K, P;
+  int slabs_per_split;
+  FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
+};
+
+template <int BN, int WGM, int WGN, bool VEC>
+__global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const WgradParams p) {
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int LDAW = BM;  // A' slab is [32 pixels][128 r], r contiguous
+  constexpr int LDB = BN;
+  constexpr int NB = (BK * BN / 4) / 256;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float* As = reinterpret_cast<float*>(smem);  // [2][BK*LDAW]
+  float* Bs = As + 2 * BK * LDAW;               // [2][BK*LDB]
+
+  const int t = threadIdx.x;
+  const uint32_t ntn = (p.Cout + BN - 1) / BN;
+  const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t tile_r = bid / ntn, tile_n = bid - tile_r * ntn;
+  const int rbase = tile_r * BM, n0 = tile_n * BN;
+
+  // A' chunk owned by this thread: r = rbase + 4*rc (fixed tap / channel), pixel rows (t>>5) + 8 j
+  const int rc = t & 31, pr0 = t >> 5;
+  constexpr int NV = VEC ? 1 : 4;
+  int dh[NV], dw[NV], ci_e[NV];
+  bool rvalid[NV];
+  {
+#pragma unroll
+    for (int e = 0; e < NV; ++e) {
+      const int r = rbase + 4 * rc + e;
+      rvalid[e] = r < p.K;
+      uint32_t tap, ci, kh, kw;
+      fd_divmod((uint32_t)r, p.fd_c, tap, ci);
+      fd_divmod(tap, p.fd_kw, kh, kw);
+      dh[e] = (int)kh * p.dil - p.pad_t;
+      dw[e] = (int)kw * p.dil - p.pad_l;
+      ci_e[e] = (int)ci;
+    }
+  }
+
+  const int slab_begin = blockIdx.z * p.slabs_per_split;
+  const int nslab_total = (p.P + BK - 1) / BK;
+  int slab_end = slab_begin + p.slabs_per_split;
+  if (slab_end > nslab_total) slab_end = nslab_total;
+
+  f32x4 ra[4];
+  f32x4 rb[NB];
+
+  auto load_A = [&](int p0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int pp = p0 + pr0 + 8 * j;
+      const bool pv = pp < p.P;
+      uint32_t n, rem, oh, ow;
+      fd_divmod((uint32_t)(pv ? pp : 0), p.fd_ohow, n, rem);
+      fd_divmod(rem, p.fd_ow, oh, ow);
+      const int pixbase = n * p.H * p.W;
+      if constexpr (VEC) {
+        const int ih = (int)oh * p.stride + dh[0], iw = (int)ow * p.stride + dw[0];
+        const bool v = pv && rvalid[0] && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ra[j] = v ? *reinterpret_cast<const f32x4*>(p.x + (int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[0]) : z;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int ih = (int)oh * p.stride + dh[e], iw = (int)ow * p.stride + dw[e];
+          const bool v = pv && rvalid[e] && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+          ra[j][e] = v ? p.x[(int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[e]] : 0.f;
+        }
+      }
+    }
+  };
+
+  auto load_B = [&](int p0) {
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + 256 * i;
+      const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+      const int pp = p0 + kr, n = n0 + 4 * c4;
+      if constexpr (VEC) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        rb[i] = (pp < p.P && n < p.Cout) ? *reinterpret_cast<const f32x4*>(p.dy + (int64_t)pp * p.y_ld + n) : z;
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          rb[i][e] = (pp < p.P && n + e < p.Cout) ? p.dy[(int64_t)pp * p.y_ld + n + e] : 0.f;
+      }
+    }
+  };
+
+  auto store_AB = [&](int buf) {
+    float* a = As + buf * BK * LDAW;
+    float* b = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(a + (pr0 + 8 * j) * LDAW + 4 * rc) = ra[j];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + 256 * i;
+      const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+      *reinterpret_cast<f32x4*>(b + kr * LDB + 4 * c4) = rb[i];
+    }
+  };
+
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+  const int lr = lane & 31, lh = lane >> 5;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  if (slab_begin < slab_end) {
+    load_A(slab_begin * BK);
+    load_B(slab_begin * BK);
+    store_AB(0);
+  }
+  __syncthreads();
+
+  for (int s = slab_begin; s < slab_end; ++s) {
+    const int buf = (s - slab_begin) & 1;
+    if (s + 1 < slab_end) {
+      load_A((s + 1) * BK);
+      load_B((s + 1) * BK);
+    }
+    const float* a = As + buf * BK * LDAW;
+    const float* b = Bs + buf * BK * LDB;
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const int pk = 2 * kk + lh;
+      float af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = a[pk * LDAW + wm + 32 * i + lr];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = b[pk * LDB + wn + 32 * j + lr];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+    if (s + 1 < slab_end) store_AB(buf ^ 1);
+    __syncthreads();
+  }
+
+  float* out = p.out + (int64_t)blockIdx.z * p.K * p.Cout;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn + 32 * j + lr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (col < p.Cout && row < p.K) out[(int64_t)row * p.Cout + col] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+// out[i] = sum_z part[z][i]  in fixed z order
+__global__ void reduce_splits_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int S) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    float s = part[i];
+    for (int z = 1; z < S; ++z) s += part[(int64_t)z * n + i];
+    out[i] = s;
+  }
+}
+
+// column sums of a [rows][C] matrix with pixel stride ld: stage 1 writes part[by][c], stage 2 sums by.
+__global__ void colsum_stage1_kernel(const float* __restrict__ a, int64_t rows, int C, int ld, float* __restrict__ part) {
+  __shared__ float red[256];
+  const int TX = blockDim.x, TY = blockDim.y;  // TX*TY == 256
+  const int c = blockIdx.x * TX + threadIdx.x;
+  float s = 0.f;
+  if (c < C) {
+    for (int64_t r = (int64_t)blockIdx.y * TY + threadIdx.y; r < rows; r += (int64_t)gridDim.y * TY) s += a[r * ld + c];
+  }
+  red[threadIdx.y * TX + threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.y == 0 && c < C) {
+    float tot = 0.f;
+    for (int y = 0; y < TY; ++y) tot += red[y * TX + threadIdx.x];
+    part[(int64_t)blockIdx.y * C + c] = tot;
+  }
+}
+
+__global__ void colsum_stage2_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < nparts; ++i) s += (double)part[(int64_t)i * C + c];
+  out[c] = (float)s;
+}
+
+template <typename KernelT>
+int set_dyn_lds(KernelT k, size_t bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    sg_set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize=%zu): %s", bytes, hipGetErrorString(e));
+    return (int)e;
+  }
+  return 0;
+}
+
+template <int BN, int WGM, int WGN, bool VEC>
+int launch_igemm(const IgemmParams& p, hipStream_t st) {
+  constexpr size_t lds = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float);
+  static bool attr_done = false;  // idempotent; racing threads set the same value
+  if (!attr_done) {
+    int rc = set_dyn_lds(igemm_conv_kernel<BN, WGM, WGN, VEC>, lds);
+    if (rc) return rc;
+    attr_done = true;
+  }
+  const int64_t tiles = sg_cdiv(p.M, BM) * sg_cdiv(p.Nout, BN);
+  if (tiles <= 0 || tiles > 0x7fffffff) {
+    sg_set_error("igemm: bad tile count %lld", (long long)tiles);
+    return SG_EINVAL;
+  }
+  hipLaunchKernelGGL((igemm_conv_kernel<BN, WGM, WGN, VEC>), dim3((unsigned)tiles), dim3(256), lds, st, p);
+  SG_LAUNCH_CHECK("igemm_conv_kernel");
+  return 0;
+}
+
+int dispatch_igemm(const IgemmParams& p, bool vec, hipStream_t st) {
+  if (p.Nout > 64) return vec ? launch_igemm<128, 2, 2, true>(p, st) : launch_igemm<128, 2, 2, false>(p, st);
+  if (p.Nout > 32) return vec ? launch_igemm<64, 2, 2, true>(p, st) : launch_igemm<64, 2, 2, false>(p, st);
+  return vec ? launch_igemm<32, 4, 1, true>(p, st) : launch_igemm<32, 4, 1, false>(p, st);
+}
+
+template <int BN, int WGM, int WGN, bool VEC>
+int launch_wgrad(const WgradParams& p, int S, hipStream_t st) {
+  constexpr size_t lds = (size_t)(2 * BK * BM + 2 * BK * BN) * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = set_dyn_lds(igemm_wgrad_kernel<BN, WGM, WGN, VEC>, lds);
+    if (rc) return rc;
+    attr_done = true;
+  }
+  const int64_t tiles = sg_cdiv(p.K, BM) * sg_cdiv(p.Cout, BN);
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, VEC>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(256), lds, st, p);
+  SG_LAUNCH_CHECK("igemm_wgrad_kernel");
+  return 0;
+}
+
+int dispatch_wgrad(const WgradParams& p, int S, bool vec, hipStream_t st) {
+  if (p.Cout > 64) return vec ? launch_wgrad<128, 2, 2, true>(p, S, st) : launch_wgrad<128, 2, 2, false>(p, S, st);
+  if (p.Cout > 32) return vec ? launch_wgrad<64, 2, 2, true>(p, S, st) : launch_wgrad<64, 2, 2, false>(p, S, st);
+  return vec ? launch_wgrad<32, 4, 1, true>(p, S, st) : launch_wgrad<32, 4, 1, false>(p, S, st);
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int check_desc(const sg_conv_desc* d, const char* who) {
+  SG_CHECK_ARG(d != nullptr, "%s: null desc", who);
+  SG_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "%s: non-positive dims", who);
+  SG_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dilation > 0, "%s: bad kernel geometry", who);
+  SG_CHECK_ARG(d->Ho > 0 && d->Wo > 0, "%s: bad output dims", who);
+  SG_CHECK_ARG(d->pad_t >= 0 && d->pad_l >= 0, "%s: negative pad", who);
+  const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+  SG_CHECK_ARG(xl >= d->Cin && yl >= d->Cout, "%s: pixel stride smaller than channel count", who);
+  SG_CHECK_ARG((int64_t)d->N * d->H * d->W * xl < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo * yl < (1ll << 31),
+               "%s: tensor exceeds 2^31 elements", who);
+  // the last tap of the last output position must not need more than pad_after < kernel extent
+  return 0;
+}
+
+struct WgradPlan {
+  int S;
+  int slabs_per_split;
+  size_t dw_part_bytes;
+  int bias_parts;
+  size_t bias_part_bytes;
+};
+
+WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
+  WgradPlan pl;
+  const int64_t K = (int64_t)d->KH * d->KW * d->Cin;
+  const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+  const int bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
+  const int64_t tiles = sg_cdiv(K, BM) * sg_cdiv(d->Cout, bn);
+  const int64_t nslab = sg_cdiv(P, BK);
+  int64_t S = sg_cdiv((int64_t)2 * num_cus, tiles);
+  if (S > nslab / 4) S = nslab / 4;  // at least 4 slabs per split
+  if (S < 1) S = 1;
+  // keep the partial slab under 256 MiB
+  while (S > 1 && S * K * d->Cout * 4 > (256ll << 20)) --S;
+  pl.slabs_per_split = (int)sg_cdiv(nslab, S);
+  pl.S = (int)sg_cdiv(nslab, pl.slabs_per_split);
+  pl.dw_part_bytes = pl.S > 1 ? (size_t)pl.S * K * d->Cout * 4 : 0;
+  int64_t parts = sg_cdiv(P, 256 * 8);
+  if (parts > 256) parts = 256;
+  if (parts < 1) parts = 1;
+  pl.bias_parts = (int)parts;
+  pl.bias_part_bytes = (size_t)parts * d->Cout * 4;
+  return pl;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
+                  const void* bias, void* y, int flags) {
+  SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_fwd: null ctx");
+  SG_CHECK_ARG(dtype == SG_F32, "sg_conv2d_fwd: only SG_F32 is implemented");
+  int rc = check_desc(d, "sg_conv2d_fwd");
+  if (rc) return rc;
+  SG_CHECK_ARG(x && w && y, "sg_conv2d_fwd: null tensor");
+  SG_CHECK_ARG(!(flags & SG_EPI_BIAS) || bias, "sg_conv2d_fwd: SG_EPI_BIAS without bias");
+  IgemmParams p;
+  p.x = (const float*)x;
+  p.w = (const float*)w;
+  p.bias = (const float*)bias;
+  p.y = (float*)y;
+  p.H = d->H; p.W = d->W; p.C = d->Cin; p.x_ld = d->x_ld ? d->x_ld : d->Cin;
+  p.OH = d->Ho; p.OW = d->Wo;
+  p.Nout = d->Cout; p.y_ld = d->y_ld ? d->y_ld : d->Cout;
+  p.a_mul = d->stride; p.k_mul = d->dilation; p.off_h = -d->pad_t; p.off_w = -d->pad_l; p.div = 1;
+  p.K = d->KH * d->KW * d->Cin;
+  p.M = d->N * d->Ho * d->Wo;
+  p.flags = flags;
+  p.fd_ohow = make_fastdiv((uint32_t)(d->Ho * d->Wo));
+  p.fd_ow = make_fastdiv((uint32_t)d->Wo);
+  p.fd_c = make_fastdiv((uint32_t)d->Cin);
+  p.fd_kw = make_fastdiv((uint32_t)d->KW);
+  const bool vec = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
+  return dispatch_igemm(p, vec, (hipStream_t)stream);
+}
+
+size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d) {
+  if (!d) return 0;
+  return (size_t)d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+}
+
+int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                    const void* bias, void* dx, int flags, void* ws, size_t ws_bytes) {
+  SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_dgrad: null ctx");
+  SG_CHECK_ARG(dtype == SG_F32, "sg_conv2d_dgrad: only SG_F32 is implemented");
+  int rc = check_desc(d, "sg_conv2d_dgrad");
+  if (rc) return rc;
+  SG_CHECK_ARG(dy && w && dx, "sg_conv2d_dgrad: null tensor");
+  SG_CHECK_ARG(!(flags & SG_EPI_BIAS) || bias, "sg_conv2d_dgrad: SG_EPI_BIAS without bias");
+  if (d->stride != 1 && d->stride != 2) {
+    sg_set_error("sg_conv2d_dgrad: stride %d unsupported (the path uses strides 1 and 2 only)", d->stride);
+    return SG_EUNSUPPORTED;
+  }
+  const size_t need = sg_conv2d_dgrad_ws_bytes(d);
+  if (!ws || ws_bytes < need) {
+    sg_set_error("sg_conv2d_dgrad: workspace %zu < %zu", ws_bytes, need);
+    return SG_EWORKSPACE;
+  }
+  SG_CHECK_ARG(aligned16(ws), "sg_conv2d_dgrad: workspace must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  float* wt = (float*)ws;
+  {
+    dim3 grid((unsigned)sg_cdiv(d->Cout, 32), (unsigned)sg_cdiv(d->Cin, 32), (unsigned)(d->KH * d->KW));
+    hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, st, (const float*)w, wt, d->Cin, d->Cout);
+    SG_LAUNCH_CHECK("transpose_taps_kernel");
+  }
+  IgemmParams p;
+  p.x = (const float*)dy;
+  p.w = wt;
+  p.bias = (const float*)bias;
+  p.y = (float*)dx;
+  p.H = d->Ho; p.W = d->Wo; p.C = d->Cout; p.x_ld = d->y_ld ? d->y_ld : d->Cout;
+  p.OH = d->H; p.OW = d->W;
+  p.Nout = d->Cin; p.y_ld = d->x_ld ? d->x_ld : d->Cin;
+  p.a_mul = 1; p.k_mul = -d->dilation; p.off_h = d->pad_t; p.off_w = d->pad_l; p.div = d->stride;
+  p.K = d->KH * d->KW * d->Cout;
+  p.M = d->N * d->H * d->W;
+  p.flags = flags;
+  p.fd_ohow = make_fastdiv((uint32_t)(d->H * d->W));
+  p.fd_ow = make_fastdiv((uint32_t)d->W);
+  p.fd_c = make_fastdiv((uint32_t)d->Cout);
+  p.fd_kw = make_fastdiv((uint32_t)d->KW);
+  const bool vec = (d->Cout % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy);
+  return dispatch_igemm(p, vec, st);
+}
+
+size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
+  if (!ctx || !d) return 0;
+  WgradPlan pl = plan_wgrad(ctx->num_cus, d);
+  return pl.dw_part_bytes + pl.bias_part_bytes + 256;
+}
+
+int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
+                    void* dw, void* dbias, void* ws, size_t ws_bytes) {
+  SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_wgrad: null ctx");
+  SG_CHECK_ARG(dtype == SG_F32, "sg_conv2d_wgrad: only SG_F32 is implemented");
+  int rc = check_desc(d, "sg_conv2d_wgrad");
+  if (rc) return rc;
+  SG_CHECK_ARG(x && dy && dw, "sg_conv2d_wgrad: null tensor");
+  const WgradPlan pl = plan_wgrad(ctx->num_cus, d);
+  const size_t need = pl.dw_part_bytes + pl.bias_part_bytes + 256;
+  if (!ws || ws_bytes < need) {
+    sg_set_error("sg_conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
+    return SG_EWORKSPACE;
+  }
+  SG_CHECK_ARG(aligned16(ws), "sg_conv2d_wgrad: workspace must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  WgradParams p;
+  p.x = (const float*)x;
+  p.dy = (const float*)dy;
+  p.out = pl.S > 1 ? (float*)ws : (float*)dw;
+  p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_ld = d->x_ld ? d->x_ld : d->Cin;
+  p.OH = d->Ho; p.OW = d->Wo; p.Cout = d->Cout; p.y_ld = d->y_ld ? d->y_ld : d->Cout;
+  p.stride = d->stride; p.dil = d->dilation; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+  p.K = d->KH * d->KW * d->Cin;
+  p.P = d->N * d->Ho * d->Wo;
+  p.slabs_per_split = pl.slabs_per_split;
+  p.fd_ohow = make_fastdiv((uint32_t)(d->Ho * d->Wo));
+  p.fd_ow = make_fastdiv((uint32_t)d->Wo);
+  p.fd_c = make_fastdiv((uint32_t)d->Cin);
+  p.fd_kw = make_fastdiv((uint32_t)d->KW);
+  const bool vec = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cout % 4 == 0) && (p.y_ld % 4 == 0) &&
+                   aligned16(x) && aligned16(dy);
+  rc = dispatch_wgrad(p, pl.S, vec, st);
+  if (rc) return rc;
+  if (pl.S > 1) {
+    const int64_t n = (int64_t)p.K * p.Cout;
+    int64_t blocks = sg_cdiv(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, (float*)dw, n, pl.S);
+    SG_LAUNCH_CHECK("reduce_splits_kernel");
+  }
+  if (dbias) {
+    // 256-byte aligned region after the dw partials
+    float* part = (float*)((char*)ws + ((pl.dw_part_bytes + 255) & ~(size_t)255));
+    const int C = d->Cout;
+    int TX = 1;
+    while (TX < C && TX < 64) TX <<= 1;
+    const int TY = 256 / TX;
+    dim3 grid((unsigned)sg_cdiv(C, TX), (unsigned)pl.bias_parts);
+    hipLaunchKernelGGL(colsum_stage1_kernel, grid, dim3(TX, TY), 0, st, (const float*)dy, (int64_t)p.P, C, p.y_ld, part);
+    SG_LAUNCH_CHECK("colsum_stage1_kernel");
+    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)sg_cdiv(C, 64)), dim3(64), 0, st, (const float*)part, pl.bias_parts, C, (float*)dbias);
+    SG_LAUNCH_CHECK("colsum_stage2_kernel");
+  }
+  return 0;
+}
+
+int sg_dense_fwd(sg_ctx* ctx, void* stream, int dtype, int rows, int in, int out, const void* x, const void* w,
+                 const void* bias, void* y, int flags) {
+  sg_conv_desc d = {};
+  d.N = rows; d.H = 1; d.W = 1; d.Cin = in; d.Cout = out; d.KH = 1; d.KW = 1; d.stride = 1; d.dilation = 1;
+  d.Ho = 1; d.Wo = 1;
+  return sg_conv2d_fwd(ctx, stream, dtype, &d, x, w, bias, y, flags);
+}
+
+}  // extern "C"

@@ -1,0 +1,255 @@
+// BatchNormalization (Keras defaults) for NHWC [rows][C]: training forward/backward and inference.
+// HBM-bound: forward = one statistics pass (read x) + one apply pass (read x, write y); backward = one
+// reduction pass (read x, dy[, y]) + one apply pass.  Statistics use a per-channel pivot (the first row) so
+// the single-pass variance  E[(x-K)^2] - E[x-K]^2  does not cancel, and are combined in fp64.
+#include "sg_reduce.h"
+
+namespace {
+
+struct BnStatsOp {
+  static constexpr int NOUT = 2;
+  const float* __restrict__ x;
+  int C;
+  int64_t rows;
+  float* moving_mean;
+  float* moving_var;
+  float* save_mean;
+  float* save_invstd;
+  float momentum, eps;
+  int unbiased;
+
+  template <int V>
+  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[2][V]) const {
+    float k[V], v[V];
+    ldv<V>(x + c, k);  // pivot = row 0
+    ldv<V>(x + r * C + c, v);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float d = v[i] - k[i];
+      acc[0][i] += d;
+      acc[1][i] = fmaf(d, d, acc[1][i]);
+    }
+  }
+  __device__ __forceinline__ void finalize(int, int c, const double (&s)[2]) const {
+    const double n = (double)rows;
+    const double m1 = s[0] / n;
+    const double mean = (double)x[c] + m1;
+    double var = s[1] / n - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const double var_u = (unbiased && rows > 1) ? var * (n / (n - 1.0)) : var;
+    moving_mean[c] = (float)((double)moving_mean[c] * momentum + mean * (1.0 - (double)momentum));
+    moving_var[c] = (float)((double)moving_var[c] * momentum + var_u * (1.0 - (double)momentum));
+  }
+};
+
+struct BnBwdOp {
+  static constexpr int NOUT = 2;  // sum dy, sum dy * xhat
+  const float* __restrict__ x;
+  const float* __restrict__ y;
+  const float* __restrict__ dy;
+  const float* __restrict__ mean;
+  const float* __restrict__ invstd;
+  float* dgamma;
+  float* dbeta;
+  int C;
+  int relu;
+
+  template <int V>
+  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[2][V]) const {
+    float xv[V], gv[V], mv[V], iv[V];
+    ldv<V>(x + r * C + c, xv);
+    ldv<V>(dy + r * C + c, gv);
+    ldv<V>(mean + c, mv);
+    ldv<V>(invstd + c, iv);
+    if (relu) {
+      float yv[V];
+      ldv<V>(y + r * C + c, yv);
+#pragma unroll
+      for (int i = 0; i < V; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      acc[0][i] += gv[i];
+      acc[1][i] = fmaf(gv[i], (xv[i] - mv[i]) * iv[i], acc[1][i]);
+    }
+  }
+  __device__ __forceinline__ void finalize(int, int c, const double (&s)[2]) const {
+    dbeta[c] = (float)s[0];
+    dgamma[c] = (float)s[1];
+  }
+};
+
+template <int V>
+__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float* __restrict__ y, int64_t rows, int C, int relu,
+                                float eps, int infer, FastDiv fd_cv) {
+  const uint32_t cv = C / V;
+  const uint32_t total = (uint32_t)(rows * cv);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = fd_div(i, fd_cv);
+    const int c = (int)(i - (uint32_t)r * cv) * V;
+    float xv[V], mv[V], iv[V], gv[V], bv[V], o[V];
+    ldv<V>(x + r * C + c, xv);
+    ldv<V>(mean + c, mv);
+    ldv<V>(invstd + c, iv);  // inference: this is the moving variance
+    ldv<V>(gamma + c, gv);
+    ldv<V>(beta + c, bv);
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float is = infer ? rsqrtf(iv[k] + eps) : iv[k];
+      float t = (xv[k] - mv[k]) * is * gv[k] + bv[k];
+      if (relu) t = fmaxf(t, 0.f);
+      o[k] = t;
+    }
+    stv<V>(y + r * C + c, o);
+  }
+}
+
+template <int V>
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                    const float* __restrict__ dy, const float* __restrict__ mean,
+                                    const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
+                                    float* __restrict__ dx, int64_t rows, int C, int relu, FastDiv fd_cv) {
+  const uint32_t cv = C / V;
+  const uint32_t total = (uint32_t)(rows * cv);
+  const uint32_t stride = gridDim.x * blockDim.x;
+  const float inv_n = 1.0f / (float)rows;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int64_t r = fd_div(i, fd_cv);
+    const int c = (int)(i - (uint32_t)r * cv) * V;
+    float xv[V], gv[V], mv[V], iv[V], gam[V], dg[V], db[V], o[V];
+    ldv<V>(x + r * C + c, xv);
+    ldv<V>(dy + r * C + c, gv);
+    ldv<V>(mean + c, mv);
+    ldv<V>(invstd + c, iv);
+    ldv<V>(gamma + c, gam);
+    ldv<V>(dgamma + c, dg);
+    ldv<V>(dbeta + c, db);
+    if (relu) {
+      float yv[V];
+      ldv<V>(y + r * C + c, yv);
+#pragma unroll
+      for (int k = 0; k < V; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float xh = (xv[k] - mv[k]) * iv[k];
+      o[k] = gam[k] * iv[k] * (gv[k] - db[k] * inv_n - xh * dg[k] * inv_n);
+    }
+    stv<V>(dx + r * C + c, o);
+  }
+}
+
+inline unsigned ew_blocks(int64_t total) {
+  int64_t b = sg_cdiv(total, 256);
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sg_bn_ws_bytes(const sg_ctx* ctx, int64_t rows, int C) {
+  if (!ctx) return 0;
+  SegPlan pl = seg_plan<2>(ctx->num_cus, 1, rows, C, true);
+  // scalar plan can only be smaller or equal in part_bytes (same formula, S differs): take the max of both
+  SegPlan pls = seg_plan<2>(ctx->num_cus, 1, rows, C, false);
+  return (pl.part_bytes > pls.part_bytes ? pl.part_bytes : pls.part_bytes) + 256;
+}
+
+int sg_bn_train_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* gamma,
+                    const void* beta, void* moving_mean, void* moving_var, void* y, void* save_mean,
+                    void* save_invstd, float momentum, float eps, int relu, int unbiased_update, void* ws,
+                    size_t ws_bytes) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_train_fwd: bad ctx/dtype");
+  SG_CHECK_ARG(rows > 0 && C > 0 && x && gamma && beta && moving_mean && moving_var && y && save_mean && save_invstd,
+               "sg_bn_train_fwd: bad argument");
+  SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_train_fwd: tensor exceeds 2^31 elements");
+  const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const SegPlan pl = seg_plan<2>(ctx->num_cus, 1, rows, C, vec);
+  if (!ws || ws_bytes < pl.part_bytes) {
+    sg_set_error("sg_bn_train_fwd: workspace %zu < %zu", ws_bytes, pl.part_bytes);
+    return SG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  BnStatsOp op;
+  op.x = (const float*)x; op.C = C; op.rows = rows;
+  op.moving_mean = (float*)moving_mean; op.moving_var = (float*)moving_var;
+  op.save_mean = (float*)save_mean; op.save_invstd = (float*)save_invstd;
+  op.momentum = momentum; op.eps = eps; op.unbiased = unbiased_update;
+  int rc = seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_stats");
+  if (rc) return rc;
+  const int V = vec ? 4 : 1;
+  const unsigned blocks = ew_blocks(rows * (C / V));
+  if (vec)
+    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)save_mean,
+                       (const float*)save_invstd, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, eps, 0, make_fastdiv((uint32_t)(C / V)));
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)save_mean,
+                       (const float*)save_invstd, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, eps, 0, make_fastdiv((uint32_t)(C / V)));
+  SG_LAUNCH_CHECK("bn_apply_kernel");
+  return 0;
+}
+
+int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* y,
+                    const void* dy, const void* gamma, const void* save_mean, const void* save_invstd, void* dx,
+                    void* dgamma, void* dbeta, int relu, void* ws, size_t ws_bytes) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_train_bwd: bad ctx/dtype");
+  SG_CHECK_ARG(rows > 0 && C > 0 && x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta,
+               "sg_bn_train_bwd: bad argument");
+  SG_CHECK_ARG(!relu || y, "sg_bn_train_bwd: relu set but y is null");
+  SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_train_bwd: tensor exceeds 2^31 elements");
+  const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy) && sg_aligned16(dx) && (!relu || sg_aligned16(y));
+  const SegPlan pl = seg_plan<2>(ctx->num_cus, 1, rows, C, vec);
+  if (!ws || ws_bytes < pl.part_bytes) {
+    sg_set_error("sg_bn_train_bwd: workspace %zu < %zu", ws_bytes, pl.part_bytes);
+    return SG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  BnBwdOp op;
+  op.x = (const float*)x; op.y = (const float*)y; op.dy = (const float*)dy;
+  op.mean = (const float*)save_mean; op.invstd = (const float*)save_invstd;
+  op.dgamma = (float*)dgamma; op.dbeta = (float*)dbeta; op.C = C; op.relu = relu;
+  int rc = seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_bwd_reduce");
+  if (rc) return rc;
+  const int V = vec ? 4 : 1;
+  const unsigned blocks = ew_blocks(rows * (C / V));
+  if (vec)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)y,
+                       (const float*)dy, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
+                       (const float*)dgamma, (const float*)dbeta, (float*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)y,
+                       (const float*)dy, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
+                       (const float*)dgamma, (const float*)dbeta, (float*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));
+  SG_LAUNCH_CHECK("bn_bwd_apply_kernel");
+  return 0;
+}
+
+int sg_bn_infer(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* gamma,
+                const void* beta, const void* moving_mean, const void* moving_var, void* y, float eps, int relu) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_infer: bad ctx/dtype");
+  SG_CHECK_ARG(rows > 0 && C > 0 && x && gamma && beta && moving_mean && moving_var && y, "sg_bn_infer: bad argument");
+  SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_infer: tensor exceeds 2^31 elements");
+  const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const int V = vec ? 4 : 1;
+  const unsigned blocks = ew_blocks(rows * (C / V));
+  hipStream_t st = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)moving_mean,
+                       (const float*)moving_var, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, eps, 1, make_fastdiv((uint32_t)(C / V)));
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)moving_mean,
+                       (const float*)moving_var, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, eps, 1, make_fastdiv((uint32_t)(C / V)));
+  SG_LAUNCH_CHECK("bn_apply_kernel(infer)");
+  return 0;
+}
+
+}  // extern "C"

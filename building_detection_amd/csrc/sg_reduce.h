@@ -1,0 +1,136 @@
+// Segmented column reductions over NHWC data: out[seg][o][c] = sum_{r < rows} f_o(seg, r, c).
+//
+// This one shape covers every "squeeze" on the path: BatchNorm statistics (1 segment, all pixels),
+// GlobalAveragePooling / AveragePooling2D (segment = output pixel), the channel-gate gradients of cSE / BAM /
+// SK (segment = image), the depthwise-conv kernel gradient (9 outputs per channel) and bias gradients.
+//
+// Mapping: a 256-thread block is TX x TY with TX threads on consecutive V-wide channel chunks (coalesced
+// 16-byte loads along C) and TY threads on rows; each thread keeps NOUT x V partial sums in registers, the TY
+// partials are combined through LDS in a fixed order, and when the rows are split over S workgroups
+// (grid.z) the S partial rows are added in fixed order (in fp64) by the finalize kernel.  Results are
+// therefore bit-reproducible run to run (no float atomics).
+#pragma once
+#include "sg_common.h"
+
+template <class Op, int V>
+__global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int64_t rows, const int C, const int S,
+                                                         float* __restrict__ part) {
+  constexpr int NO = Op::NOUT;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* red = reinterpret_cast<float*>(smem_raw);  // [TY][TX][NO*V]
+  const int TX = blockDim.x, TY = blockDim.y;
+  const int tx = threadIdx.x, ty = threadIdx.y;
+  const int c = (blockIdx.x * TX + tx) * V;
+  const int seg = blockIdx.y, z = blockIdx.z;
+  float acc[NO][V];
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[o][v] = 0.f;
+  if (c < C) {
+    const int64_t per = (rows + S - 1) / S;
+    const int64_t rb = (int64_t)z * per;
+    int64_t re = rb + per;
+    if (re > rows) re = rows;
+    for (int64_t r = rb + ty; r < re; r += TY) op.template accum<V>(seg, r, c, acc);
+  }
+  float* mine = red + ((size_t)(ty * TX + tx)) * (NO * V);
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int v = 0; v < V; ++v) mine[o * V + v] = acc[o][v];
+  __syncthreads();
+  if (ty == 0 && c < C) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int v = 0; v < V; ++v) {
+        float s = 0.f;
+        for (int y = 0; y < TY; ++y) s += red[((size_t)(y * TX + tx)) * (NO * V) + o * V + v];
+        if (c + v < C) part[(((int64_t)seg * S + z) * NO + o) * C + c + v] = s;
+      }
+  }
+}
+
+template <class Op>
+__global__ void seg_finalize_kernel(const Op op, const int nseg, const int C, const int S,
+                                    const float* __restrict__ part) {
+  constexpr int NO = Op::NOUT;
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)nseg * C) return;
+  const int seg = (int)(idx / C), c = (int)(idx - (int64_t)seg * C);
+  double s[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) {
+    double t = 0.0;
+    for (int z = 0; z < S; ++z) t += (double)part[(((int64_t)seg * S + z) * NO + o) * C + c];
+    s[o] = t;
+  }
+  op.finalize(seg, c, s);
+}
+
+struct SegPlan {
+  int V, TX, TY, gx, S;
+  size_t part_bytes;
+};
+
+template <int NOUT>
+static inline SegPlan seg_plan(int num_cus, int nseg, int64_t rows, int C, bool vec_ok) {
+  SegPlan pl;
+  pl.V = (vec_ok && C % 4 == 0) ? 4 : 1;
+  const int chunks = C / pl.V;
+  int tx = 1;
+  while (tx < chunks && tx < 64) tx <<= 1;
+  pl.TX = tx;
+  pl.TY = 256 / tx;
+  pl.gx = (int)sg_cdiv(chunks, tx);
+  int64_t S = sg_cdiv((int64_t)4 * num_cus, (int64_t)pl.gx * nseg);
+  const int64_t maxS = sg_cdiv(rows, (int64_t)pl.TY * 4);
+  if (S > maxS) S = maxS;
+  if (S > 1024) S = 1024;
+  if (S < 1) S = 1;
+  pl.S = (int)S;
+  pl.part_bytes = (size_t)nseg * pl.S * NOUT * C * sizeof(float);
+  return pl;
+}
+
+// Launch reduce + finalize.  `part` must hold pl.part_bytes.
+template <class Op>
+static inline int seg_reduce_launch(const Op& op, const SegPlan& pl, int nseg, int64_t rows, int C, float* part,
+                                    hipStream_t st, const char* name) {
+  if (nseg <= 0 || rows <= 0 || C <= 0) return 0;
+  const size_t lds = (size_t)256 * Op::NOUT * pl.V * sizeof(float);
+  dim3 grid((unsigned)pl.gx, (unsigned)nseg, (unsigned)pl.S), block((unsigned)pl.TX, (unsigned)pl.TY);
+  if (pl.V == 4)
+    hipLaunchKernelGGL((seg_reduce_kernel<Op, 4>), grid, block, lds, st, op, rows, C, pl.S, part);
+  else
+    hipLaunchKernelGGL((seg_reduce_kernel<Op, 1>), grid, block, lds, st, op, rows, C, pl.S, part);
+  SG_LAUNCH_CHECK(name);
+  const int64_t n = (int64_t)nseg * C;
+  hipLaunchKernelGGL((seg_finalize_kernel<Op>), dim3((unsigned)sg_cdiv(n, 256)), dim3(256), 0, st, op, nseg, C, pl.S,
+                     (const float*)part);
+  SG_LAUNCH_CHECK(name);
+  return 0;
+}
+
+// vector load/store helpers (V = 4: 16-byte access; V = 1: scalar)
+template <int V>
+__device__ __forceinline__ void ldv(const float* __restrict__ p, float (&o)[V]) {
+  if constexpr (V == 4) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(p);
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+  } else {
+    o[0] = p[0];
+  }
+}
+template <int V>
+__device__ __forceinline__ void stv(float* __restrict__ p, const float (&o)[V]) {
+  if constexpr (V == 4) {
+    f32x4 t = {o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(p) = t;
+  } else {
+    p[0] = o[0];
+  }
+}
+
+static inline bool sg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -1,0 +1,551 @@
+// HBM-bound spatial kernels of the hot path (NHWC, channels innermost so every access is a coalesced run of
+// 16-byte channel chunks): depthwise 3x3 (SeparableConv2D's first half) forward / dgrad / wgrad, max / average
+// pooling, nearest up-sampling.
+#include "sg_reduce.h"
+
+namespace {
+
+inline unsigned ew_blocks(int64_t total) {
+  int64_t b = sg_cdiv(total, 256);
+  if (b > 16384) b = 16384;
+  if (b < 1) b = 1;
+  return (unsigned)b;
+}
+
+struct DwParams {
+  const float* __restrict__ x;   // forward input (or mask source for dgrad)
+  const float* __restrict__ w;   // [KH][KW][C]
+  const float* __restrict__ dy;
+  float* __restrict__ out;
+  int N, H, W, C, Ho, Wo, KH, KW, stride, dil, pad_t, pad_l, x_ld, y_ld, pre_relu;
+  FastDiv fd_cv, fd_w, fd_h;  // decomposition of the flat index: channel chunk, then width, then height
+};
+
+// y[n,oh,ow,c] = sum_taps relu?(x[n, oh*s - pt + kh*d, ow*s - pl + kw*d, c]) * w[kh,kw,c]
+template <int V>
+__global__ void dw_fwd_kernel(const DwParams p) {
+  const uint32_t cv = p.C / V;
+  const uint32_t total = (uint32_t)((int64_t)p.N * p.Ho * p.Wo * cv), stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t pix, cc, row, ow, n, oh;
+    fd_divmod(i, p.fd_cv, pix, cc);
+    fd_divmod(pix, p.fd_w, row, ow);
+    fd_divmod(row, p.fd_h, n, oh);
+    const int c = (int)cc * V;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int kh = 0; kh < p.KH; ++kh) {
+      const int ih = (int)oh * p.stride - p.pad_t + kh * p.dil;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      for (int kw = 0; kw < p.KW; ++kw) {
+        const int iw = (int)ow * p.stride - p.pad_l + kw * p.dil;
+        if ((unsigned)iw >= (unsigned)p.W) continue;
+        float xv[V], wv[V];
+        ldv<V>(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.x_ld + c, xv);
+        ldv<V>(p.w + (kh * p.KW + kw) * p.C + c, wv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = fmaf(p.pre_relu ? fmaxf(xv[k], 0.f) : xv[k], wv[k], acc[k]);
+      }
+    }
+    stv<V>(p.out + (int64_t)pix * p.y_ld + c, acc);
+  }
+}
+
+// dx[n,ih,iw,c] = sum_taps dy[n,(ih+pt-kh*d)/s,(iw+pl-kw*d)/s,c] * w[kh,kw,c]   (* [x>0] if pre_relu)
+template <int V>
+__global__ void dw_dgrad_kernel(const DwParams p) {
+  const uint32_t cv = p.C / V;
+  const uint32_t total = (uint32_t)((int64_t)p.N * p.H * p.W * cv), stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t pix, cc, row, iw, n, ih;
+    fd_divmod(i, p.fd_cv, pix, cc);
+    fd_divmod(pix, p.fd_w, row, iw);
+    fd_divmod(row, p.fd_h, n, ih);
+    const int c = (int)cc * V;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int kh = 0; kh < p.KH; ++kh) {
+      int oh = (int)ih + p.pad_t - kh * p.dil;
+      if (oh < 0 || oh % p.stride) continue;
+      oh /= p.stride;
+      if (oh >= p.Ho) continue;
+      for (int kw = 0; kw < p.KW; ++kw) {
+        int ow = (int)iw + p.pad_l - kw * p.dil;
+        if (ow < 0 || ow % p.stride) continue;
+        ow /= p.stride;
+        if (ow >= p.Wo) continue;
+        float gv[V], wv[V];
+        ldv<V>(p.dy + ((int64_t)(n * p.Ho + oh) * p.Wo + ow) * p.y_ld + c, gv);
+        ldv<V>(p.w + (kh * p.KW + kw) * p.C + c, wv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] = fmaf(gv[k], wv[k], acc[k]);
+      }
+    }
+    if (p.pre_relu) {
+      float xv[V];
+      ldv<V>(p.x + (int64_t)pix * p.x_ld + c, xv);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] = xv[k] > 0.f ? acc[k] : 0.f;
+    }
+    stv<V>(p.out + (int64_t)pix * p.x_ld + c, acc);
+  }
+}
+
+// dw[kh,kw,c] = sum_{n,oh,ow} relu?(x[n,ih,iw,c]) * dy[n,oh,ow,c]  — 9 outputs per channel
+struct DwWgradOp {
+  static constexpr int NOUT = 9;
+  const float* __restrict__ x;
+  const float* __restrict__ dy;
+  float* dw;
+  int H, W, C, Ho, Wo, stride, dil, pad_t, pad_l, x_ld, y_ld, pre_relu;
+  FastDiv fd_w, fd_h;
+  template <int V>
+  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[9][V]) const {
+    uint32_t row, ow, n, oh;
+    fd_divmod((uint32_t)r, fd_w, row, ow);
+    fd_divmod(row, fd_h, n, oh);
+    float gv[V];
+    ldv<V>(dy + r * y_ld + c, gv);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      const int ih = (int)oh * stride - pad_t + kh * dil;
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int iw = (int)ow * stride - pad_l + kw * dil;
+        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
+          float xv[V];
+          ldv<V>(x + ((int64_t)(n * H + ih) * W + iw) * x_ld + c, xv);
+#pragma unroll
+          for (int k = 0; k < V; ++k)
+            acc[kh * 3 + kw][k] = fmaf(pre_relu ? fmaxf(xv[k], 0.f) : xv[k], gv[k], acc[kh * 3 + kw][k]);
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void finalize(int, int c, const double (&s)[9]) const {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw[t * C + c] = (float)s[t];
+  }
+};
+
+// ---------------------------------------------------------------------------------------------- pooling
+struct PoolParams {
+  const float* __restrict__ x;
+  const float* __restrict__ y;
+  const float* __restrict__ dy;
+  float* __restrict__ out;
+  int N, H, W, C, Ho, Wo, k, stride, pad_t, pad_l;
+  FastDiv fd_cv, fd_w, fd_h;
+};
+
+template <int V>
+__global__ void maxpool_fwd_kernel(const PoolParams p) {
+  const uint32_t cv = p.C / V;
+  const uint32_t total = (uint32_t)((int64_t)p.N * p.Ho * p.Wo * cv), stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t pix, cc, row, ow, n, oh;
+    fd_divmod(i, p.fd_cv, pix, cc);
+    fd_divmod(pix, p.fd_w, row, ow);
+    fd_divmod(row, p.fd_h, n, oh);
+    const int c = (int)cc * V;
+    float m[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) m[k] = -INFINITY;
+    for (int a = 0; a < p.k; ++a) {
+      const int ih = (int)oh * p.stride - p.pad_t + a;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      for (int b = 0; b < p.k; ++b) {
+        const int iw = (int)ow * p.stride - p.pad_l + b;
+        if ((unsigned)iw >= (unsigned)p.W) continue;
+        float xv[V];
+        ldv<V>(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.C + c, xv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) m[k] = fmaxf(m[k], xv[k]);
+      }
+    }
+    stv<V>(p.out + (int64_t)pix * p.C + c, m);
+  }
+}
+
+// Gather form (deterministic, no atomics): input element (ih,iw) receives dy of every window in which it is the
+// FIRST maximum in window scan order (row-major), which is where TF / Eigen route the gradient.
+template <int V>
+__global__ void maxpool_bwd_kernel(const PoolParams p) {
+  const uint32_t cv = p.C / V;
+  const uint32_t total = (uint32_t)((int64_t)p.N * p.H * p.W * cv), stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t pix, cc, row, iw, n, ih;
+    fd_divmod(i, p.fd_cv, pix, cc);
+    fd_divmod(pix, p.fd_w, row, iw);
+    fd_divmod(row, p.fd_h, n, ih);
+    const int c = (int)cc * V;
+    float xv[V], acc[V];
+    ldv<V>(p.x + (int64_t)pix * p.C + c, xv);
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    // windows (oh, ow) that contain (ih, iw): oh*s - pt <= ih < oh*s - pt + k
+    const int th = (int)ih + p.pad_t, tw = (int)iw + p.pad_l;
+    int oh_hi = th / p.stride, ow_hi = tw / p.stride;
+    int oh_lo = (th - p.k + p.stride) / p.stride, ow_lo = (tw - p.k + p.stride) / p.stride;  // ceil((t-k+1)/s)
+    if (th - p.k + 1 <= 0) oh_lo = 0;
+    if (tw - p.k + 1 <= 0) ow_lo = 0;
+    if (oh_hi >= p.Ho) oh_hi = p.Ho - 1;
+    if (ow_hi >= p.Wo) ow_hi = p.Wo - 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const int64_t opix = ((int64_t)n * p.Ho + oh) * p.Wo + ow;
+        float yv[V], gv[V];
+        ldv<V>(p.y + opix * p.C + c, yv);
+        ldv<V>(p.dy + opix * p.C + c, gv);
+        bool first[V];
+#pragma unroll
+        for (int k = 0; k < V; ++k) first[k] = (xv[k] == yv[k]);
+        // any earlier element of this window (scan order) equal to the max takes precedence
+        const int a0 = (int)ih - (oh * p.stride - p.pad_t), b0 = (int)iw - (ow * p.stride - p.pad_l);
+        for (int a = 0; a <= a0; ++a) {
+          const int jh = oh * p.stride - p.pad_t + a;
+          if ((unsigned)jh >= (unsigned)p.H) continue;
+          const int bend = (a == a0) ? b0 : p.k;
+          for (int b = 0; b < bend; ++b) {
+            const int jw = ow * p.stride - p.pad_l + b;
+            if ((unsigned)jw >= (unsigned)p.W) continue;
+            float ev[V];
+            ldv<V>(p.x + ((int64_t)(n * p.H + jh) * p.W + jw) * p.C + c, ev);
+#pragma unroll
+            for (int k = 0; k < V; ++k) first[k] = first[k] && !(ev[k] == yv[k]);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += first[k] ? gv[k] : 0.f;
+      }
+    }
+    stv<V>(p.out + (int64_t)pix * p.C + c, acc);
+  }
+}
+
+// AveragePooling2D(k) / GlobalAveragePooling2D as a segmented reduction: segment = output pixel (n,oh,ow),
+// rows = kh*kw window cells.
+struct AvgPoolOp {
+  static constexpr int NOUT = 1;
+  const float* __restrict__ x;
+  float* y;
+  int H, W, C, Ho, Wo, kh, kw;
+  FastDiv fd_howo, fd_wo, fd_kw;
+  template <int V>
+  __device__ __forceinline__ void accum(int seg, int64_t r, int c, float (&acc)[1][V]) const {
+    uint32_t n, rem, oh, ow, a, b;
+    fd_divmod((uint32_t)seg, fd_howo, n, rem);
+    fd_divmod(rem, fd_wo, oh, ow);
+    fd_divmod((uint32_t)r, fd_kw, a, b);
+    float xv[V];
+    ldv<V>(x + ((int64_t)(n * H + oh * kh + a) * W + ow * kw + b) * C + c, xv);
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[0][k] += xv[k];
+  }
+  __device__ __forceinline__ void finalize(int seg, int c, const double (&s)[1]) const {
+    y[(int64_t)seg * C + c] = (float)(s[0] / (double)(kh * kw));
+  }
+};
+
+template <int V>
+__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C,
+                                   int kh, int kw, int accumulate, FastDiv fd_cv, FastDiv fd_w, FastDiv fd_h) {
+  const uint32_t cv = C / V;
+  const uint32_t total = (uint32_t)((int64_t)N * H * W * cv), stride = gridDim.x * blockDim.x;
+  const int Ho = H / kh, Wo = W / kw;
+  const float sc = 1.0f / (float)(kh * kw);
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t pix, cc, row, iw, n, ih;
+    fd_divmod(i, fd_cv, pix, cc);
+    fd_divmod(pix, fd_w, row, iw);
+    fd_divmod(row, fd_h, n, ih);
+    const int c = (int)cc * V;
+    const int oh = (int)ih / kh, ow = (int)iw / kw;
+    float o[V];
+    if (oh < Ho && ow < Wo) {
+      ldv<V>(dy + (((int64_t)n * Ho + oh) * Wo + ow) * C + c, o);
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] *= sc;
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] = 0.f;
+    }
+    if (accumulate) {
+      float t[V];
+      ldv<V>(dx + (int64_t)pix * C + c, t);
+#pragma unroll
+      for (int k = 0; k < V; ++k) o[k] += t[k];
+    }
+    stv<V>(dx + (int64_t)pix * C + c, o);
+  }
+}
+
+template <int V>
+__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+                                    int sh, int sw, int y_ld, FastDiv fd_cv, FastDiv fd_w, FastDiv fd_h) {
+  const uint32_t cv = C / V;
+  const int OH = H * sh, OW = W * sw;
+  const uint32_t total = (uint32_t)((int64_t)N * OH * OW * cv), stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t pix, cc, row, ow, n, oh;
+    fd_divmod(i, fd_cv, pix, cc);
+    fd_divmod(pix, fd_w, row, ow);
+    fd_divmod(row, fd_h, n, oh);
+    const int c = (int)cc * V;
+    float v[V];
+    ldv<V>(x + (((int64_t)n * H + oh / sh) * W + ow / sw) * C + c, v);
+    stv<V>(y + (int64_t)pix * y_ld + c, v);
+  }
+}
+
+template <int V>
+__global__ void upsample_bwd_kernel(const float* __restrict__ dy, int dy_ld, float* __restrict__ dx, int N, int H,
+                                    int W, int C, int sh, int sw, int accumulate, FastDiv fd_cv, FastDiv fd_w,
+                                    FastDiv fd_h) {
+  const uint32_t cv = C / V;
+  const uint32_t total = (uint32_t)((int64_t)N * H * W * cv), stride = gridDim.x * blockDim.x;
+  const int OW = W * sw, OH = H * sh;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t pix, cc, row, iw, n, ih;
+    fd_divmod(i, fd_cv, pix, cc);
+    fd_divmod(pix, fd_w, row, iw);
+    fd_divmod(row, fd_h, n, ih);
+    const int c = (int)cc * V;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    for (int a = 0; a < sh; ++a)
+      for (int b = 0; b < sw; ++b) {
+        float g[V];
+        ldv<V>(dy + (((int64_t)n * OH + ih * sh + a) * OW + iw * sw + b) * dy_ld + c, g);
+#pragma unroll
+        for (int k = 0; k < V; ++k) acc[k] += g[k];
+      }
+    if (accumulate) {
+      float t[V];
+      ldv<V>(dx + (int64_t)pix * C + c, t);
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[k] += t[k];
+    }
+    stv<V>(dx + (int64_t)pix * C + c, acc);
+  }
+}
+
+int dw_check(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, const char* who) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32 && d, "%s: bad ctx/dtype/desc", who);
+  SG_CHECK_ARG(d->Cin == d->Cout, "%s: depthwise needs Cin == Cout (depth_multiplier 1)", who);
+  SG_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Ho > 0 && d->Wo > 0 && d->KH > 0 && d->KW > 0 &&
+                   d->stride > 0 && d->dilation > 0,
+               "%s: bad geometry", who);
+  const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+  SG_CHECK_ARG((int64_t)d->N * d->H * d->W * xl < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo * yl < (1ll << 31),
+               "%s: tensor exceeds 2^31 elements", who);
+  return 0;
+}
+
+void dw_fill(DwParams& p, const sg_conv_desc* d) {
+  p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.KH = d->KH; p.KW = d->KW;
+  p.stride = d->stride; p.dil = d->dilation; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+  p.x_ld = d->x_ld ? d->x_ld : d->Cin;
+  p.y_ld = d->y_ld ? d->y_ld : d->Cout;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sg_dwconv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w, void* y,
+                    int pre_relu) {
+  int rc = dw_check(ctx, dtype, d, "sg_dwconv2d_fwd");
+  if (rc) return rc;
+  SG_CHECK_ARG(x && w && y, "sg_dwconv2d_fwd: null tensor");
+  DwParams p;
+  dw_fill(p, d);
+  p.x = (const float*)x; p.w = (const float*)w; p.dy = nullptr; p.out = (float*)y; p.pre_relu = pre_relu;
+  const bool vec = (p.C % 4 == 0) && (p.x_ld % 4 == 0) && (p.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(w) && sg_aligned16(y);
+  const int V = vec ? 4 : 1;
+  p.fd_cv = make_fastdiv((uint32_t)(p.C / V)); p.fd_w = make_fastdiv((uint32_t)p.Wo); p.fd_h = make_fastdiv((uint32_t)p.Ho);
+  const unsigned blocks = ew_blocks((int64_t)p.N * p.Ho * p.Wo * (p.C / V));
+  if (vec) hipLaunchKernelGGL((dw_fwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((dw_fwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  SG_LAUNCH_CHECK("dw_fwd_kernel");
+  return 0;
+}
+
+int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                      const void* x_for_mask, void* dx, int pre_relu) {
+  int rc = dw_check(ctx, dtype, d, "sg_dwconv2d_dgrad");
+  if (rc) return rc;
+  SG_CHECK_ARG(dy && w && dx, "sg_dwconv2d_dgrad: null tensor");
+  SG_CHECK_ARG(!pre_relu || x_for_mask, "sg_dwconv2d_dgrad: pre_relu needs the forward input");
+  DwParams p;
+  dw_fill(p, d);
+  p.x = (const float*)x_for_mask; p.w = (const float*)w; p.dy = (const float*)dy; p.out = (float*)dx; p.pre_relu = pre_relu;
+  const bool vec = (p.C % 4 == 0) && (p.x_ld % 4 == 0) && (p.y_ld % 4 == 0) && sg_aligned16(dy) && sg_aligned16(w) &&
+                   sg_aligned16(dx) && (!pre_relu || sg_aligned16(x_for_mask));
+  const int V = vec ? 4 : 1;
+  p.fd_cv = make_fastdiv((uint32_t)(p.C / V)); p.fd_w = make_fastdiv((uint32_t)p.W); p.fd_h = make_fastdiv((uint32_t)p.H);
+  const unsigned blocks = ew_blocks((int64_t)p.N * p.H * p.W * (p.C / V));
+  if (vec) hipLaunchKernelGGL((dw_dgrad_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((dw_dgrad_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  SG_LAUNCH_CHECK("dw_dgrad_kernel");
+  return 0;
+}
+
+size_t sg_dwconv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
+  if (!ctx || !d) return 0;
+  const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
+  const SegPlan a = seg_plan<9>(ctx->num_cus, 1, rows, d->Cin, true), b = seg_plan<9>(ctx->num_cus, 1, rows, d->Cin, false);
+  return (a.part_bytes > b.part_bytes ? a.part_bytes : b.part_bytes) + 256;
+}
+
+int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
+                      void* dw, int pre_relu, void* ws, size_t ws_bytes) {
+  int rc = dw_check(ctx, dtype, d, "sg_dwconv2d_wgrad");
+  if (rc) return rc;
+  SG_CHECK_ARG(x && dy && dw, "sg_dwconv2d_wgrad: null tensor");
+  SG_CHECK_ARG(d->KH == 3 && d->KW == 3, "sg_dwconv2d_wgrad: only 3x3 depthwise kernels occur on this path");
+  DwWgradOp op;
+  op.x = (const float*)x; op.dy = (const float*)dy; op.dw = (float*)dw;
+  op.H = d->H; op.W = d->W; op.C = d->Cin; op.Ho = d->Ho; op.Wo = d->Wo; op.stride = d->stride; op.dil = d->dilation;
+  op.pad_t = d->pad_t; op.pad_l = d->pad_l; op.x_ld = d->x_ld ? d->x_ld : d->Cin; op.y_ld = d->y_ld ? d->y_ld : d->Cout;
+  op.pre_relu = pre_relu;
+  op.fd_w = make_fastdiv((uint32_t)d->Wo); op.fd_h = make_fastdiv((uint32_t)d->Ho);
+  const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
+  const bool vec = (op.C % 4 == 0) && (op.x_ld % 4 == 0) && (op.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy);
+  const SegPlan pl = seg_plan<9>(ctx->num_cus, 1, rows, op.C, vec);
+  if (!ws || ws_bytes < pl.part_bytes) {
+    sg_set_error("sg_dwconv2d_wgrad: workspace %zu < %zu", ws_bytes, pl.part_bytes);
+    return SG_EWORKSPACE;
+  }
+  return seg_reduce_launch(op, pl, 1, rows, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad");
+}
+
+int sg_maxpool_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride, int pad_t,
+                   int pad_l, int Ho, int Wo, const void* x, void* y) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32 && x && y, "sg_maxpool_fwd: bad argument");
+  SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && Ho > 0 && Wo > 0 && pad_t >= 0 && pad_l >= 0,
+               "sg_maxpool_fwd: bad geometry");
+  SG_CHECK_ARG((int64_t)N * H * W * C < (1ll << 31), "sg_maxpool_fwd: tensor exceeds 2^31 elements");
+  PoolParams p;
+  p.x = (const float*)x; p.y = nullptr; p.dy = nullptr; p.out = (float*)y;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const int V = vec ? 4 : 1;
+  p.fd_cv = make_fastdiv((uint32_t)(C / V)); p.fd_w = make_fastdiv((uint32_t)Wo); p.fd_h = make_fastdiv((uint32_t)Ho);
+  const unsigned blocks = ew_blocks((int64_t)N * Ho * Wo * (C / V));
+  if (vec) hipLaunchKernelGGL((maxpool_fwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((maxpool_fwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  SG_LAUNCH_CHECK("maxpool_fwd_kernel");
+  return 0;
+}
+
+int sg_maxpool_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride, int pad_t,
+                   int pad_l, int Ho, int Wo, const void* x, const void* y, const void* dy, void* dx) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32 && x && y && dy && dx, "sg_maxpool_bwd: bad argument");
+  SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && Ho > 0 && Wo > 0 && pad_t >= 0 && pad_l >= 0,
+               "sg_maxpool_bwd: bad geometry");
+  SG_CHECK_ARG((int64_t)N * H * W * C < (1ll << 31), "sg_maxpool_bwd: tensor exceeds 2^31 elements");
+  PoolParams p;
+  p.x = (const float*)x; p.y = (const float*)y; p.dy = (const float*)dy; p.out = (float*)dx;
+  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+  const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y) && sg_aligned16(dy) && sg_aligned16(dx);
+  const int V = vec ? 4 : 1;
+  p.fd_cv = make_fastdiv((uint32_t)(C / V)); p.fd_w = make_fastdiv((uint32_t)W); p.fd_h = make_fastdiv((uint32_t)H);
+  const unsigned blocks = ew_blocks((int64_t)N * H * W * (C / V));
+  if (vec) hipLaunchKernelGGL((maxpool_bwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  SG_LAUNCH_CHECK("maxpool_bwd_kernel");
+  return 0;
+}
+
+size_t sg_avgpool_ws_bytes(const sg_ctx* ctx, int N, int H, int W, int C, int kh, int kw) {
+  if (!ctx || kh <= 0 || kw <= 0) return 0;
+  const int nseg = N * (H / kh) * (W / kw);
+  const SegPlan a = seg_plan<1>(ctx->num_cus, nseg, (int64_t)kh * kw, C, true),
+                b = seg_plan<1>(ctx->num_cus, nseg, (int64_t)kh * kw, C, false);
+  return (a.part_bytes > b.part_bytes ? a.part_bytes : b.part_bytes) + 256;
+}
+
+int sg_avgpool_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int kh, int kw, const void* x,
+                   void* y, void* ws, size_t ws_bytes) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32 && x && y, "sg_avgpool_fwd: bad argument");
+  SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && H >= kh && W >= kw, "sg_avgpool_fwd: bad geometry");
+  SG_CHECK_ARG((int64_t)N * H * W * C < (1ll << 31), "sg_avgpool_fwd: tensor exceeds 2^31 elements");
+  AvgPoolOp op;
+  op.x = (const float*)x; op.y = (float*)y; op.H = H; op.W = W; op.C = C; op.Ho = H / kh; op.Wo = W / kw; op.kh = kh; op.kw = kw;
+  op.fd_howo = make_fastdiv((uint32_t)(op.Ho * op.Wo)); op.fd_wo = make_fastdiv((uint32_t)op.Wo); op.fd_kw = make_fastdiv((uint32_t)kw);
+  const int nseg = N * op.Ho * op.Wo;
+  const bool vec = (C % 4 == 0) && sg_aligned16(x);
+  const SegPlan pl = seg_plan<1>(ctx->num_cus, nseg, (int64_t)kh * kw, C, vec);
+  if (!ws || ws_bytes < pl.part_bytes) {
+    sg_set_error("sg_avgpool_fwd: workspace %zu < %zu", ws_bytes, pl.part_bytes);
+    return SG_EWORKSPACE;
+  }
+  return seg_reduce_launch(op, pl, nseg, (int64_t)kh * kw, C, (float*)ws, (hipStream_t)stream, "avgpool_fwd");
+}
+
+int sg_avgpool_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int kh, int kw, const void* dy,
+                   void* dx, int accumulate) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32 && dy && dx, "sg_avgpool_bwd: bad argument");
+  SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && H >= kh && W >= kw, "sg_avgpool_bwd: bad geometry");
+  SG_CHECK_ARG((int64_t)N * H * W * C < (1ll << 31), "sg_avgpool_bwd: tensor exceeds 2^31 elements");
+  const bool vec = (C % 4 == 0) && sg_aligned16(dy) && sg_aligned16(dx);
+  const int V = vec ? 4 : 1;
+  const unsigned blocks = ew_blocks((int64_t)N * H * W * (C / V));
+  const FastDiv a = make_fastdiv((uint32_t)(C / V)), b = make_fastdiv((uint32_t)W), c = make_fastdiv((uint32_t)H);
+  if (vec)
+    hipLaunchKernelGGL((avgpool_bwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+                       (float*)dx, N, H, W, C, kh, kw, accumulate, a, b, c);
+  else
+    hipLaunchKernelGGL((avgpool_bwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
+                       (float*)dx, N, H, W, C, kh, kw, accumulate, a, b, c);
+  SG_LAUNCH_CHECK("avgpool_bwd_kernel");
+  return 0;
+}
+
+int sg_upsample_nearest_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int sh, int sw,
+                            const void* x, void* y, int y_ld) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32 && x && y, "sg_upsample_nearest_fwd: bad argument");
+  SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && sh > 0 && sw > 0, "sg_upsample_nearest_fwd: bad geometry");
+  if (y_ld == 0) y_ld = C;
+  SG_CHECK_ARG(y_ld >= C, "sg_upsample_nearest_fwd: y_ld < C");
+  SG_CHECK_ARG((int64_t)N * H * sh * W * sw * y_ld < (1ll << 31), "sg_upsample_nearest_fwd: tensor exceeds 2^31 elements");
+  const bool vec = (C % 4 == 0) && (y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const int V = vec ? 4 : 1;
+  const unsigned blocks = ew_blocks((int64_t)N * H * sh * W * sw * (C / V));
+  const FastDiv a = make_fastdiv((uint32_t)(C / V)), b = make_fastdiv((uint32_t)(W * sw)), c = make_fastdiv((uint32_t)(H * sh));
+  if (vec)
+    hipLaunchKernelGGL((upsample_fwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (float*)y, N, H, W, C, sh, sw, y_ld, a, b, c);
+  else
+    hipLaunchKernelGGL((upsample_fwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       (float*)y, N, H, W, C, sh, sw, y_ld, a, b, c);
+  SG_LAUNCH_CHECK("upsample_fwd_kernel");
+  return 0;
+}
+
+int sg_upsample_nearest_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int sh, int sw,
+                            const void* dy, int dy_ld, void* dx, int accumulate) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32 && dy && dx, "sg_upsample_nearest_bwd: bad argument");
+  SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && sh > 0 && sw > 0, "sg_upsample_nearest_bwd: bad geometry");
+  if (dy_ld == 0) dy_ld = C;
+  SG_CHECK_ARG(dy_ld >= C, "sg_upsample_nearest_bwd: dy_ld < C");
+  SG_CHECK_ARG((int64_t)N * H * sh * W * sw * dy_ld < (1ll << 31), "sg_upsample_nearest_bwd: tensor exceeds 2^31 elements");
+  const bool vec = (C % 4 == 0) && (dy_ld % 4 == 0) && sg_aligned16(dy) && sg_aligned16(dx);
+  const int V = vec ? 4 : 1;
+  const unsigned blocks = ew_blocks((int64_t)N * H * W * (C / V));
+  const FastDiv a = make_fastdiv((uint32_t)(C / V)), b = make_fastdiv((uint32_t)W), c = make_fastdiv((uint32_t)H);
+  if (vec)
+    hipLaunchKernelGGL((upsample_bwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, dy_ld,
+                       (float*)dx, N, H, W, C, sh, sw, accumulate, a, b, c);
+  else
+    hipLaunchKernelGGL((upsample_bwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, dy_ld,
+                       (float*)dx, N, H, W, C, sh, sw, accumulate, a, b, c);
+  SG_LAUNCH_CHECK("upsample_bwd_kernel");
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,393 @@
+"""Host-side launchers: torch CUDA tensors in, libsegengine kernels on the current HIP stream, tensors out.
+
+torch is used here only for device memory and the stream handle; all arithmetic happens in the hand-written
+HIP kernels behind the C ABI (include/segengine.h).  Activations are NHWC float32 contiguous; kernels use the
+tf.keras `get_weights()` layouts (HWIO, depthwise [kh,kw,C,1], Conv2DTranspose [kh,kw,Cout,Cin], Dense
+[in,out]).  No function here has a CPU path: a CPU tensor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, SG_F32, check
+
+
+def same_pad(in_size: int, k: int, stride: int, dilation: int = 1) -> Tuple[int, int, int]:
+    """tf `padding='same'` -> (out, pad_before, pad_after); the smaller half goes before."""
+    out = -(-in_size // stride)
+    total = max((out - 1) * stride + (k - 1) * dilation + 1 - in_size, 0)
+    before = total // 2
+    return out, before, total - before
+
+
+def conv_out_geometry(h: int, w: int, kh: int, kw: int, stride: int, dilation: int, padding: str):
+    if padding == "same":
+        ho, pt, _ = same_pad(h, kh, stride, dilation)
+        wo, pl, _ = same_pad(w, kw, stride, dilation)
+    elif padding == "valid":
+        ho = (h - (kh - 1) * dilation - 1) // stride + 1
+        wo = (w - (kw - 1) * dilation - 1) // stride + 1
+        pt = pl = 0
+    else:
+        raise ValueError(f"padding={padding!r}")
+    return ho, wo, pt, pl
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise _lib.SgError(f"{name}: expected a CUDA (HIP) tensor - this engine has no CPU path")
+    if t.dtype != torch.float32:
+        raise _lib.SgError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.SgError(f"{name}: tensor must be contiguous")
+
+
+class Engine:
+    """Per-device launcher state: the `sg_ctx`, one reusable scratch buffer and the stream to launch on."""
+
+    def __init__(self, device: int = 0):
+        if not torch.cuda.is_available():
+            raise _lib.SgError("no HIP device visible; building_detection_amd requires an MI355X (gfx950) GPU")
+        self.lib = _lib.load()
+        self.ctx = _lib.Context(device)
+        self.h = self.ctx.handle
+        self.device = torch.device("cuda", device)
+        self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+
+    # ------------------------------------------------------------------------------------------ plumbing
+    @property
+    def stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def ws(self, nbytes: int):
+        if nbytes > self._ws.numel():
+            self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+        return C.c_void_p(self._ws.data_ptr()), C.c_size_t(self._ws.numel())
+
+    def empty(self, *shape):
+        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+
+    def zeros(self, *shape):
+        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+
+    # ---------------------------------------------------------------------------------------------- conv
+    @staticmethod
+    def conv_desc(xshape, cout, kh, kw, stride=1, dilation=1, padding="same", x_ld=0, y_ld=0) -> ConvDesc:
+        n, h, w, cin = xshape
+        ho, wo, pt, pl = conv_out_geometry(h, w, kh, kw, stride, dilation, padding)
+        return ConvDesc(n, h, w, cin, cout, kh, kw, stride, dilation, pt, pl, ho, wo, x_ld, y_ld)
+
+    def conv2d_fwd(self, x, w, b=None, stride=1, dilation=1, padding="same", relu=False, out=None, desc=None):
+        _chk(x, "x"); _chk(w, "w")
+        kh, kw, cin, cout = w.shape
+        d = desc or self.conv_desc(x.shape, cout, kh, kw, stride, dilation, padding)
+        assert d.Cin == cin, (d.Cin, cin)
+        y = out if out is not None else self.empty(d.N, d.Ho, d.Wo, cout)
+        flags = (_lib.SG_EPI_BIAS if b is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
+        check(self.lib.sg_conv2d_fwd(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags),
+              "sg_conv2d_fwd")
+        return y
+
+    def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None):
+        """dx of the forward conv described by `d`; also Conv2DTranspose forward (then bias/relu apply)."""
+        _chk(dy, "dy"); _chk(w, "w")
+        dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin)
+        need = self.lib.sg_conv2d_dgrad_ws_bytes(C.byref(d))
+        wsp, wsn = self.ws(need)
+        flags = (_lib.SG_EPI_BIAS if bias is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
+        check(self.lib.sg_conv2d_dgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
+                                       flags, wsp, wsn), "sg_conv2d_dgrad")
+        return dx
+
+    def conv2d_wgrad(self, x, dy, d: ConvDesc, want_bias=True, dw=None, db=None):
+        _chk(x, "x"); _chk(dy, "dy")
+        if dw is None:
+            dw = self.empty(d.KH, d.KW, d.Cin, d.Cout)
+        if want_bias and db is None:
+            db = self.empty(d.Cout)
+        need = self.lib.sg_conv2d_wgrad_ws_bytes(self.h, C.byref(d))
+        wsp, wsn = self.ws(need)
+        check(self.lib.sg_conv2d_wgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+                                       _ptr(db) if want_bias else None, wsp, wsn), "sg_conv2d_wgrad")
+        return dw, (db if want_bias else None)
+
+    # --------------------------------------------------------------------------------------- depthwise
+    def dwconv_fwd(self, x, w, stride=1, pre_relu=False, out=None, desc=None):
+        _chk(x, "x"); _chk(w, "w")
+        kh, kw, c = w.shape[0], w.shape[1], w.shape[2]
+        d = desc or self.conv_desc(x.shape, c, kh, kw, stride, 1, "same")
+        y = out if out is not None else self.empty(d.N, d.Ho, d.Wo, c)
+        check(self.lib.sg_dwconv2d_fwd(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(y), int(pre_relu)),
+              "sg_dwconv2d_fwd")
+        return y
+
+    def dwconv_dgrad(self, dy, w, d: ConvDesc, x=None, pre_relu=False, out=None):
+        dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin)
+        check(self.lib.sg_dwconv2d_dgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(dy), _ptr(w), _ptr(x), _ptr(dx),
+                                         int(pre_relu)), "sg_dwconv2d_dgrad")
+        return dx
+
+    def dwconv_wgrad(self, x, dy, d: ConvDesc, pre_relu=False, dw=None):
+        if dw is None:
+            dw = self.empty(d.KH, d.KW, d.Cin, 1)
+        need = self.lib.sg_dwconv2d_wgrad_ws_bytes(self.h, C.byref(d))
+        wsp, wsn = self.ws(need)
+        check(self.lib.sg_dwconv2d_wgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+                                         int(pre_relu), wsp, wsn), "sg_dwconv2d_wgrad")
+        return dw
+
+    # ---------------------------------------------------------------------------------------------- BN
+    def bn_train_fwd(self, x, gamma, beta, mm, mv, relu=False, momentum=0.99, eps=1e-3, out=None):
+        _chk(x, "x")
+        c = x.shape[-1]
+        rows = x.numel() // c
+        y = out if out is not None else torch.empty_like(x)
+        mean, invstd = self.empty(c), self.empty(c)
+        wsp, wsn = self.ws(self.lib.sg_bn_ws_bytes(self.h, rows, c))
+        check(self.lib.sg_bn_train_fwd(self.h, self.stream, SG_F32, rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mm),
+                                       _ptr(mv), _ptr(y), _ptr(mean), _ptr(invstd), momentum, eps, int(relu),
+                                       int(x.dim() == 4), wsp, wsn), "sg_bn_train_fwd")
+        return y, mean, invstd
+
+    def bn_train_bwd(self, x, y, dy, gamma, mean, invstd, relu=False, out=None):
+        c = x.shape[-1]
+        rows = x.numel() // c
+        dx = out if out is not None else torch.empty_like(x)
+        dgamma, dbeta = self.empty(c), self.empty(c)
+        wsp, wsn = self.ws(self.lib.sg_bn_ws_bytes(self.h, rows, c))
+        check(self.lib.sg_bn_train_bwd(self.h, self.stream, SG_F32, rows, c, _ptr(x), _ptr(y), _ptr(dy), _ptr(gamma),
+                                       _ptr(mean), _ptr(invstd), _ptr(dx), _ptr(dgamma), _ptr(dbeta), int(relu), wsp, wsn),
+              "sg_bn_train_bwd")
+        return dx, dgamma, dbeta
+
+    def bn_infer(self, x, gamma, beta, mm, mv, relu=False, eps=1e-3, out=None):
+        _chk(x, "x")
+        c = x.shape[-1]
+        y = out if out is not None else torch.empty_like(x)
+        check(self.lib.sg_bn_infer(self.h, self.stream, SG_F32, x.numel() // c, c, _ptr(x), _ptr(gamma), _ptr(beta),
+                                   _ptr(mm), _ptr(mv), _ptr(y), eps, int(relu)), "sg_bn_infer")
+        return y
+
+    # ------------------------------------------------------------------------------------- element-wise
+    def act_fwd(self, x, act, out=None):
+        _chk(x, "x")
+        y = out if out is not None else torch.empty_like(x)
+        check(self.lib.sg_act_fwd(self.h, self.stream, SG_F32, act, x.numel(), _ptr(x), _ptr(y)), "sg_act_fwd")
+        return y
+
+    def act_bwd(self, y, dy, act, out=None, accumulate=False):
+        dx = out if out is not None else torch.empty_like(y)
+        check(self.lib.sg_act_bwd(self.h, self.stream, SG_F32, act, y.numel(), _ptr(y), _ptr(dy), _ptr(dx), int(accumulate)),
+              "sg_act_bwd")
+        return dx
+
+    def add_n(self, xs: Sequence[torch.Tensor], relu=False, out=None):
+        assert 1 <= len(xs) <= 8
+        for t in xs:
+            _chk(t, "add_n operand")
+        arr = (C.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
+        y = out if out is not None else torch.empty_like(xs[0])
+        check(self.lib.sg_add_n(self.h, self.stream, SG_F32, len(xs), arr, xs[0].numel(), _ptr(y), int(relu)), "sg_add_n")
+        return y
+
+    def copy_channels(self, src, src_off, dst, dst_off, c, accumulate=False):
+        rows = src.numel() // src.shape[-1]
+        assert rows == dst.numel() // dst.shape[-1]
+        check(self.lib.sg_copy_channels(self.h, self.stream, SG_F32, rows, c, _ptr(src), src.shape[-1], src_off, _ptr(dst),
+                                        dst.shape[-1], dst_off, int(accumulate)), "sg_copy_channels")
+        return dst
+
+    def concat(self, xs: Sequence[torch.Tensor], out=None):
+        ctot = sum(t.shape[-1] for t in xs)
+        y = out if out is not None else self.empty(*xs[0].shape[:-1], ctot)
+        off = 0
+        for t in xs:
+            self.copy_channels(t, 0, y, off, t.shape[-1])
+            off += t.shape[-1]
+        return y
+
+    def softmax2_fwd(self, z, out=None):
+        _chk(z, "z")
+        assert z.shape[-1] == 2
+        p = out if out is not None else torch.empty_like(z)
+        check(self.lib.sg_softmax2_fwd(self.h, self.stream, SG_F32, z.numel() // 2, _ptr(z), _ptr(p)), "sg_softmax2_fwd")
+        return p
+
+    def softmax2_bwd(self, p, dp, out=None):
+        dz = out if out is not None else torch.empty_like(p)
+        check(self.lib.sg_softmax2_bwd(self.h, self.stream, SG_F32, p.numel() // 2, _ptr(p), _ptr(dp), _ptr(dz)),
+              "sg_softmax2_bwd")
+        return dz
+
+    def softmax_branch_fwd(self, z):
+        n, b, c = z.shape
+        p = torch.empty_like(z)
+        check(self.lib.sg_softmax_branch_fwd(self.h, self.stream, SG_F32, n, b, c, _ptr(z), _ptr(p)), "sg_softmax_branch_fwd")
+        return p
+
+    def softmax_branch_bwd(self, p, dp):
+        n, b, c = p.shape
+        dz = torch.empty_like(p)
+        check(self.lib.sg_softmax_branch_bwd(self.h, self.stream, SG_F32, n, b, c, _ptr(p), _ptr(dp), _ptr(dz)),
+              "sg_softmax_branch_bwd")
+        return dz
+
+    # -------------------------------------------------------------------------------------------- gates
+    def bcast_mul_fwd(self, x, g, mode, out=None, accumulate=False):
+        n, h, w, c = x.shape
+        y = out if out is not None else torch.empty_like(x)
+        check(self.lib.sg_bcast_mul_fwd(self.h, self.stream, SG_F32, n, h * w, c, mode, _ptr(x), _ptr(g), _ptr(y),
+                                        int(accumulate)), "sg_bcast_mul_fwd")
+        return y
+
+    def bcast_mul_bwd(self, x, g, dy, mode, dx=None, accumulate_dx=False):
+        n, h, w, c = x.shape
+        if dx is None:
+            dx = torch.empty_like(x)
+            accumulate_dx = False
+        dg = torch.empty_like(g)
+        wsp, wsn = self.ws(self.lib.sg_bcast_mul_bwd_ws_bytes(self.h, n, h * w, c, mode))
+        check(self.lib.sg_bcast_mul_bwd(self.h, self.stream, SG_F32, n, h * w, c, mode, _ptr(x), _ptr(g), _ptr(dy), _ptr(dx),
+                                        _ptr(dg), int(accumulate_dx), wsp, wsn), "sg_bcast_mul_bwd")
+        return dx, dg
+
+    def scse_fwd(self, x, s, cl, out=None):
+        n, h, w, c = x.shape
+        y = out if out is not None else torch.empty_like(x)
+        check(self.lib.sg_scse_fwd(self.h, self.stream, SG_F32, n, h * w, c, _ptr(x), _ptr(s), _ptr(cl), _ptr(y)), "sg_scse_fwd")
+        return y
+
+    def scse_bwd(self, x, s, cl, dy):
+        n, h, w, c = x.shape
+        dx, ds, dc = torch.empty_like(x), torch.empty_like(s), torch.empty_like(cl)
+        wsp, wsn = self.ws(self.lib.sg_scse_bwd_ws_bytes(self.h, n, h * w, c))
+        check(self.lib.sg_scse_bwd(self.h, self.stream, SG_F32, n, h * w, c, _ptr(x), _ptr(s), _ptr(cl), _ptr(dy), _ptr(dx),
+                                   _ptr(ds), _ptr(dc), wsp, wsn), "sg_scse_bwd")
+        return dx, ds, dc
+
+    def bam_fwd(self, x, mc, ms, out=None):
+        n, h, w, c = x.shape
+        y = out if out is not None else torch.empty_like(x)
+        check(self.lib.sg_bam_fwd(self.h, self.stream, SG_F32, n, h * w, c, _ptr(x), _ptr(mc), _ptr(ms), _ptr(y)), "sg_bam_fwd")
+        return y
+
+    def bam_bwd(self, x, mc, ms, dy):
+        n, h, w, c = x.shape
+        dx, dmc, dms = torch.empty_like(x), torch.empty_like(mc), torch.empty_like(ms)
+        wsp, wsn = self.ws(self.lib.sg_bam_bwd_ws_bytes(self.h, n, h * w, c))
+        check(self.lib.sg_bam_bwd(self.h, self.stream, SG_F32, n, h * w, c, _ptr(x), _ptr(mc), _ptr(ms), _ptr(dy), _ptr(dx),
+                                  _ptr(dmc), _ptr(dms), wsp, wsn), "sg_bam_bwd")
+        return dx, dmc, dms
+
+    # ------------------------------------------------------------------------------------------ pooling
+    def maxpool_fwd(self, x, k, stride, padding="valid", out=None):
+        n, h, w, c = x.shape
+        if padding == "same":
+            ho, pt, _ = same_pad(h, k, stride)
+            wo, pl, _ = same_pad(w, k, stride)
+        else:
+            ho, wo, pt, pl = (h - k) // stride + 1, (w - k) // stride + 1, 0, 0
+        y = out if out is not None else self.empty(n, ho, wo, c)
+        check(self.lib.sg_maxpool_fwd(self.h, self.stream, SG_F32, n, h, w, c, k, stride, pt, pl, ho, wo, _ptr(x), _ptr(y)),
+              "sg_maxpool_fwd")
+        return y, (k, stride, pt, pl, ho, wo)
+
+    def maxpool_bwd(self, x, y, dy, geom, out=None):
+        n, h, w, c = x.shape
+        k, stride, pt, pl, ho, wo = geom
+        dx = out if out is not None else torch.empty_like(x)
+        check(self.lib.sg_maxpool_bwd(self.h, self.stream, SG_F32, n, h, w, c, k, stride, pt, pl, ho, wo, _ptr(x), _ptr(y),
+                                      _ptr(dy), _ptr(dx)), "sg_maxpool_bwd")
+        return dx
+
+    def avgpool_fwd(self, x, kh, kw, out=None):
+        n, h, w, c = x.shape
+        y = out if out is not None else self.empty(n, h // kh, w // kw, c)
+        wsp, wsn = self.ws(self.lib.sg_avgpool_ws_bytes(self.h, n, h, w, c, kh, kw))
+        check(self.lib.sg_avgpool_fwd(self.h, self.stream, SG_F32, n, h, w, c, kh, kw, _ptr(x), _ptr(y), wsp, wsn), "sg_avgpool_fwd")
+        return y
+
+    def avgpool_bwd(self, dy, xshape, kh, kw, out=None, accumulate=False):
+        n, h, w, c = xshape
+        dx = out if out is not None else self.empty(n, h, w, c)
+        check(self.lib.sg_avgpool_bwd(self.h, self.stream, SG_F32, n, h, w, c, kh, kw, _ptr(dy), _ptr(dx), int(accumulate)),
+              "sg_avgpool_bwd")
+        return dx
+
+    def upsample_fwd(self, x, sh, sw=None, out=None, out_ld=0):
+        sw = sh if sw is None else sw
+        n, h, w, c = x.shape
+        y = out if out is not None else self.empty(n, h * sh, w * sw, c)
+        check(self.lib.sg_upsample_nearest_fwd(self.h, self.stream, SG_F32, n, h, w, c, sh, sw, _ptr(x), _ptr(y), out_ld),
+              "sg_upsample_nearest_fwd")
+        return y
+
+    def upsample_bwd(self, dy, xshape, sh, sw=None, out=None, accumulate=False, dy_ld=0):
+        sw = sh if sw is None else sw
+        n, h, w, c = xshape
+        dx = out if out is not None else self.empty(n, h, w, c)
+        check(self.lib.sg_upsample_nearest_bwd(self.h, self.stream, SG_F32, n, h, w, c, sh, sw, _ptr(dy), dy_ld, _ptr(dx),
+                                               int(accumulate)), "sg_upsample_nearest_bwd")
+        return dx
+
+    # ------------------------------------------------------------------------------ loss / metrics / Adam
+    def loss_fwd(self, kind, p, y_true):
+        rows = p.numel() // 2
+        out = self.empty(1)
+        wsp, wsn = self.ws(self.lib.sg_loss_ws_bytes(self.h, rows))
+        check(self.lib.sg_loss_fwd(self.h, self.stream, kind, rows, y_true.shape[-1], _ptr(p), _ptr(y_true), _ptr(out), wsp, wsn),
+              "sg_loss_fwd")
+        return out
+
+    def loss_bwd(self, kind, p, y_true, scale=1.0, out=None):
+        dp = out if out is not None else torch.empty_like(p)
+        check(self.lib.sg_loss_bwd(self.h, self.stream, kind, p.numel() // 2, y_true.shape[-1], _ptr(p), _ptr(y_true), _ptr(dp),
+                                   float(scale)), "sg_loss_bwd")
+        return dp
+
+    def confusion_counts(self, p, y_true, out=None):
+        if out is None:
+            out = torch.zeros(4, dtype=torch.int64, device=self.device)
+        check(self.lib.sg_confusion_counts(self.h, self.stream, p.numel() // 2, y_true.shape[-1], _ptr(p), _ptr(y_true),
+                                           C.c_void_p(out.data_ptr())), "sg_confusion_counts")
+        return out
+
+    def adam_step(self, w, m, v, g, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+        check(self.lib.sg_adam_step(self.h, self.stream, w.numel(), _ptr(w), _ptr(m), _ptr(v), _ptr(g), float(lr_t), beta1,
+                                    beta2, eps, float(grad_scale)), "sg_adam_step")
+
+    # -------------------------------------------------------------------------------------- inference tail
+    def argmax_accumulate(self, p, canvas, y0, x0):
+        th, tw = p.shape[-3], p.shape[-2]
+        ch, cw = canvas.shape
+        assert canvas.dtype == torch.int8
+        check(self.lib.sg_argmax_accumulate_i8(self.h, self.stream, _ptr(p), th, tw, C.c_void_p(canvas.data_ptr()), ch, cw,
+                                               y0, x0), "sg_argmax_accumulate_i8")
+
+    def vote_ge(self, masks: Sequence[torch.Tensor], k: int):
+        arr = (C.c_void_p * len(masks))(*[m.data_ptr() for m in masks])
+        out = torch.empty_like(masks[0])
+        check(self.lib.sg_vote_ge(self.h, self.stream, len(masks), arr, masks[0].numel(), k, C.c_void_p(out.data_ptr())),
+              "sg_vote_ge")
+        return out
+
+    def fill(self, t, value=0.0):
+        check(self.lib.sg_fill_f32(self.h, self.stream, _ptr(t), t.numel(), float(value)), "sg_fill_f32")
+        return t
+
+
+_engines = {}
+
+
+def get_engine(device: int = 0) -> Engine:
+    if device not in _engines:
+        _engines[device] = Engine(device)
+    return _engines[device]

@@ -1,0 +1,250 @@
+/*
+ * segengine.h — C ABI of the MI355X (gfx950) segmentation hot-path library, libsegengine.so.
+ *
+ * The reference (A511-1103/building-detection) is 100 % Python on tf.keras; it has no FFI of its own.  The
+ * seam this library plugs into is the one TensorFlow occupies there: the numeric runtime underneath the
+ * tf.keras layer calls of predict_model/{v3plus,bam,scse,res34,hrnet}.py and the loss / metric / optimizer
+ * ops of train_model/DeepLabv3plus.py:490-623,834-837.  Every entry point below names the reference layer
+ * call (file:line, relative to the reference root) whose arithmetic it replaces.  The Python host in
+ * building_detection_amd/ binds these symbols with ctypes (building_detection_amd/_lib.py) and is the only
+ * caller; INTEGRATION.md shows the binding.
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; no C++/torch types cross the boundary.
+ *  - every function returns int: 0 = ok, <0 = SG_E* engine error, >0 = hipError_t.  sg_last_error() returns
+ *    a thread-local message for the last non-zero return on the calling thread.
+ *  - all tensor pointers are DEVICE pointers owned by the caller (they may be torch-owned storage).
+ *  - every launch takes the hipStream_t to launch on (as void*); no function synchronises, allocates or
+ *    frees device memory (so all of them are hipGraph-capturable); scratch is a caller-provided workspace
+ *    whose size the matching *_ws_bytes() query returns.
+ *  - layout is fixed: activations NHWC, conv kernels HWIO ([kh][kw][Cin][Cout]), depthwise [kh][kw][C],
+ *    Conv2DTranspose kernels [kh][kw][Cout][Cin], Dense [in][out]  (the tf.keras get_weights() layouts).
+ *  - dtype: SG_F32 everywhere in this round (the reference is fp32 end to end).  SG_BF16 is reserved.
+ *  - "pixel stride" arguments (x_ld / y_ld, in elements) let an operand be a channel slice of a wider
+ *    NHWC buffer, which is how concat is aliased away; 0 means "dense" (= its channel count).
+ */
+#ifndef SEGENGINE_H_
+#define SEGENGINE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_ABI_VERSION 1
+
+/* engine error codes (negative returns) */
+#define SG_EINVAL   (-1)  /* bad argument / unsupported shape */
+#define SG_EWORKSPACE (-2) /* workspace too small */
+#define SG_EUNSUPPORTED (-3)
+
+#define SG_F32  0
+#define SG_BF16 1
+
+/* epilogue flags for conv-like ops */
+#define SG_EPI_BIAS 1
+#define SG_EPI_RELU 2
+
+typedef struct sg_ctx sg_ctx;
+
+int sg_abi_version(void);
+const char* sg_last_error(void);
+int sg_create(int device, sg_ctx** out);
+int sg_destroy(sg_ctx* ctx);
+/* number of compute units of the ctx's device (for host-side split heuristics) */
+int sg_num_cus(const sg_ctx* ctx);
+
+/* ------------------------------------------------------------------------------------------------ conv
+ * Geometry of a forward convolution  y[N,Ho,Wo,Cout] = conv(x[N,H,W,Cin], w[KH,KW,Cin,Cout]).
+ * pad_t / pad_l are the TF "SAME" pads *before* (SURVEY.md App. B-1); pads after follow from Ho/Wo. */
+typedef struct sg_conv_desc {
+  int32_t N, H, W, Cin;
+  int32_t Cout, KH, KW;
+  int32_t stride, dilation;
+  int32_t pad_t, pad_l;
+  int32_t Ho, Wo;
+  int32_t x_ld; /* pixel stride of x  (0 = Cin)  */
+  int32_t y_ld; /* pixel stride of y  (0 = Cout) */
+} sg_conv_desc;
+
+/* Conv2D forward: implicit-GEMM on MFMA, M = N*Ho*Wo, N = Cout, K = KH*KW*Cin.
+ * Replaces tf.keras.layers.Conv2D at predict_model/v3plus.py:173,177,185,289 (incl. the ASPP / SK dilated
+ * 3x3 of :83-91,:298-300), predict_model/scse.py:52-95, predict_model/res34.py:33,54,147,156,
+ * predict_model/hrnet.py:21, and the pointwise half of SeparableConv2D (v3plus.py:187-278).
+ * flags: SG_EPI_BIAS adds bias[Cout]; SG_EPI_RELU applies max(.,0) (Conv2D(activation='relu')). */
+int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
+                  const void* w, const void* bias, void* y, int flags);
+
+/* Conv2D input gradient dx[N,H,W,Cin] (pixel stride d->x_ld) from dy[N,Ho,Wo,Cout] (pixel stride d->y_ld).
+ * The same routine is Conv2DTranspose *forward* (y_T = dgrad of the SAME conv that maps the upsampled grid
+ * back): v3plus.py:328,335, scse.py:71-89, res34.py:144 — hence the optional epilogue
+ * (bias has d->Cin entries here).  ws: sg_conv2d_dgrad_ws_bytes(d) bytes (transposed kernel). */
+size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d);
+int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
+                    const void* w, const void* bias, void* dx, int flags, void* ws, size_t ws_bytes);
+
+/* Conv2D kernel gradient dw[KH,KW,Cin,Cout] (and dbias[Cout] if non-null) = sum over N*Ho*Wo.
+ * Deterministic split-K: partial slabs in ws, then a fixed-order reduce.  ws: sg_conv2d_wgrad_ws_bytes. */
+size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d);
+int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
+                    const void* dy, void* dw, void* dbias, void* ws, size_t ws_bytes);
+
+/* Depthwise 3x3 (the first half of SeparableConv2D, depth_multiplier 1, no bias): v3plus.py:187-278.
+ * d->Cout must equal d->Cin; w is [KH][KW][C].  pre_relu folds the Activation('relu') that precedes the
+ * layer (v3plus.py:204,225,242,...) into the gather: y = dw(relu(x)); its dgrad masks by x > 0. */
+int sg_dwconv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
+                    const void* w, void* y, int pre_relu);
+int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
+                      const void* w, const void* x_for_mask, void* dx, int pre_relu);
+size_t sg_dwconv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d);
+int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
+                      const void* dy, void* dw, int pre_relu, void* ws, size_t ws_bytes);
+
+/* Dense on [rows,in] x [in,out] (+bias): bam.py channel_gate, res34.py:94,98.  Tiny GEMMs. */
+int sg_dense_fwd(sg_ctx* ctx, void* stream, int dtype, int rows, int in, int out, const void* x,
+                 const void* w, const void* bias, void* y, int flags);
+
+/* ------------------------------------------------------------------------------------- normalisation
+ * BatchNormalization, Keras defaults (momentum .99, eps 1e-3): v3plus.py:174 ... (92 sites), 2-D after
+ * Dense in bam.py / res34.py:95,99.  rows = N*H*W (or N for 2-D), C channels innermost.
+ * train_fwd: batch statistics (biased var for normalisation), y = gamma*xhat+beta (ReLU if relu!=0),
+ *   saves mean[C], invstd[C]; updates moving_mean / moving_var in place (unbiased var iff unbiased_update,
+ *   which Keras' fused 4-D path uses; the 2-D path passes 0).  ws: sg_bn_ws_bytes(rows, C).
+ * train_bwd: given dy (and y when relu was fused), produces dx, dgamma[C], dbeta[C].
+ * infer: y = gamma*(x-mm)/sqrt(mv+eps)+beta (ReLU optional). */
+size_t sg_bn_ws_bytes(const sg_ctx* ctx, int64_t rows, int C);
+int sg_bn_train_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x,
+                    const void* gamma, const void* beta, void* moving_mean, void* moving_var, void* y,
+                    void* save_mean, void* save_invstd, float momentum, float eps, int relu,
+                    int unbiased_update, void* ws, size_t ws_bytes);
+int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x,
+                    const void* y, const void* dy, const void* gamma, const void* save_mean,
+                    const void* save_invstd, void* dx, void* dgamma, void* dbeta, int relu, void* ws,
+                    size_t ws_bytes);
+int sg_bn_infer(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x,
+                const void* gamma, const void* beta, const void* moving_mean, const void* moving_var,
+                void* y, float eps, int relu);
+
+/* ------------------------------------------------------------------------------------- element-wise
+ * Activation('relu'|'sigmoid'), n-ary add, channel concat / slice copies. act: 0 relu, 1 sigmoid. */
+#define SG_ACT_RELU 0
+#define SG_ACT_SIGMOID 1
+int sg_act_fwd(sg_ctx* ctx, void* stream, int dtype, int act, int64_t n, const void* x, void* y);
+/* dx = dy * act'(.) expressed through the OUTPUT y (relu: y>0; sigmoid: y(1-y)); accumulate!=0 adds into dx */
+int sg_act_bwd(sg_ctx* ctx, void* stream, int dtype, int act, int64_t n, const void* y, const void* dy,
+               void* dx, int accumulate);
+/* y = sum_i xs[i]  (k <= 8 device pointers passed by value in a host array); relu!=0 fuses the
+ * Activation('relu') that follows a residual add (res34.py:43-44, hrnet.py:35-36). */
+int sg_add_n(sg_ctx* ctx, void* stream, int dtype, int k, const void* const* xs, int64_t n, void* y,
+             int relu);
+/* strided channel copy: dst[r, dst_off + c] (pixel stride dst_ld) (+)= src[r, src_off + c] (stride src_ld),
+ * c < C.  Used for concat forward (tf.concat, v3plus.py:306,323,...) and its backward (slice). */
+int sg_copy_channels(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* src,
+                     int src_ld, int src_off, void* dst, int dst_ld, int dst_off, int accumulate);
+/* softmax over the last axis of size 2 (Conv2D(num_classes, 1, activation='softmax'), v3plus.py:345) and
+ * its backward dz = p * (dp - sum_k dp_k p_k). */
+int sg_softmax2_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, const void* z, void* p);
+int sg_softmax2_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, const void* p, const void* dp,
+                    void* dz);
+/* Softmax(axis=-2) over the B stacked SK branch logits z[N,B,C] (v3plus.py:120-121), and backward. */
+int sg_softmax_branch_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int B, int C, const void* z,
+                          void* p);
+int sg_softmax_branch_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int B, int C, const void* p,
+                          const void* dp, void* dz);
+
+/* Broadcast multiply  y[n,h,w,c] = x[n,h,w,c] * g  with g either per (n,c) ([N,C], cSE / SK weights /
+ * attention_demo: v3plus.py:128-132,159; res34.py:104) or per (n,h,w) ([N,HW], sSE: v3plus.py:145).
+ * mode 0 = channel gate g[N,C]; mode 1 = spatial gate g[N,HW].  accumulate!=0: y += x*g (SK fusion sum).
+ * bwd: dx (+)= dy*g ; dg = reduce(dy*x) over HW (mode 0) or over C (mode 1).  ws for mode-0 dg partials. */
+int sg_bcast_mul_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int64_t HW, int C, int mode,
+                     const void* x, const void* g, void* y, int accumulate);
+size_t sg_bcast_mul_bwd_ws_bytes(const sg_ctx* ctx, int N, int64_t HW, int C, int mode);
+int sg_bcast_mul_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int64_t HW, int C, int mode,
+                     const void* x, const void* g, const void* dy, void* dx, void* dg, int accumulate_dx,
+                     void* ws, size_t ws_bytes);
+/* scSE combine  y = x * (sigmoid(s) + sigmoid(c))  with s[N,HW] spatial logits and c[N,C] channel logits
+ * (sSE_block + cSE + tf.add, v3plus.py:141-167 / scse.py:20-46); backward gives dx (from the product
+ * only), ds[N,HW], dc[N,C]. */
+int sg_scse_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int64_t HW, int C, const void* x,
+                const void* s, const void* c, void* y);
+size_t sg_scse_bwd_ws_bytes(const sg_ctx* ctx, int N, int64_t HW, int C);
+int sg_scse_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int64_t HW, int C, const void* x,
+                const void* s, const void* c, const void* dy, void* dx, void* ds, void* dc, void* ws,
+                size_t ws_bytes);
+/* BAM combine  y = x + x * sigmoid(mc[n,c] + ms[n,hw])  (BAM_attention, bam.py:57-71); backward. */
+int sg_bam_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int64_t HW, int C, const void* x,
+               const void* mc, const void* ms, void* y);
+size_t sg_bam_bwd_ws_bytes(const sg_ctx* ctx, int N, int64_t HW, int C);
+int sg_bam_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int64_t HW, int C, const void* x,
+               const void* mc, const void* ms, const void* dy, void* dx, void* dmc, void* dms, void* ws,
+               size_t ws_bytes);
+
+/* ------------------------------------------------------------------------------------------ pooling
+ * MaxPooling2D (3x3 s2 'same' v3plus.py:192; 2x2 s2 scse.py:54-66, res34.py:152,154; 2x2 window stride 4
+ * res34.py:153).  pad_t/pad_l = TF SAME pad before (0 for valid); padded cells are -inf.  The backward
+ * recomputes the argmax (first max in window scan order wins) and scatters dy into dx (dx zeroed first). */
+int sg_maxpool_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride,
+                   int pad_t, int pad_l, int Ho, int Wo, const void* x, void* y);
+int sg_maxpool_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride,
+                   int pad_t, int pad_l, int Ho, int Wo, const void* x, const void* y, const void* dy,
+                   void* dx);
+/* AveragePooling2D(pool_size=k) (stride k, valid; v3plus.py:302) and GlobalAveragePooling2D (k = H = W):
+ * y[N,H/kh,W/kw,C] (a wavefront/LDS two-stage reduce over the window; ws from sg_avgpool_ws_bytes);
+ * backward spreads dy/(kh*kw).  accumulate!=0 adds into dx. */
+size_t sg_avgpool_ws_bytes(const sg_ctx* ctx, int N, int H, int W, int C, int kh, int kw);
+int sg_avgpool_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int kh, int kw,
+                   const void* x, void* y, void* ws, size_t ws_bytes);
+int sg_avgpool_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int kh, int kw,
+                   const void* dy, void* dx, int accumulate);
+/* UpSampling2D(size=s) nearest (v3plus.py:100,304,321,341; bam.py:332; hrnet.py:105-158):
+ * y[N,H*s,W*s,C] with pixel stride y_ld (0 = C) so it can write straight into a concat buffer;
+ * backward sums each s x s block. */
+int sg_upsample_nearest_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int sh,
+                            int sw, const void* x, void* y, int y_ld);
+int sg_upsample_nearest_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int sh,
+                            int sw, const void* dy, int dy_ld, void* dx, int accumulate);
+
+/* -------------------------------------------------------------------------------- loss / metrics / Adam
+ * The three losses of train_model/DeepLabv3plus.py:490-527 on softmax probabilities p[rows,2] and
+ * y_true[rows,4] = (one-hot 2, f_edge weight, p_edge weight):
+ *   kind 0 "binary_crossentropy": a_c = y_c,                      no focal term
+ *   kind 1 focal_loss:            a_c = .5 * y_c,                 (1-p_c)^2
+ *   kind 2 edge_focal_loss:       a_c = alpha_c * w_c * y_c,      (1-p_c)^2, alpha = (.35,.65), w = y_true[2:4]
+ *   L = -(1/rows) * sum_rows sum_c a_c * f(p_c) * log(p_c + 1e-7).
+ * fwd writes the scalar loss to loss_out[0] (fixed-order two-stage reduce; ws: sg_loss_ws_bytes(rows)).
+ * bwd writes dL/dp[rows,2] scaled by grad_scale (=1 for the plain mean). y_cols = 2 or 4 (row length). */
+#define SG_LOSS_CE2 0
+#define SG_LOSS_FOCAL 1
+#define SG_LOSS_EDGE_FOCAL 2
+size_t sg_loss_ws_bytes(const sg_ctx* ctx, int64_t rows);
+int sg_loss_fwd(sg_ctx* ctx, void* stream, int kind, int64_t rows, int y_cols, const void* p,
+                const void* y_true, void* loss_out, void* ws, size_t ws_bytes);
+int sg_loss_bwd(sg_ctx* ctx, void* stream, int kind, int64_t rows, int y_cols, const void* p,
+                const void* y_true, void* dp, float grad_scale);
+/* PA / IoU / MIoU / F1_score share one confusion count (DeepLabv3plus.py:530-623): argmax of p (ties ->
+ * class 0) vs argmax of y_true[:, :2]; out[4] = int64 {TP, TN, FP, FN}, accumulated (caller zeroes). */
+int sg_confusion_counts(sg_ctx* ctx, void* stream, int64_t rows, int y_cols, const void* p,
+                        const void* y_true, void* out_i64x4);
+/* Keras-2 Adam (compile(optimizer='adam'), DeepLabv3plus.py:835) on one flat fp32
+ * parameter arena: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; w -= lr_t * m / (sqrt(v) + eps) with
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) precomputed by the host.  g is scaled by grad_scale first (1/world). */
+int sg_adam_step(sg_ctx* ctx, void* stream, int64_t n, void* w, void* m, void* v, const void* g,
+                 float lr_t, float beta1, float beta2, float eps, float grad_scale);
+
+/* ------------------------------------------------------------------------------------ inference tail
+ * predict.py:110-114: mask = argmax(p) (ties -> 0) added as int8 into the canvas window at (y0,x0) of a
+ * [CH,CW] canvas; tile is [TH,TW] probabilities p[TH*TW,2]. */
+int sg_argmax_accumulate_i8(sg_ctx* ctx, void* stream, const void* p, int TH, int TW, void* canvas,
+                            int CH, int CW, int y0, int x0);
+/* model_fuse.py:315,323: out = 255 where sum_i (masks[i] // 255) >= k else 0; masks are u8 [n]. */
+int sg_vote_ge(sg_ctx* ctx, void* stream, int nmasks, const void* const* masks, int64_t n, int k,
+               void* out_u8);
+/* fill n floats with value (workspace / gradient zeroing without leaving the stream) */
+int sg_fill_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float value);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEGENGINE_H_ */

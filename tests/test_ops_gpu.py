@@ -1,0 +1,367 @@
+"""HIP kernel parity (through the C ABI) against the CPU oracle (oracle/tfops.py) on seeded inputs.
+
+Tolerance: the north_star bar is 1e-3 absolute on fp32 outputs; these op tests hold each kernel to a much
+tighter bound, max|gpu-cpu| <= RTOL * max|cpu| with RTOL = 2e-5 (fp32 accumulation-order noise only), so
+errors cannot hide inside the end-to-end budget.  Integer outputs (confusion counts, argmax, vote) are exact.
+"""
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import tfops as T
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 2e-5
+
+
+def close(got, ref, rtol=RTOL, what=""):
+    got = got.detach().cpu().double()
+    ref = ref.detach().cpu().double()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(ref.abs().max().item(), 1e-6)
+    err = (got - ref).abs().max().item()
+    assert err <= rtol * scale, f"{what}: max err {err:.3e} vs scale {scale:.3e} (rel {err / scale:.2e})"
+
+
+def rnd(gen, *shape, lo=-1.0, hi=1.0):
+    return (torch.rand(*shape, generator=gen) * (hi - lo) + lo).float()
+
+
+CONV_CASES = [
+    # n, h, w, cin, cout, k, stride, dil, tag
+    (2, 32, 32, 2048, 256, 3, 1, 6, "aspp_d6"),
+    (1, 32, 32, 2048, 256, 3, 1, 12, "aspp_d12"),
+    (1, 32, 32, 2048, 256, 3, 1, 18, "aspp_d18"),
+    (2, 32, 32, 256, 256, 3, 1, 6, "sk_d6"),
+    (2, 16, 16, 728, 728, 1, 1, 1, "pw_728"),
+    (2, 24, 20, 3, 32, 3, 2, 1, "stem_s2"),
+    (2, 17, 19, 64, 64, 3, 2, 1, "odd_s2"),
+    (2, 16, 16, 256, 128, 1, 2, 1, "short_1x1_s2"),
+    (1, 16, 16, 45, 45, 3, 1, 4, "bam_d4_c45"),
+    (2, 16, 16, 64, 1, 1, 1, 1, "sse_cout1"),
+    (2, 16, 16, 32, 2, 1, 1, 1, "head_cout2"),
+    (2, 12, 12, 64, 2, 3, 1, 1, "res34_head"),
+    (3, 8, 8, 512, 96, 3, 1, 1, "cout96"),
+    (16, 1, 1, 256, 16, 1, 1, 1, "gap_1x1"),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[-1] for c in CONV_CASES])
+def test_conv2d_fwd_dgrad_wgrad(engine, case):
+    n, h, w, cin, cout, k, stride, dil, tag = case
+    g = torch.Generator().manual_seed(zlib.crc32(tag.encode()) % (2 ** 31))
+    x = rnd(g, n, h, w, cin)
+    wt = rnd(g, k, k, cin, cout) * (1.0 / np.sqrt(k * k * cin))
+    b = rnd(g, cout)
+    xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = T.conv2d(xr, wr, br, stride, dil, "same")
+    dy = rnd(g, *yr.shape)
+    yr.backward(dy)
+
+    xd, wd, bd, dyd = x.cuda(), wt.cuda(), b.cuda(), dy.cuda()
+    y = engine.conv2d_fwd(xd, wd, bd, stride, dil, "same")
+    close(y, yr, what=f"{tag} fwd")
+    y2 = engine.conv2d_fwd(xd, wd, bd, stride, dil, "same", relu=True)
+    close(y2, torch.relu(yr), what=f"{tag} fwd+relu")
+    d = engine.conv_desc(x.shape, cout, k, k, stride, dil, "same")
+    dx = engine.conv2d_dgrad(dyd, wd, d)
+    close(dx, xr.grad, what=f"{tag} dgrad")
+    dw, db = engine.conv2d_wgrad(xd, dyd, d)
+    close(dw, wr.grad, what=f"{tag} wgrad")
+    close(db, br.grad, what=f"{tag} bias grad")
+
+
+def test_conv2d_into_concat_slice(engine):
+    """y_ld / x_ld: a conv writing into (and reading from) a channel slice of a wider buffer."""
+    g = torch.Generator().manual_seed(7)
+    x = rnd(g, 2, 12, 12, 64)
+    wt = rnd(g, 3, 3, 32, 64) * 0.1
+    # input = channels [16,48) of x ; output = channels [64,128) of a 160-wide buffer
+    xs = x[..., 16:48].contiguous()
+    yr = T.conv2d(xs, wt, None, 1, 1, "same")
+    xd = x.cuda()
+    buf = torch.zeros(2, 12, 12, 160, device="cuda")
+    d = engine.conv_desc((2, 12, 12, 32), 64, 3, 3, 1, 1, "same", x_ld=64, y_ld=160)
+    engine.conv2d_fwd(xd.view(-1)[16:], wt.cuda(), None, out=buf.view(-1)[64:], desc=d)
+    close(buf[..., 64:128], yr, what="slice conv")
+    assert buf[..., :64].abs().max().item() == 0 and buf[..., 128:].abs().max().item() == 0
+
+
+@pytest.mark.parametrize("k,tag", [(3, "convT3"), (2, "convT2")])
+def test_conv2d_transpose(engine, k, tag):
+    g = torch.Generator().manual_seed(11 + k)
+    n, h, w, cin, cout = 2, 9, 11, 64, 32
+    x = rnd(g, n, h, w, cin)
+    wt = rnd(g, k, k, cout, cin) * 0.1
+    b = rnd(g, cout)
+    xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = T.conv2d_transpose(xr, wr, br, 2, "same")
+    dy = rnd(g, *yr.shape)
+    yr.backward(dy)
+    # forward conv F whose dgrad is this transpose: input [n,2h,2w,cout] -> [n,h,w,cin], kernel HWIO = wt
+    d = engine.conv_desc((n, 2 * h, 2 * w, cout), cin, k, k, 2, 1, "same")
+    assert (d.Ho, d.Wo) == (h, w)
+    y = engine.conv2d_dgrad(x.cuda(), wt.cuda(), d, bias=b.cuda())
+    close(y, yr, what=f"{tag} fwd")
+    yrelu = engine.conv2d_dgrad(x.cuda(), wt.cuda(), d, bias=b.cuda(), relu=True)
+    close(yrelu, torch.relu(yr), what=f"{tag} fwd relu")
+    dx = engine.conv2d_fwd(dy.cuda(), wt.cuda(), None, desc=d)
+    close(dx, xr.grad, what=f"{tag} dx")
+    dw, _ = engine.conv2d_wgrad(dy.cuda(), x.cuda(), d, want_bias=False)
+    close(dw, wr.grad, what=f"{tag} dw")
+
+
+@pytest.mark.parametrize("c,stride,pre_relu", [(728, 1, True), (128, 2, False), (45, 1, True), (256, 2, True)])
+def test_depthwise(engine, c, stride, pre_relu):
+    g = torch.Generator().manual_seed(c + stride)
+    n, h, w = 2, 14, 18
+    x = rnd(g, n, h, w, c)
+    wt = rnd(g, 3, 3, c, 1)
+    xr, wr = x.clone().requires_grad_(), wt.clone().requires_grad_()
+    yr = T.depthwise_conv2d(torch.relu(xr) if pre_relu else xr, wr, stride)
+    dy = rnd(g, *yr.shape)
+    yr.backward(dy)
+    xd, wd, dyd = x.cuda(), wt.cuda(), dy.cuda()
+    y = engine.dwconv_fwd(xd, wd, stride, pre_relu)
+    close(y, yr, what="dw fwd")
+    d = engine.conv_desc(x.shape, c, 3, 3, stride, 1, "same")
+    dx = engine.dwconv_dgrad(dyd, wd, d, x=xd, pre_relu=pre_relu)
+    close(dx, xr.grad, what="dw dgrad")
+    dw = engine.dwconv_wgrad(xd, dyd, d, pre_relu)
+    close(dw, wr.grad, what="dw wgrad")
+
+
+@pytest.mark.parametrize("shape,relu", [((4, 16, 16, 728), True), ((2, 9, 7, 45), False), ((16, 24), True),
+                                         ((2, 64, 64, 64), True)])
+def test_batchnorm(engine, shape, relu):
+    g = torch.Generator().manual_seed(sum(shape))
+    c = shape[-1]
+    x = rnd(g, *shape) * 2 + 0.7
+    gamma, beta = rnd(g, c) + 1.5, rnd(g, c)
+    mm, mv = rnd(g, c), rnd(g, c, lo=0.5, hi=2.0)
+    xr, gr, br = x.clone().requires_grad_(), gamma.clone().requires_grad_(), beta.clone().requires_grad_()
+    yr, nm, nv = T.batch_norm(xr, gr, br, mm, mv, training=True)
+    if relu:
+        yr = torch.relu(yr)
+    dy = rnd(g, *shape)
+    yr.backward(dy)
+    mmd, mvd = mm.cuda(), mv.cuda()
+    y, mean, invstd = engine.bn_train_fwd(x.cuda(), gamma.cuda(), beta.cuda(), mmd, mvd, relu=relu)
+    close(y, yr, what="bn fwd")
+    close(mmd, nm, what="moving mean")
+    close(mvd, nv, what="moving var")
+    dx, dg, db = engine.bn_train_bwd(x.cuda(), y, dy.cuda(), gamma.cuda(), mean, invstd, relu=relu)
+    close(dx, xr.grad, rtol=1e-4, what="bn dx")
+    close(dg, gr.grad, rtol=1e-4, what="bn dgamma")
+    close(db, br.grad, rtol=1e-4, what="bn dbeta")
+    yi, _, _ = T.batch_norm(x, gamma, beta, mm, mv, training=False)
+    yg = engine.bn_infer(x.cuda(), gamma.cuda(), beta.cuda(), mm.cuda(), mv.cuda(), relu=relu)
+    close(yg, torch.relu(yi) if relu else yi, what="bn infer")
+
+
+def test_activations_add_concat(engine):
+    g = torch.Generator().manual_seed(3)
+    x = rnd(g, 2, 7, 9, 36) * 3
+    for act, f in ((0, torch.relu), (1, torch.sigmoid)):
+        xr = x.clone().requires_grad_()
+        yr = f(xr)
+        dy = rnd(g, *x.shape)
+        yr.backward(dy)
+        y = engine.act_fwd(x.cuda(), act)
+        close(y, yr, what=f"act{act}")
+        dx = engine.act_bwd(y, dy.cuda(), act)
+        close(dx, xr.grad, what=f"act{act} bwd")
+    xs = [rnd(g, 2, 5, 5, 13) for _ in range(5)]
+    close(engine.add_n([t.cuda() for t in xs]), sum(xs), what="add_n")
+    close(engine.add_n([t.cuda() for t in xs[:2]], relu=True), torch.relu(xs[0] + xs[1]), what="add relu")
+    parts = [rnd(g, 2, 5, 5, c) for c in (8, 20, 3)]
+    close(engine.concat([t.cuda() for t in parts]), torch.cat(parts, -1), what="concat")
+
+
+def test_softmaxes(engine):
+    g = torch.Generator().manual_seed(5)
+    z = rnd(g, 2, 9, 9, 2) * 6
+    zr = z.clone().requires_grad_()
+    pr = torch.softmax(zr, -1)
+    dp = rnd(g, *z.shape)
+    pr.backward(dp)
+    p = engine.softmax2_fwd(z.cuda())
+    close(p, pr, what="softmax2")
+    close(engine.softmax2_bwd(p, dp.cuda()), zr.grad, what="softmax2 bwd")
+    zb = rnd(g, 3, 5, 256) * 4
+    zbr = zb.clone().requires_grad_()
+    pbr = torch.softmax(zbr, 1)
+    dpb = rnd(g, *zb.shape)
+    pbr.backward(dpb)
+    pb = engine.softmax_branch_fwd(zb.cuda())
+    close(pb, pbr, what="softmax branch")
+    close(engine.softmax_branch_bwd(pb, dpb.cuda()), zbr.grad, what="softmax branch bwd")
+
+
+@pytest.mark.parametrize("c", [64, 45, 728])
+def test_gates(engine, c):
+    g = torch.Generator().manual_seed(c)
+    n, h, w = 3, 10, 12
+    x = rnd(g, n, h, w, c)
+    dy = rnd(g, n, h, w, c)
+    # channel gate
+    gc = rnd(g, n, c)
+    xr, gr = x.clone().requires_grad_(), gc.clone().requires_grad_()
+    yr = xr * gr.view(n, 1, 1, c)
+    yr.backward(dy)
+    close(engine.bcast_mul_fwd(x.cuda(), gc.cuda(), 0), yr, what="cgate fwd")
+    dx, dg = engine.bcast_mul_bwd(x.cuda(), gc.cuda(), dy.cuda(), 0)
+    close(dx, xr.grad, what="cgate dx")
+    close(dg, gr.grad, rtol=1e-4, what="cgate dg")
+    # spatial gate
+    gs = rnd(g, n, h, w, 1)
+    xr, gr = x.clone().requires_grad_(), gs.clone().requires_grad_()
+    yr = xr * gr
+    yr.backward(dy)
+    close(engine.bcast_mul_fwd(x.cuda(), gs.cuda(), 1), yr, what="sgate fwd")
+    dx, dg = engine.bcast_mul_bwd(x.cuda(), gs.cuda(), dy.cuda(), 1)
+    close(dx, xr.grad, what="sgate dx")
+    close(dg, gr.grad, rtol=1e-4, what="sgate dg")
+    # scSE
+    s, cl = rnd(g, n, h, w, 1) * 3, rnd(g, n, c) * 3
+    xr, sr, cr = x.clone().requires_grad_(), s.clone().requires_grad_(), cl.clone().requires_grad_()
+    yr = xr * torch.sigmoid(sr) + xr * torch.sigmoid(cr).view(n, 1, 1, c)
+    yr.backward(dy)
+    close(engine.scse_fwd(x.cuda(), s.cuda(), cl.cuda()), yr, what="scse fwd")
+    dx, ds, dc = engine.scse_bwd(x.cuda(), s.cuda(), cl.cuda(), dy.cuda())
+    close(dx, xr.grad, what="scse dx")
+    close(ds, sr.grad, rtol=1e-4, what="scse ds")
+    close(dc, cr.grad, rtol=1e-4, what="scse dc")
+    # BAM
+    mc, ms = rnd(g, n, c) * 2, rnd(g, n, h, w, 1) * 2
+    xr, mcr, msr = x.clone().requires_grad_(), mc.clone().requires_grad_(), ms.clone().requires_grad_()
+    gate = torch.sigmoid(mcr.view(n, 1, 1, c) + msr)
+    yr = gate * xr + xr
+    yr.backward(dy)
+    close(engine.bam_fwd(x.cuda(), mc.cuda(), ms.cuda()), yr, what="bam fwd")
+    dx, dmc, dms = engine.bam_bwd(x.cuda(), mc.cuda(), ms.cuda(), dy.cuda())
+    close(dx, xr.grad, what="bam dx")
+    close(dmc, mcr.grad, rtol=1e-4, what="bam dmc")
+    close(dms, msr.grad, rtol=1e-4, what="bam dms")
+
+
+@pytest.mark.parametrize("k,stride,padding", [(3, 2, "same"), (2, 2, "valid"), (2, 4, "valid")])
+def test_maxpool(engine, k, stride, padding):
+    g = torch.Generator().manual_seed(k * 10 + stride)
+    x = rnd(g, 2, 16, 20, 24)
+    xr = x.clone().requires_grad_()
+    yr = T.max_pool(xr, k, stride, padding)
+    dy = rnd(g, *yr.shape)
+    yr.backward(dy)
+    y, geom = engine.maxpool_fwd(x.cuda(), k, stride, padding)
+    close(y, yr, what="maxpool fwd")
+    dx = engine.maxpool_bwd(x.cuda(), y, dy.cuda(), geom)
+    close(dx, xr.grad, what="maxpool bwd")
+
+
+def test_maxpool_odd_same(engine):
+    g = torch.Generator().manual_seed(99)
+    x = rnd(g, 1, 15, 17, 8)
+    yr = T.max_pool(x, 3, 2, "same")
+    y, _ = engine.maxpool_fwd(x.cuda(), 3, 2, "same")
+    close(y, yr, what="maxpool odd")
+
+
+@pytest.mark.parametrize("shape,kh", [((2, 32, 32, 2048), 32), ((2, 64, 64, 64), 64), ((2, 64, 64, 256), 32),
+                                       ((3, 12, 12, 45), 12)])
+def test_avgpool_gap(engine, shape, kh):
+    g = torch.Generator().manual_seed(shape[-1])
+    x = rnd(g, *shape)
+    xr = x.clone().requires_grad_()
+    yr = T.avg_pool(xr, kh)
+    dy = rnd(g, *yr.shape)
+    yr.backward(dy)
+    y = engine.avgpool_fwd(x.cuda(), kh, kh)
+    close(y, yr, what="avgpool fwd")
+    dx = engine.avgpool_bwd(dy.cuda(), shape, kh, kh)
+    close(dx, xr.grad, what="avgpool bwd")
+
+
+@pytest.mark.parametrize("s", [2, 4, 32])
+def test_upsample(engine, s):
+    g = torch.Generator().manual_seed(s)
+    x = rnd(g, 2, 3, 5, 24)
+    xr = x.clone().requires_grad_()
+    yr = T.upsample_nearest(xr, s)
+    dy = rnd(g, *yr.shape)
+    yr.backward(dy)
+    close(engine.upsample_fwd(x.cuda(), s), yr, what="up fwd")
+    close(engine.upsample_bwd(dy.cuda(), x.shape, s), xr.grad, what="up bwd")
+
+
+def _ref_loss(kind, y_true, p):
+    eps = 1e-7
+    y = y_true[..., :2]
+    if kind == 0:
+        l = y * torch.log(p + eps)
+    elif kind == 1:
+        l = torch.tensor([0.5, 0.5]) * y * (1 - p) * (1 - p) * torch.log(p + eps)
+    else:
+        l = torch.tensor([0.35, 0.65]) * y_true[..., 2:] * y * (1 - p) * (1 - p) * torch.log(p + eps)
+    return -(l[..., 0] + l[..., 1]).mean()
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_loss_and_metrics(engine, kind):
+    g = torch.Generator().manual_seed(kind)
+    n, h, w = 2, 24, 24
+    z = rnd(g, n, h, w, 2) * 4
+    p = torch.softmax(z, -1)
+    m = (torch.rand(n, h, w, generator=g) > 0.6).float()
+    yt = torch.stack([1 - m, m, 1 + (torch.rand(n, h, w, generator=g) > 0.8).float(),
+                      1 + (torch.rand(n, h, w, generator=g) > 0.8).float()], -1)
+    pr = p.clone().requires_grad_()
+    lr = _ref_loss(kind, yt, pr)
+    lr.backward()
+    pd, yd = p.cuda(), yt.cuda()
+    close(engine.loss_fwd(kind, pd, yd), lr.reshape(1), what="loss")
+    close(engine.loss_bwd(kind, pd, yd), pr.grad, what="loss bwd")
+    cnt = engine.confusion_counts(pd, yd).cpu()
+    pred = (p[..., 1] > p[..., 0]).long()
+    tru = m.long()
+    exp = torch.tensor([(pred * tru).sum(), ((1 - pred) * (1 - tru)).sum(), (pred * (1 - tru)).sum(),
+                        ((1 - pred) * tru).sum()])
+    assert torch.equal(cnt, exp)
+
+
+def test_adam(engine):
+    g = torch.Generator().manual_seed(1)
+    n = 100003
+    w, m, v, gr = rnd(g, n), rnd(g, n) * 0.1, rnd(g, n, lo=0, hi=0.01), rnd(g, n)
+    wd, md, vd = w.cuda(), m.cuda(), v.cuda()
+    t, lr, b1, b2, eps = 7, 3e-4, 0.9, 0.999, 1e-7
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)
+    engine.adam_step(wd, md, vd, gr.cuda(), lr_t)
+    m2 = b1 * m + (1 - b1) * gr
+    v2 = b2 * v + (1 - b2) * gr * gr
+    w2 = w - lr_t * m2 / (v2.sqrt() + eps)
+    close(md, m2, what="adam m")
+    close(vd, v2, what="adam v")
+    close(wd, w2, what="adam w")
+
+
+def test_inference_tail(engine):
+    g = torch.Generator().manual_seed(2)
+    p = torch.softmax(rnd(g, 1, 16, 16, 2) * 3, -1)
+    p[0, 0, 0] = torch.tensor([0.5, 0.5])  # tie -> class 0
+    canvas = torch.zeros(40, 40, dtype=torch.int8, device="cuda")
+    engine.argmax_accumulate(p.cuda(), canvas, 5, 7)
+    engine.argmax_accumulate(p.cuda(), canvas, 10, 7)
+    ref = np.zeros((40, 40), np.int8)
+    mask = (p[0, ..., 1] > p[0, ..., 0]).numpy().astype(np.int8)
+    ref[5:21, 7:23] += mask
+    ref[10:26, 7:23] += mask
+    assert np.array_equal(canvas.cpu().numpy(), ref)
+    assert canvas[5, 7].item() == 0
+    masks = [(torch.rand(50, 60, generator=g) > 0.5).to(torch.uint8) * 255 for _ in range(5)]
+    out = engine.vote_ge([m.cuda() for m in masks], 3).cpu()
+    exp = ((sum((m // 255).int() for m in masks) >= 3).to(torch.uint8) * 255)
+    assert torch.equal(out, exp)
