@@ -1,0 +1,164 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 512x512 tiles/s for one full DeepLabv3+ training step (forward + edge_focal_loss +
+metrics + backward + Adam [+ gradient all-reduce]) in fp32, batch 16 per GPU, on N MI355X (BASELINE.json
+configs[1]).  Synthetic tiles, random-init weights, inputs resident in HBM before timing.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Extra objects:
+  roofline     the north_star target kernel set = the six dilated 3x3 convs (3 ASPP + 3 SK branches) fwd +
+               dgrad + wgrad: algorithmic FLOPs (nominal 2*M*N*K, SURVEY §8d: 97.84 GFLOP/tile) divided by
+               their summed device time, measured with HIP events on the launch stream inside the timed
+               steps; peak = 157.3 TFLOP/s (fp32-in MFMA, MI355X_MICROARCH.md).
+  cpu_baseline the CPU oracle (restatement of the TF2 path; TF itself is unavailable) timed on this box's
+               host cores for the same step at a reduced batch.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MFMA_PEAK_TFLOPS = 157.3
+DILATED_GFLOP_PER_TILE = 97.84  # fwd + dgrad + wgrad of the 6 dilated convs, SURVEY.md §8d
+
+
+def cpu_baseline(threads, batch, size, steps):
+    """One oracle training step (fwd + loss + bwd + Adam) per iteration on the host cores."""
+    import torch
+    from oracle import models as M
+    from building_detection_amd.data import synthetic_batch
+    torch.set_num_threads(threads)
+    x, y = synthetic_batch(batch, size, size, seed=1103)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    P = M.Params(seed=1103)
+    times = []
+    m = v = None
+    for it in range(steps + 1):
+        t0 = time.time()
+        p = M.deeplab_v3plus(P, xt, training=True)
+        loss = M.loss_fn("edge_focal_loss", yt, p)
+        tr = P.trainable_tensors()
+        for t in tr:
+            t.grad = None
+        loss.backward()
+        if m is None:
+            m = [torch.zeros_like(t) for t in tr]
+            v = [torch.zeros_like(t) for t in tr]
+        M.adam_step(tr, [t.grad for t in tr], m, v, t=it + 1, lr=1e-3)
+        if it > 0:  # first iteration creates the parameters
+            times.append(time.time() - t0)
+    best = min(times)
+    return {"value": round(batch / best, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
+            "sample": f"CPU oracle (restated TF2 semantics, torch CPU ops) DeepLabv3+ {size}x{size} bs={batch}, "
+                      f"min of {steps} full steps (fwd+loss+bwd+Adam), {best:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (BASELINE config: 16)")
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--model", default="v3plus")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from building_detection_amd import zoo
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss, PA, IoU, MIoU, F1_score
+    from building_detection_amd.ops import get_engine
+
+    eng = get_engine(local_rank)
+    if args.model in ("v3plus", "bam"):
+        model = zoo.BUILDERS[args.model]((args.size, args.size, 3), 2, aspp_pool=args.size // 16)
+    else:
+        model = zoo.BUILDERS[args.model]((args.size, args.size, 3))
+    model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
+    if world > 1:
+        from building_detection_amd.dist import DataParallel
+        DataParallel(model)
+
+    # rank r takes tiles [16 r, 16 r + 16) of the global synthetic batch (weak scaling)
+    x, y = synthetic_batch(args.batch, args.size, args.size, seed=1103 + rank)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.from_numpy(y).cuda()
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        model.train_on_batch(xd, yd, return_device_scalars=True)
+    sync()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = model.train_on_batch(xd, yd, return_device_scalars=True)
+    sync()
+    dt = time.perf_counter() - t0
+    prof = eng.profile_end()
+    if dist is not None:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    tiles_per_s = world * args.batch * args.steps / dt
+    step_tflop = 3 * model.flops(args.batch) / 1e12  # fwd + dgrad + wgrad, nominal
+
+    if rank == 0:
+        dil_ms = prof.get("dilated_conv", 0.0) / max(args.steps, 1)
+        dil_tflop = DILATED_GFLOP_PER_TILE * args.batch / 1e3 * (args.size / 512.0) ** 2
+        achieved = dil_tflop / (dil_ms / 1e3) if dil_ms > 0 else None
+        out = {
+            "metric": "512x512 tiles/sec fwd+bwd DeepLabv3+ (full train step: fwd+loss+bwd+Adam)",
+            "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"DeepLabv3+ (v3plus.py) {args.size}x{args.size} bs={args.batch}/GPU fp32, "
+                                   f"train step, {'dp%d' % world if world > 1 else 'single GPU'}",
+                       "global_batch": world * args.batch, "model_flops_per_step_tflop": round(step_tflop, 3),
+                       "step_achieved_tflops": round(step_tflop / (ms_per_step / 1e3), 2),
+                       "final_loss": float(loss.item())},
+            "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2),
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "traffic": None,
+                         "kernel": "igemm_conv_kernel / igemm_wgrad_kernel on the 6 dilated 3x3 convs (fwd+dgrad+wgrad)",
+                         "ms_per_step": round(dil_ms, 3), "launches_per_step": prof.get("dilated_conv_launches", 0) // max(args.steps, 1)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
+            try:
+                out["cpu_baseline"] = cpu_baseline(threads, 2, args.size, 2)
+            except Exception as e:  # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

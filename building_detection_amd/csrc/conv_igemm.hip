@@ -710,6 +710,40 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   return 0;
 }
 
+static int bias_parts_for(int64_t rows) {
+  int64_t parts = sg_cdiv(rows, 256 * 8);
+  if (parts > 256) parts = 256;
+  if (parts < 1) parts = 1;
+  return (int)parts;
+}
+
+size_t sg_bias_grad_ws_bytes(const sg_ctx* ctx, int64_t rows, int C) {
+  if (!ctx) return 0;
+  return (size_t)bias_parts_for(rows) * C * sizeof(float) + 256;
+}
+
+int sg_bias_grad(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, int ld, const void* dy, void* dbias,
+                 void* ws, size_t ws_bytes) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32 && dy && dbias && rows > 0 && C > 0, "sg_bias_grad: bad argument");
+  if (ld == 0) ld = C;
+  SG_CHECK_ARG(ld >= C, "sg_bias_grad: ld < C");
+  const int parts = bias_parts_for(rows);
+  if (!ws || ws_bytes < (size_t)parts * C * sizeof(float)) {
+    sg_set_error("sg_bias_grad: workspace %zu < %zu", ws_bytes, (size_t)parts * C * sizeof(float));
+    return SG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int TX = 1;
+  while (TX < C && TX < 64) TX <<= 1;
+  const int TY = 256 / TX;
+  dim3 grid((unsigned)sg_cdiv(C, TX), (unsigned)parts);
+  hipLaunchKernelGGL(colsum_stage1_kernel, grid, dim3(TX, TY), 0, st, (const float*)dy, rows, C, ld, (float*)ws);
+  SG_LAUNCH_CHECK("colsum_stage1_kernel");
+  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)sg_cdiv(C, 64)), dim3(64), 0, st, (const float*)ws, parts, C, (float*)dbias);
+  SG_LAUNCH_CHECK("colsum_stage2_kernel");
+  return 0;
+}
+
 int sg_dense_fwd(sg_ctx* ctx, void* stream, int dtype, int rows, int in, int out, const void* x, const void* w,
                  const void* bias, void* y, int flags) {
   sg_conv_desc d = {};

@@ -50,6 +50,29 @@ def _chk(t: torch.Tensor, name: str):
         raise _lib.SgError(f"{name}: tensor must be contiguous")
 
 
+class _Timed:
+    """`with eng.timed(tag):` brackets the launches inside with two HIP events on the current stream while a
+    profile is open (eng.profile_begin()); otherwise it is free."""
+
+    __slots__ = ("eng", "tag", "a")
+
+    def __init__(self, eng, tag):
+        self.eng, self.tag, self.a = eng, tag, None
+
+    def __enter__(self):
+        if getattr(self.eng, "_prof", None) is not None and self.tag:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream(self.eng.device))
+        return self
+
+    def __exit__(self, *exc):
+        if self.a is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record(torch.cuda.current_stream(self.eng.device))
+            self.eng._prof.setdefault(self.tag, []).append((self.a, b))
+        return False
+
+
 class Engine:
     """Per-device launcher state: the `sg_ctx`, one reusable scratch buffer and the stream to launch on."""
 
@@ -71,6 +94,22 @@ class Engine:
         if nbytes > self._ws.numel():
             self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
         return C.c_void_p(self._ws.data_ptr()), C.c_size_t(self._ws.numel())
+
+    # -- in-run timing of tagged launches with HIP events recorded on the launch stream (bench.py roofline) --
+    def profile_begin(self):
+        self._prof = {}
+
+    def profile_end(self):
+        prof, self._prof = getattr(self, "_prof", None) or {}, None
+        torch.cuda.synchronize(self.device)
+        out = {}
+        for tag, evs in prof.items():
+            out[tag] = sum(a.elapsed_time(b) for a, b in evs)  # milliseconds
+            out[tag + "_launches"] = len(evs)
+        return out
+
+    def timed(self, tag):
+        return _Timed(self, tag)
 
     def empty(self, *shape):
         return torch.empty(*shape, dtype=torch.float32, device=self.device)
@@ -119,6 +158,14 @@ class Engine:
                                        _ptr(db) if want_bias else None, wsp, wsn), "sg_conv2d_wgrad")
         return dw, (db if want_bias else None)
 
+    def bias_grad(self, dy, db):
+        """db[C] = column sums of dy[..., C] (bias gradient of Conv2DTranspose / stand-alone use)."""
+        c = dy.shape[-1]
+        rows = dy.numel() // c
+        wsp, wsn = self.ws(self.lib.sg_bias_grad_ws_bytes(self.h, rows, c))
+        check(self.lib.sg_bias_grad(self.h, self.stream, SG_F32, rows, c, c, _ptr(dy), _ptr(db), wsp, wsn), "sg_bias_grad")
+        return db
+
     # --------------------------------------------------------------------------------------- depthwise
     def dwconv_fwd(self, x, w, stride=1, pre_relu=False, out=None, desc=None):
         _chk(x, "x"); _chk(w, "w")
@@ -157,11 +204,12 @@ class Engine:
                                        int(x.dim() == 4), wsp, wsn), "sg_bn_train_fwd")
         return y, mean, invstd
 
-    def bn_train_bwd(self, x, y, dy, gamma, mean, invstd, relu=False, out=None):
+    def bn_train_bwd(self, x, y, dy, gamma, mean, invstd, relu=False, out=None, dgamma=None, dbeta=None):
         c = x.shape[-1]
         rows = x.numel() // c
         dx = out if out is not None else torch.empty_like(x)
-        dgamma, dbeta = self.empty(c), self.empty(c)
+        dgamma = dgamma if dgamma is not None else self.empty(c)
+        dbeta = dbeta if dbeta is not None else self.empty(c)
         wsp, wsn = self.ws(self.lib.sg_bn_ws_bytes(self.h, rows, c))
         check(self.lib.sg_bn_train_bwd(self.h, self.stream, SG_F32, rows, c, _ptr(x), _ptr(y), _ptr(dy), _ptr(gamma),
                                        _ptr(mean), _ptr(invstd), _ptr(dx), _ptr(dgamma), _ptr(dbeta), int(relu), wsp, wsn),

@@ -1,0 +1,462 @@
+"""Model: the tf.keras.Model surface the reference's callers use, executed on MI355X.
+
+    model = Model(inputs, outputs)           predict_model/v3plus.py:347
+    model.predict(x)                         predict.py:109, train_model/DeepLabv3plus.py:815
+    model.compile(optimizer='adam', loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])   :834-837
+    model.fit_generator(generator, steps_per_epoch, epochs, callbacks, validation_data, validation_steps)  :844-849
+    model.load_weights / save_weights        predict.py:21-49, DeepLabv3plus.py:780
+    model.optimizer.lr (get/set), model.stop_training, model.summary()
+
+Execution model: the graph is static, so a training step is one forward sweep over the node list (every node
+output kept), the fused loss kernel, one reverse sweep that hands each node its output gradient and lets it
+launch its dgrad / wgrad kernels (weight gradients land directly in one flat fp32 arena), then ONE fused Adam
+launch over the whole arena.  Under data parallelism the gradient arena is all-reduced in buckets over RCCL
+(dist.py) between the reverse sweep and Adam.  All arithmetic is in libsegengine; torch supplies memory.
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from .graph import KTensor, Node, ParamSpec, collect_nodes, init_array
+from . import layers as L
+from . import losses as LS
+
+ALIGN = 4  # every parameter starts on a 16-byte boundary inside its arena
+
+
+class _Shared:
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+class LRVariable:
+    """`model.optimizer.lr`: what the reference hands to K.get_value / K.set_value (DeepLabv3plus.py:658,736)."""
+
+    def __init__(self, v):
+        self.value = float(v)
+
+    def assign(self, v):
+        self.value = float(v)
+
+    def numpy(self):
+        return np.float32(self.value)
+
+    def __float__(self):
+        return self.value
+
+    def __repr__(self):
+        return f"<lr {self.value:g}>"
+
+
+class Optimizer:
+    """Keras-2 Adam state holder (`compile(optimizer='adam')`); `lr` is what the LR callbacks set."""
+
+    def __init__(self, lr=1e-3, beta_1=0.9, beta_2=0.999, epsilon=1e-7):
+        self._lr = LRVariable(lr)
+        self.beta_1, self.beta_2, self.epsilon = beta_1, beta_2, epsilon
+        self.iterations = 0
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, v):
+        self._lr.assign(float(v))
+
+    learning_rate = lr
+
+
+class History:
+    def __init__(self):
+        self.history: Dict[str, list] = {}
+        self.epoch: List[int] = []
+
+
+class Model:
+    def __init__(self, inputs, outputs, name=None, seed: int = 1103):
+        self.inputs = [inputs] if isinstance(inputs, KTensor) else list(inputs)
+        self.outputs = [outputs] if isinstance(outputs, KTensor) else list(outputs)
+        assert len(self.inputs) == 1 and len(self.outputs) == 1, "the path's models are single-input single-output"
+        self.name = name or "model"
+        self.nodes: List[Node] = collect_nodes(self.outputs)
+        for i, n in enumerate(self.nodes):
+            n.index = i
+        self.seed = seed
+        self.stop_training = False
+        self.optimizer: Optional[Optimizer] = None
+        self.loss_kind: Optional[int] = None
+        self.metric_names: List[str] = []
+        self._rt = None
+        self._fuse()
+        self._layout_params()
+        self.dist = None  # set by dist.DataParallel
+
+    # ------------------------------------------------------------------------------------- graph passes
+    def _fuse(self):
+        """Peephole fusions that remove full-tensor passes (each is exact, not an approximation):
+        BN -> ReLU   => BN kernel applies ReLU (and masks in backward);
+        ReLU -> SeparableConv2D => depthwise gather applies ReLU (pre_relu);
+        Add -> ReLU  => add_n applies ReLU.
+        A ReLU is absorbed only if its output has exactly one consumer (or, for producers, it is the only
+        consumer of the producer's output and is not a model output)."""
+        outs = {id(t) for t in self.outputs}
+        for n in self.nodes:
+            if not isinstance(n, L._ActNode) or n.act != "relu" or n.fused_away:
+                continue
+            src = n.inputs[0]
+            prod = src.node
+            if prod is not None and len(src.consumers) == 1 and id(src) not in outs:
+                if isinstance(prod, L._BNNode) and not prod.relu:
+                    prod.relu, n.fused_away = True, True
+                    continue
+                if isinstance(prod, L._AddNode) and not prod.relu:
+                    prod.relu, n.fused_away = True, True
+                    continue
+            cons = n.output.consumers
+            if len(cons) == 1 and isinstance(cons[0], L._SepConvNode) and id(n.output) not in outs and not cons[0].pre_relu:
+                cons[0].pre_relu, n.fused_away = True, True
+
+    def _layout_params(self):
+        self.params: List[ParamSpec] = [p for n in self.nodes for p in n.params]
+        off_t = off_n = 0
+        for p in self.params:
+            if p.trainable:
+                p.offset, off_t = off_t, off_t + (p.size + ALIGN - 1) // ALIGN * ALIGN
+            else:
+                p.offset, off_n = off_n, off_n + (p.size + ALIGN - 1) // ALIGN * ALIGN
+        self._n_train, self._n_frozen = off_t, off_n
+
+    # ---------------------------------------------------------------------------------------- inspection
+    @property
+    def layers(self):
+        return self.nodes
+
+    @property
+    def trainable_weights(self):
+        return [p for p in self.params if p.trainable]
+
+    @property
+    def non_trainable_weights(self):
+        return [p for p in self.params if not p.trainable]
+
+    def count_params(self):
+        return sum(p.size for p in self.params)
+
+    def summary(self, print_fn=print):
+        print_fn(f'Model: "{self.name}"')
+        print_fn(f"{'Layer (type)':<44}{'Output Shape':<26}{'Param #':>10}")
+        for n in self.nodes:
+            print_fn(f"{n.name + ' (' + n.op + ')':<44}{str(n.output.shape):<26}{sum(p.size for p in n.params):>10}")
+        tr = sum(p.size for p in self.params if p.trainable)
+        print_fn(f"Total params: {self.count_params():,}")
+        print_fn(f"Trainable params: {tr:,}")
+        print_fn(f"Non-trainable params: {self.count_params() - tr:,}")
+
+    def flops(self, batch=1) -> int:
+        """Nominal forward FLOPs (2*MACs of conv / convT / dense), SURVEY.md §8d convention."""
+        return sum(n.flops(batch) for n in self.nodes)
+
+    # ------------------------------------------------------------------------------------------- runtime
+    def _runtime(self):
+        if self._rt is None:
+            self._rt = _Runtime(self)
+        return self._rt
+
+    def get_weights(self) -> List[np.ndarray]:
+        rt = self._runtime()
+        return [rt.param(p).detach().cpu().numpy().copy() for p in self.params]
+
+    def set_weights(self, weights: Sequence[np.ndarray]):
+        import torch
+        rt = self._runtime()
+        if len(weights) != len(self.params):
+            raise ValueError(f"set_weights: expected {len(self.params)} arrays, got {len(weights)}")
+        for p, w in zip(self.params, weights):
+            w = np.asarray(w, dtype=np.float32)
+            if tuple(w.shape) != p.shape:
+                raise ValueError(f"set_weights: {p.name} expects {p.shape}, got {w.shape}")
+            rt.param(p).copy_(torch.from_numpy(np.ascontiguousarray(w)))
+
+    def get_gradients(self) -> List[np.ndarray]:
+        """Trainable-weight gradients of the last train step / backward, in trainable_weights order."""
+        rt = self._runtime()
+        return [rt.grad(p).detach().cpu().numpy().copy() for p in self.params if p.trainable]
+
+    def save_weights(self, path):
+        from .weights_io import save_weights
+        save_weights(self, path)
+
+    def load_weights(self, path):
+        from .weights_io import load_weights
+        load_weights(self, path)
+
+    # ------------------------------------------------------------------------------------------ compile
+    def compile(self, optimizer="adam", loss=None, metrics=None, **kw):
+        if isinstance(optimizer, str):
+            if optimizer.lower() != "adam":
+                raise ValueError("the reference compiles with optimizer='adam' (DeepLabv3plus.py:835)")
+            optimizer = Optimizer()
+        self.optimizer = optimizer
+        self.loss_kind = LS.resolve_loss(loss)
+        self.metric_names = [LS.resolve_metric(m) for m in (metrics or [])]
+
+    # ------------------------------------------------------------------------------------------ predict
+    def predict(self, x, batch_size=32, verbose=0, **kw):
+        """numpy [N,H,W,3] (any float dtype; predict.py feeds float64) -> numpy float32 probabilities."""
+        import torch
+        rt = self._runtime()
+        x = np.asarray(x)
+        outs = []
+        for i in range(0, x.shape[0], batch_size):
+            xb = torch.from_numpy(np.ascontiguousarray(x[i:i + batch_size], dtype=np.float32)).to(rt.eng.device)
+            outs.append(rt.forward(xb, training=False).cpu().numpy())
+            rt.release()
+        return np.concatenate(outs, 0)
+
+    def predict_device(self, x_dev):
+        """Device tensor in, device tensor out (used by the tile pipeline and the benchmark)."""
+        rt = self._runtime()
+        y = rt.forward(x_dev, training=False)
+        rt.release()
+        return y
+
+    def __call__(self, x, training=False):
+        return self.predict_device(x) if not training else self._runtime().forward(x, True)
+
+    # ----------------------------------------------------------------------------------------- training
+    def train_on_batch(self, x, y, return_device_scalars=False):
+        """One optimisation step; x [N,H,W,3], y [N,H,W,4|2] as numpy or device tensors.
+        Returns dict(loss=..., PA=..., ...) of python floats (forces one host sync) unless
+        `return_device_scalars`."""
+        import torch
+        if self.optimizer is None or self.loss_kind is None:
+            raise RuntimeError("compile() the model before training")
+        rt = self._runtime()
+        xd, yd = rt.to_device(x), rt.to_device(y)
+        p = rt.forward(xd, training=True)
+        loss = rt.eng.loss_fwd(self.loss_kind, p, yd)
+        counts = rt.eng.confusion_counts(p, yd) if self.metric_names else None
+        dp = rt.eng.loss_bwd(self.loss_kind, p, yd, 1.0)
+        rt.backward(dp)
+        grad_scale = 1.0
+        if self.dist is not None:
+            grad_scale = self.dist.allreduce_grads(rt)
+        opt = self.optimizer
+        opt.iterations += 1
+        t = opt.iterations
+        lr_t = float(opt.lr) * math.sqrt(1.0 - opt.beta_2 ** t) / (1.0 - opt.beta_1 ** t)
+        rt.eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, lr_t, opt.beta_1, opt.beta_2, opt.epsilon, grad_scale)
+        rt.release()
+        if return_device_scalars:
+            return loss, counts
+        return self._logs(loss, counts)
+
+    def test_on_batch(self, x, y):
+        rt = self._runtime()
+        xd, yd = rt.to_device(x), rt.to_device(y)
+        p = rt.forward(xd, training=False)
+        loss = rt.eng.loss_fwd(self.loss_kind, p, yd)
+        counts = rt.eng.confusion_counts(p, yd) if self.metric_names else None
+        rt.release()
+        return self._logs(loss, counts)
+
+    def _logs(self, loss, counts):
+        logs = {"loss": float(loss.item())}
+        if counts is not None:
+            tp, tn, fp, fn = [int(v) for v in counts.cpu().tolist()]
+            m = LS.metrics_from_counts(tp, tn, fp, fn)
+            for name in self.metric_names:
+                logs[name] = m[name]
+        return logs
+
+    def fit_generator(self, generator, steps_per_epoch=None, epochs=1, verbose=1, callbacks=None,
+                      validation_data=None, validation_steps=None, initial_epoch=0, **kw):
+        """Keras-2 `fit_generator` loop (train_model/DeepLabv3plus.py:844-849): per-batch callbacks, epoch
+        logs are the MEAN of the per-batch values, validation in inference mode."""
+        callbacks = list(callbacks or [])
+        hist = History()
+        for cb in callbacks:
+            cb.set_model(self)
+        self.stop_training = False
+        for cb in callbacks:
+            cb.on_train_begin({})
+        for epoch in range(initial_epoch, epochs):
+            for cb in callbacks:
+                cb.on_epoch_begin(epoch, {})
+            sums: Dict[str, float] = {}
+            t0 = time.time()
+            for step in range(steps_per_epoch):
+                for cb in callbacks:
+                    cb.on_batch_begin(step, {})
+                x, y = next(generator)
+                logs = self.train_on_batch(x, y)
+                for k, v in logs.items():
+                    sums[k] = sums.get(k, 0.0) + v
+                for cb in callbacks:
+                    cb.on_batch_end(step, dict(logs))
+            ep_logs = {k: v / max(steps_per_epoch, 1) for k, v in sums.items()}
+            if validation_data is not None:
+                vs: Dict[str, float] = {}
+                nval = validation_steps or 1
+                for _ in range(nval):
+                    x, y = next(validation_data)
+                    for k, v in self.test_on_batch(x, y).items():
+                        vs[k] = vs.get(k, 0.0) + v
+                ep_logs.update({"val_" + k: v / nval for k, v in vs.items()})
+            if verbose:
+                msg = " - ".join(f"{k}: {v:.4f}" for k, v in ep_logs.items())
+                print(f"Epoch {epoch + 1}/{epochs} - {time.time() - t0:.1f}s - {msg}")
+            hist.epoch.append(epoch)
+            for k, v in ep_logs.items():
+                hist.history.setdefault(k, []).append(v)
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, ep_logs)
+            if self.stop_training:
+                break
+        for cb in callbacks:
+            cb.on_train_end({})
+        self.history = hist
+        return hist
+
+    def fit(self, x=None, y=None, batch_size=None, epochs=1, steps_per_epoch=None, **kw):
+        if hasattr(x, "__next__"):
+            return self.fit_generator(x, steps_per_epoch=steps_per_epoch, epochs=epochs, **kw)
+        x, y = np.asarray(x), np.asarray(y)
+        bs = batch_size or 32
+        steps = steps_per_epoch or max(x.shape[0] // bs, 1)
+
+        def gen():
+            while True:
+                for i in range(steps):
+                    yield x[i * bs:(i + 1) * bs], y[i * bs:(i + 1) * bs]
+        return self.fit_generator(gen(), steps_per_epoch=steps, epochs=epochs, **kw)
+
+
+class _Runtime:
+    """Device state of one model: arenas, saved activations, gradient bookkeeping."""
+
+    def __init__(self, model: Model):
+        import torch
+        from .ops import get_engine
+        self.torch = torch
+        self.model = model
+        dev = int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() and torch.cuda.device_count() > 1 else 0
+        self.eng = get_engine(dev)
+        e = self.eng
+        self.w_train = e.zeros(max(model._n_train, ALIGN))
+        self.g_train = e.zeros(max(model._n_train, ALIGN))
+        self.adam_m = e.zeros(max(model._n_train, ALIGN))
+        self.adam_v = e.zeros(max(model._n_train, ALIGN))
+        self.w_frozen = e.zeros(max(model._n_frozen, ALIGN))
+        rng = np.random.default_rng(model.seed)
+        host_t = np.zeros(max(model._n_train, ALIGN), np.float32)
+        host_n = np.zeros(max(model._n_frozen, ALIGN), np.float32)
+        for p in model.params:
+            a = init_array(p, rng).reshape(-1)
+            (host_t if p.trainable else host_n)[p.offset:p.offset + p.size] = a
+        self.w_train.copy_(torch.from_numpy(host_t))
+        self.w_frozen.copy_(torch.from_numpy(host_n))
+        self._pviews: Dict[int, object] = {}
+        self._gviews: Dict[int, object] = {}
+        self.values: Dict[int, object] = {}
+        self._saved: Dict[int, dict] = {}
+        self.on_node_done = None
+
+    # -- parameters ---------------------------------------------------------------------------------------
+    def param(self, p: ParamSpec):
+        v = self._pviews.get(id(p))
+        if v is None:
+            arena = self.w_train if p.trainable else self.w_frozen
+            v = arena[p.offset:p.offset + p.size].view(p.shape)
+            self._pviews[id(p)] = v
+        return v
+
+    def grad(self, p: ParamSpec):
+        v = self._gviews.get(id(p))
+        if v is None:
+            v = self.g_train[p.offset:p.offset + p.size].view(p.shape)
+            self._gviews[id(p)] = v
+        return v
+
+    def to_device(self, a):
+        torch = self.torch
+        if isinstance(a, torch.Tensor):
+            return a if a.is_cuda and a.dtype == torch.float32 else a.to(self.eng.device, torch.float32)
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.eng.device)
+
+    # -- tape ---------------------------------------------------------------------------------------------
+    def save(self, node, **kw):
+        self._saved.setdefault(id(node), {}).update(kw)
+
+    def saved(self, node):
+        return self._saved[id(node)]
+
+    def needs_grad(self, sym: KTensor) -> bool:
+        return sym.node is not None
+
+    def shared(self, t):
+        return _Shared(t)
+
+    def release(self):
+        self.values.clear()
+        self._saved.clear()
+
+    def forward(self, x, training: bool):
+        m = self.model
+        exp = m.inputs[0].shape[1:]
+        if tuple(x.shape[1:]) != tuple(exp):
+            raise ValueError(f"input shape {tuple(x.shape)} does not match the model's {(None,) + tuple(exp)}")
+        self.values = {id(m.inputs[0]): x.contiguous()}
+        for n in m.nodes:
+            xs = [self.values[id(t)] for t in n.inputs]
+            self.values[id(n.output)] = n.forward(self, xs, training)
+        return self.values[id(m.outputs[0])]
+
+    def backward(self, dout):
+        """Reverse sweep.  Gradients of a tensor with several consumers are summed with sg_add_n; a gradient
+        handed out as `_Shared` (pass-through of an Add) is never written in place."""
+        m = self.model
+        grads: Dict[int, list] = {id(m.outputs[0]): [dout, True]}
+        e = self.eng
+        hook = self.on_node_done
+        for n in reversed(m.nodes):
+            slot = grads.pop(id(n.output), None)
+            if slot is None:  # output does not influence the loss
+                if hook is not None:
+                    hook(n.index)
+                continue
+            dy = slot[0]
+            xs = [self.values[id(t)] for t in n.inputs]
+            y = self.values[id(n.output)]
+            dxs = n.backward(self, xs, y, dy)
+            for sym, g in zip(n.inputs, dxs):
+                if g is None or sym.node is None:
+                    continue
+                fresh = True
+                if isinstance(g, _Shared):
+                    g, fresh = g.t, False
+                elif g is dy:
+                    fresh = False
+                cur = grads.get(id(sym))
+                if cur is None:
+                    grads[id(sym)] = [g, fresh]
+                elif cur[1]:
+                    e.add_n([cur[0], g], out=cur[0])
+                elif fresh:
+                    e.add_n([cur[0], g], out=g)
+                    grads[id(sym)] = [g, True]
+                else:
+                    grads[id(sym)] = [e.add_n([cur[0], g]), True]
+            # this node's saved state and output gradient are dead now
+            self._saved.pop(id(n), None)
+            if hook is not None:
+                hook(n.index)  # data-parallel: launches the all-reduce of every gradient bucket now complete

@@ -91,6 +91,13 @@ size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d);
 int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
                     const void* dy, void* dw, void* dbias, void* ws, size_t ws_bytes);
 
+/* Bias gradient db[C] = column sums of dy[rows][C] (pixel stride ld, 0 = C); fixed-order two-stage reduce.
+ * Used for the bias of Conv2DTranspose (v3plus.py:328,335; scse.py:71-89; res34.py:144), whose kernel
+ * gradient comes from sg_conv2d_wgrad with the operand roles swapped. */
+size_t sg_bias_grad_ws_bytes(const sg_ctx* ctx, int64_t rows, int C);
+int sg_bias_grad(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, int ld, const void* dy,
+                 void* dbias, void* ws, size_t ws_bytes);
+
 /* Depthwise 3x3 (the first half of SeparableConv2D, depth_multiplier 1, no bias): v3plus.py:187-278.
  * d->Cout must equal d->Cin; w is [KH][KW][C].  pre_relu folds the Activation('relu') that precedes the
  * layer (v3plus.py:204,225,242,...) into the gather: y = dw(relu(x)); its dgrad masks by x > 0. */

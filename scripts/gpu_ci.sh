@@ -1,0 +1,39 @@
+#!/bin/bash
+# One GPU-box session: parity tests, smoke, bench, rocprof summary.  Every stage runs under its own timeout; a
+# stage that times out or is killed aborts the session (no further GPU step after a hang).
+#   usage: scripts/gpu_ci.sh <tag> [stages...]      stages: tests smoke bench prof pmc
+set -u
+TAG=${1:-run}; shift || true
+STAGES=${*:-"tests smoke bench prof"}
+OUT=gpurun_out/$TAG
+mkdir -p "$OUT"
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+
+run_stage() {  # name timeout cmd...
+  local name=$1 tmo=$2; shift 2
+  echo "== stage $name: $*" | tee -a "$OUT/summary.txt"
+  timeout -k 10 "$tmo" "$@" > "$OUT/$name.log" 2>&1
+  local rc=$?
+  echo "== stage $name exit $rc" | tee -a "$OUT/summary.txt"
+  tail -n 6 "$OUT/$name.log"
+  if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then
+    echo "== stage $name timed out / was killed: aborting session" | tee -a "$OUT/summary.txt"
+    exit $rc
+  fi
+  return 0
+}
+
+for s in $STAGES; do
+  case $s in
+    tests) run_stage tests 900 python -m pytest tests -m gpu -q -p no:cacheprovider ;;
+    smoke) run_stage smoke 300 python __graft_entry__.py smoke ;;
+    bench) run_stage bench 600 python bench.py --steps 6 --warmup 2 ;;
+    prof)  run_stage prof 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/rocprof" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline
+           # keep only the small summaries
+           find "$OUT/rocprof" -name '*kernel_stats*.csv' -exec cp {} "$OUT/kernel_stats.csv" \; 2>/dev/null
+           find "$OUT/rocprof" -name '*kernel_trace*.csv' -size +20M -delete 2>/dev/null ;;
+    *) echo "unknown stage $s" ;;
+  esac
+done
+echo "== done" | tee -a "$OUT/summary.txt"

@@ -1,0 +1,226 @@
+"""Host-side logic that needs no GPU: graph construction and structural known-answers of the engine's
+builders, the C-ABI library (loads, exports every symbol include/segengine.h declares), LR schedule,
+callbacks, metrics arithmetic, synthetic data, fusion pass, gradient bucketing and a world_size-2 gloo run of
+the data-parallel reducer."""
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+EXPECTED = {  # trainable, non-trainable, forward GFLOP per 512x512 tile
+    "v3plus": (64509482, 106192, 202.12), "bam": (62863400, 105770, 151.76), "scse": (34558914, 0, 406.91),
+    "res34": (38519778, 25536, 499.06), "hrnet": (9588226, 19584, 187.48)}
+
+
+@pytest.mark.parametrize("name", list(EXPECTED))
+def test_engine_graphs_match_known_answers_and_oracle_order(name):
+    from building_detection_amd import zoo
+    from oracle import models as M
+    m = zoo.BUILDERS[name]((512, 512, 3))
+    tr = sum(p.size for p in m.params if p.trainable)
+    nt = sum(p.size for p in m.params if not p.trainable)
+    assert (tr, nt) == EXPECTED[name][:2]
+    assert m.outputs[0].shape == (None, 512, 512, 2)
+    assert abs(m.flops(1) / 1e9 - EXPECTED[name][2]) < 0.01
+    P = M.Params()
+    kw = {"aspp_pool": 4} if name in ("v3plus", "bam") else {}
+    with torch.no_grad():
+        M.BUILDERS[name](P, torch.zeros(1, 64, 64, 3), **kw)
+    assert [tuple(t.shape) for t in P.tensors] == [p.shape for p in m.params]
+    assert P.kinds == [p.kind for p in m.params]
+
+
+def test_dilated_subset_flops_match_survey():
+    """3 ASPP + 3 SK dilated convs: 32.61 GFLOP fwd per tile, x3 = 97.84."""
+    from building_detection_amd import zoo, layers as L
+    m = zoo.Xception_DeepLabV3_Plus()
+    dil = [n for n in m.nodes if isinstance(n, L._ConvNode) and n._tag]
+    assert len(dil) == 6
+    f = sum(n.flops(1) for n in dil)
+    assert abs(f / 1e9 - 32.61) < 0.01 and abs(3 * f / 1e9 - 97.84) < 0.02
+
+
+def test_fusion_pass_counts():
+    from building_detection_amd import zoo, layers as L
+    m = zoo.Xception_DeepLabV3_Plus()
+    seps = [n for n in m.nodes if isinstance(n, L._SepConvNode)]
+    assert len(seps) == 62
+    # every ReLU is absorbed into a BN, an Add or a SeparableConv gather
+    assert all(n.fused_away for n in m.nodes if isinstance(n, L._ActNode) and n.act == "relu")
+    assert sum(n.pre_relu for n in seps) > 0
+    r = zoo.ResNetFamily().run_model("res34")
+    assert any(isinstance(n, L._AddNode) and n.relu for n in r.nodes)
+    with pytest.raises(ValueError, match="This network does not exist."):
+        zoo.ResNetFamily().run_model("res18")
+
+
+def test_reference_layer_names_res34():
+    from building_detection_amd import zoo
+    names = {n.name for n in zoo.ResNetFamily((64, 64, 3)).run_model("res34").nodes}
+    for want in ("conv1_1", "conv1_1_BN", "pool1", "pool4", "conv2_0_1", "conv5_2_2_BN", "conv3_3_add", "upsame_1_1"):
+        assert want in names, want
+
+
+def test_abi_library_exports_every_declared_symbol():
+    from building_detection_amd import _lib
+    import ctypes
+    hdr = open(os.path.join(ROOT, "include", "segengine.h")).read()
+    declared = set(re.findall(r"\b(sg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.exported_symbols())
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} is declared in include/segengine.h but not exported"
+    assert _lib.load().sg_abi_version() == 1
+    assert ctypes.sizeof(_lib.ConvDesc) == 15 * 4
+
+
+def test_no_cpu_fallback():
+    """Without a GPU the product refuses to compute (it must never route through the oracle or the CPU)."""
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from building_detection_amd import zoo, _lib
+    m = zoo.HRNet((64, 64, 3))
+    with pytest.raises(_lib.SgError):
+        m.predict(np.zeros((1, 64, 64, 3), np.float32))
+    src = "".join(open(os.path.join(ROOT, "building_detection_amd", f)).read()
+                  for f in os.listdir(os.path.join(ROOT, "building_detection_amd")) if f.endswith(".py"))
+    assert "import oracle" not in src and "from oracle" not in src
+
+
+def test_lr_schedule_matches_reference_formula():
+    from building_detection_amd.callbacks import cosine_decay_with_warmup as f
+    from oracle.models import cosine_decay_with_warmup as g
+    steps, total, warm = 592, 30 * 592, 3 * 592  # 4736 // 8 steps per epoch (data_enhancement.py:14, bs 8)
+    for s in (0, 1, warm - 1, warm, warm + 1, total // 2, total - 1, total):
+        assert f(s, 1e-3, total, 1e-5, warm, 0) == g(s, 1e-3, total, 1e-5, warm, 0)
+    assert f(0, 1e-3, total, 1e-5, warm) == 1e-5
+    assert abs(f(warm, 1e-3, total, 1e-5, warm) - 1e-3) < 1e-18
+    assert f(total, 1e-3, total, 1e-5, warm) < 1e-18
+
+
+def test_callbacks_drive_optimizer_lr(tmp_path):
+    from building_detection_amd.callbacks import (WarmUpCosineDecayScheduler, MY_EarlyStoppingAtMinLoss, backend as K,
+                                                  cosine_decay_with_warmup)
+    from building_detection_amd.runtime import Optimizer
+
+    class FakeModel:
+        def __init__(self):
+            self.optimizer = Optimizer()
+            self.saved = []
+
+        def save_weights(self, p):
+            self.saved.append(p)
+
+    fm = FakeModel()
+    cb = WarmUpCosineDecayScheduler(1e-3, total_steps=100, warmup_learning_rate=1e-5, warmup_steps=10)
+    cb.set_model(fm)
+    for step in range(15):
+        cb.on_batch_begin(step)
+        assert K.get_value(fm.optimizer.lr) == cosine_decay_with_warmup(step, 1e-3, 100, 1e-5, 10)
+        cb.on_batch_end(step)
+    assert len(cb.learning_rates) == 15
+    K.set_value(fm.optimizer.lr, 0.5)  # the reference's spelling (DeepLabv3plus.py:736)
+    assert float(fm.optimizer.lr) == 0.5
+    es = MY_EarlyStoppingAtMinLoss(6, directory=str(tmp_path / "weights1"))
+    es.set_model(fm)
+    es.on_train_begin()
+    es.on_epoch_end(0, {"val_PA": 0.9})
+    assert fm.saved[0].endswith("epoch_1_weights.h5") and es.all_acc == [0.9]
+
+
+def test_metrics_float32_arithmetic():
+    from building_detection_amd.losses import metrics_from_counts, resolve_loss, resolve_metric, edge_focal_loss
+    from oracle.models import metrics_from_counts as ref
+    for c in ((10, 20, 3, 4), (0, 100, 0, 0), (1234567, 7654321, 1111, 2222)):
+        a, b = metrics_from_counts(*c), ref(*c)
+        for k in a:
+            assert abs(a[k] - b[k]) < 1e-7
+    assert metrics_from_counts(0, 5, 0, 0)["IoU"] == 0.0
+    assert resolve_loss(edge_focal_loss) == 2 and resolve_loss("focal_loss") == 1
+
+    def binary_crossentropy(y_true, y_pred):  # a reference-style callable is recognised by name
+        pass
+    assert resolve_loss(binary_crossentropy) == 0
+    assert resolve_metric("MIoU") == "MIoU"
+    with pytest.raises(ValueError):
+        resolve_loss("mse")
+
+
+def test_synthetic_batch_label_channels():
+    from building_detection_amd.data import synthetic_batch, edge_weight_channels
+    x, y = synthetic_batch(2, 64, 64, seed=1)
+    assert x.shape == (2, 64, 64, 3) and y.shape == (2, 64, 64, 4) and x.dtype == np.float32
+    assert x.min() >= -1 and x.max() <= 1
+    np.testing.assert_array_equal(y[..., 0] + y[..., 1], 1)
+    assert set(np.unique(y[..., 2:])) <= {1.0, 2.0}
+    m = np.zeros((32, 32), np.float32)
+    m[8:24, 8:24] = 1
+    f_edge, p_edge = edge_weight_channels(m)
+    # 5 erosions of a 16x16 square leave its 6x6 core: the inner 5-px rim has weight 2 (p_edge), the outer 5-px ring f_edge
+    assert p_edge[8, 8] == 2 and p_edge[12, 12] == 2 and p_edge[13, 13] == 1 and p_edge[0, 0] == 1
+    assert f_edge[7, 7] == 2 and f_edge[3, 3] == 2 and f_edge[2, 2] == 1 and f_edge[10, 10] == 1
+
+
+def test_bucket_planner_covers_arena():
+    from building_detection_amd.dist import plan_buckets
+    from building_detection_amd import zoo
+    m = zoo.Xception_DeepLabV3_Plus()
+    ranges = [(n.index, p.offset, (p.size + 3) // 4 * 4) for n in m.nodes for p in n.params if p.trainable]
+    total = m._n_train
+    b = plan_buckets(ranges, total, 12 << 20)
+    assert b[0][0] == 0 and b[-1][1] == total
+    for (s0, e0, _), (s1, e1, _) in zip(b, b[1:]):
+        assert e0 == s1 and e1 > s1
+    assert 4 <= len(b) <= 8
+    # a bucket becomes ready no later than the node owning its first parameter
+    for s, e, ready in b:
+        first = min(ni for ni, off, sz in ranges if s <= off < e)
+        assert ready == first
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from building_detection_amd.dist import BucketReducer, plan_buckets
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n = 1000
+    g = torch.Generator().manual_seed(100 + rank)
+    arena = torch.rand(n, generator=g)
+    mine = arena.clone()
+    ranges = [(i, i * 100, 100) for i in range(10)]  # 10 "layers" of 100 elements
+    red = BucketReducer(arena, plan_buckets(ranges, n, 250))
+    launched = []
+    for node in reversed(range(10)):  # backward sweep
+        before = red.next
+        red.node_done(node)
+        launched.append(red.next - before)
+    red.finish()
+    others = [torch.rand(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+    ok = torch.allclose(arena, sum(others), atol=1e-6)
+    q.put((rank, bool(ok), launched, float((arena - mine).abs().max())))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_reducer_gloo_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, launched, delta in res:
+        assert ok, f"rank {rank}: all-reduced arena is not the sum of the per-rank arenas"
+        # buckets [900,1000) [600,900) [300,600) [0,300) fire as the sweep passes nodes 9, 6, 3, 0 - not all at the end
+        assert launched == [1, 0, 0, 1, 0, 0, 1, 0, 0, 1]
+        assert delta > 0
