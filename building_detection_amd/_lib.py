@@ -103,6 +103,9 @@ def load():
     with _lock:
         if _lib is not None:
             return _lib
+        # torch must be imported first: it brings its own HIP runtime (libamdhip64) and a second copy loaded
+        # ahead of it by this library would not see the device torch allocates on.
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise SgError(
                 f"{LIB_PATH} is missing - build it with `make -C building_detection_amd/csrc` "

@@ -52,21 +52,34 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
   }
 }
 
+// Second stage: a 64 (channels) x 4 (split lanes) block adds the S partial rows of its channels in fp64 — each
+// lane a fixed subset z = lane, lane+4, ..., the four lane sums combined in fixed order through LDS — and
+// hands the NOUT totals of each channel to op.finalize.  Reads are coalesced along C.
 template <class Op>
-__global__ void seg_finalize_kernel(const Op op, const int nseg, const int C, const int S,
-                                    const float* __restrict__ part) {
+__global__ __launch_bounds__(256) void seg_finalize_kernel(const Op op, const int nseg, const int C, const int S,
+                                                           const float* __restrict__ part) {
   constexpr int NO = Op::NOUT;
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (int64_t)nseg * C) return;
-  const int seg = (int)(idx / C), c = (int)(idx - (int64_t)seg * C);
+  __shared__ double red[4][64][NO];
+  const int tx = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + tx, seg = blockIdx.y;
   double s[NO];
 #pragma unroll
-  for (int o = 0; o < NO; ++o) {
-    double t = 0.0;
-    for (int z = 0; z < S; ++z) t += (double)part[(((int64_t)seg * S + z) * NO + o) * C + c];
-    s[o] = t;
+  for (int o = 0; o < NO; ++o) s[o] = 0.0;
+  if (c < C) {
+    for (int z = zl; z < S; z += 4) {
+      const float* p = part + (((int64_t)seg * S + z) * NO) * C + c;
+#pragma unroll
+      for (int o = 0; o < NO; ++o) s[o] += (double)p[(int64_t)o * C];
+    }
   }
-  op.finalize(seg, c, s);
+#pragma unroll
+  for (int o = 0; o < NO; ++o) red[zl][tx][o] = s[o];
+  __syncthreads();
+  if (zl == 0 && c < C) {
+#pragma unroll
+    for (int o = 0; o < NO; ++o) s[o] = ((red[0][tx][o] + red[1][tx][o]) + red[2][tx][o]) + red[3][tx][o];
+    op.finalize(seg, c, s);
+  }
 }
 
 struct SegPlan {
@@ -79,15 +92,17 @@ static inline SegPlan seg_plan(int num_cus, int nseg, int64_t rows, int C, bool 
   SegPlan pl;
   pl.V = (vec_ok && C % 4 == 0) ? 4 : 1;
   const int chunks = C / pl.V;
+  // 16 lanes x 16 B = one 256-byte run per row; narrow blocks keep gx (and so the block count) high without
+  // a large row split S, which the second stage would have to add up again
   int tx = 1;
-  while (tx < chunks && tx < 64) tx <<= 1;
+  while (tx < chunks && tx < 16) tx <<= 1;
   pl.TX = tx;
   pl.TY = 256 / tx;
   pl.gx = (int)sg_cdiv(chunks, tx);
   int64_t S = sg_cdiv((int64_t)4 * num_cus, (int64_t)pl.gx * nseg);
   const int64_t maxS = sg_cdiv(rows, (int64_t)pl.TY * 4);
   if (S > maxS) S = maxS;
-  if (S > 1024) S = 1024;
+  if (S > 256) S = 256;
   if (S < 1) S = 1;
   pl.S = (int)S;
   pl.part_bytes = (size_t)nseg * pl.S * NOUT * C * sizeof(float);
@@ -106,9 +121,8 @@ static inline int seg_reduce_launch(const Op& op, const SegPlan& pl, int nseg, i
   else
     hipLaunchKernelGGL((seg_reduce_kernel<Op, 1>), grid, block, lds, st, op, rows, C, pl.S, part);
   SG_LAUNCH_CHECK(name);
-  const int64_t n = (int64_t)nseg * C;
-  hipLaunchKernelGGL((seg_finalize_kernel<Op>), dim3((unsigned)sg_cdiv(n, 256)), dim3(256), 0, st, op, nseg, C, pl.S,
-                     (const float*)part);
+  hipLaunchKernelGGL((seg_finalize_kernel<Op>), dim3((unsigned)sg_cdiv(C, 64), (unsigned)nseg), dim3(256), 0, st, op, nseg,
+                     C, pl.S, (const float*)part);
   SG_LAUNCH_CHECK(name);
   return 0;
 }

@@ -1,10 +1,13 @@
 """Whole-model parity on the GPU: engine (HIP kernels through the C ABI) vs the CPU oracle (oracle/models.py)
 on identical seeded inputs and weights.
 
-Bars (north_star): softmax probabilities within 1e-3 absolute in fp32 (asserted at 2e-4 here), argmax masks
-identical except on numerical near-ties (|p1-p0| below the probability error itself), loss to 1e-5 relative,
-every weight gradient to 2e-3 of that tensor's max |grad| (fp32 accumulation order over up to 10^6-term
-reductions), BN moving statistics and post-Adam weights to 1e-5/1e-4.
+fp32 results of two different-but-correct implementations differ by accumulation-order noise that grows with
+depth, so each check has two parts: the hard bar of `north_star` (probabilities within 1e-3 absolute; argmax
+masks identical except where the oracle's own margin |p1-p0| is inside the numerical error), and a relative
+bar against an fp64 run of the same oracle — the GPU's fp32 error vs fp64 must be within a small factor of the
+CPU-fp32 oracle's own error vs fp64 (i.e. the HIP path is as accurate as a CPU fp32 path, not merely "close").
+Gradients whose true value is structurally zero (a conv bias that feeds BatchNorm) are compared against that
+noise floor, not against their own magnitude.
 """
 import numpy as np
 import pytest
@@ -30,11 +33,18 @@ def build(name, size, kw):
     return zoo.BUILDERS[name]((size, size, 3))
 
 
-def mask_agreement(pg, pc):
-    mg, mc = pg[..., 1] > pg[..., 0], pc[..., 1] > pc[..., 0]
-    diff = mg != mc
-    margin = np.abs(pc[..., 1] - pc[..., 0])
-    return int(diff.sum()), float(margin[diff].max()) if diff.any() else 0.0
+def oracle_infer(name, ws, x, kw, dtype):
+    P = M.Params(weights=ws, dtype=dtype)
+    with torch.no_grad():
+        return M.BUILDERS[name](P, torch.from_numpy(x).to(dtype), training=False, **kw).double().numpy()
+
+
+def oracle_train(name, ws, x, y, kw, dtype):
+    P = M.Params(weights=ws, dtype=dtype)
+    p = M.BUILDERS[name](P, torch.from_numpy(x).to(dtype), training=True, **kw)
+    loss = M.loss_fn("edge_focal_loss", torch.from_numpy(y).to(dtype), p)
+    loss.backward()
+    return P, p.detach(), loss.item(), [t.grad.double().numpy() for t in P.trainable_tensors()]
 
 
 @pytest.mark.parametrize("name,size,kw", CASES, ids=[c[0] for c in CASES])
@@ -42,7 +52,7 @@ def test_inference_parity(engine, name, size, kw):
     from building_detection_amd.data import synthetic_batch
     model = build(name, size, kw)
     x, _ = synthetic_batch(2, size, size, seed=11)
-    # make BN moving statistics non-trivial so inference-mode BN is really exercised
+    # make BN moving statistics / biases non-trivial so inference-mode BN is really exercised
     ws = model.get_weights()
     rng = np.random.default_rng(5)
     for i, p in enumerate(model.params):
@@ -55,14 +65,21 @@ def test_inference_parity(engine, name, size, kw):
     model.set_weights(ws)
     pg = model.predict(x.astype(np.float64))  # predict.py feeds float64
     assert pg.dtype == np.float32 and pg.shape == (2, size, size, 2)
-    P = M.Params(weights=ws)
-    with torch.no_grad():
-        pc = M.BUILDERS[name](P, torch.from_numpy(x), training=False, **kw).numpy()
-    err = float(np.abs(pg - pc).max())
-    assert err <= 2e-4, f"{name}: max |p_gpu - p_cpu| = {err:.3e}"
-    ndiff, margin = mask_agreement(pg, pc)
-    assert ndiff == 0 or margin <= 2 * err + 1e-6, f"{name}: {ndiff} mask pixels differ with margin {margin:.3e} (err {err:.3e})"
     np.testing.assert_allclose(pg.sum(-1), 1.0, atol=1e-5)
+    p32 = oracle_infer(name, ws, x, kw, torch.float32)
+    p64 = oracle_infer(name, ws, x, kw, torch.float64)
+    err_gpu32 = float(np.abs(pg - p32).max())
+    err_gpu64 = float(np.abs(pg - p64).max())
+    err_cpu64 = float(np.abs(p32 - p64).max())
+    print(f"{name}: |gpu-cpu32|={err_gpu32:.2e} |gpu-fp64|={err_gpu64:.2e} |cpu32-fp64|={err_cpu64:.2e}")
+    assert err_gpu32 <= 1e-3, f"{name}: north_star bar: max |p_gpu - p_cpu| = {err_gpu32:.3e} > 1e-3"
+    assert err_gpu64 <= 4 * err_cpu64 + 1e-4, f"{name}: gpu fp32 error {err_gpu64:.3e} vs cpu fp32 error {err_cpu64:.3e}"
+    mg, mc = pg[..., 1] > pg[..., 0], p64[..., 1] > p64[..., 0]
+    diff = mg != mc
+    if diff.any():
+        margin = float(np.abs(p64[..., 1] - p64[..., 0])[diff].max())
+        assert margin <= 2 * err_gpu64 + 1e-7, f"{name}: {int(diff.sum())} mask pixels differ outside near-ties (margin {margin:.3e})"
+    print(f"{name}: argmax masks differ on {int(diff.sum())} of {diff.size} pixels (near-ties only)")
 
 
 @pytest.mark.parametrize("name,size,kw", CASES, ids=[c[0] for c in CASES])
@@ -75,59 +92,52 @@ def test_train_step_parity(engine, name, size, kw):
     model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
     model.optimizer.lr = 1e-3
     logs = model.train_on_batch(x, y)
-    grads_g = model.get_gradients()
+    grads_g = [g.astype(np.float64) for g in model.get_gradients()]
     ws1 = model.get_weights()
 
-    P = M.Params(weights=ws0)
-    pc = M.BUILDERS[name](P, torch.from_numpy(x), training=True, **kw)
-    loss = M.loss_fn("edge_focal_loss", torch.from_numpy(y), pc)
-    loss.backward()
-    tr = P.trainable_tensors()
-    assert len(tr) == len(grads_g)
-    assert abs(logs["loss"] - loss.item()) <= 1e-5 * max(abs(loss.item()), 1e-3), (logs["loss"], loss.item())
-    cm = M.metrics_from_counts(*M.confusion(torch.from_numpy(y), pc.detach()))
+    P32, p32, loss32, g32 = oracle_train(name, ws0, x, y, kw, torch.float32)
+    _, _, loss64, g64 = oracle_train(name, ws0, x, y, kw, torch.float64)
+    assert len(g64) == len(grads_g)
+    assert abs(logs["loss"] - loss64) <= 5 * abs(loss32 - loss64) + 1e-5 * abs(loss64), (logs["loss"], loss32, loss64)
+    cm = M.metrics_from_counts(*M.confusion(torch.from_numpy(y), p32))
     for k in ("PA", "IoU", "MIoU", "F1_score"):
         assert abs(logs[k] - cm[k]) <= 2e-3, (k, logs[k], cm[k])  # a near-tie pixel may flip a count
 
-    worst = (0.0, None)
     names = [p.name for p in model.params if p.trainable]
-    for nm, gg, t in zip(names, grads_g, tr):
-        gc = t.grad.numpy()
-        scale = max(float(np.abs(gc).max()), 1e-12)
-        rel = float(np.abs(gg - gc).max()) / scale
-        if rel > worst[0]:
-            worst = (rel, nm)
-    assert worst[0] <= 2e-3, f"{name}: worst gradient mismatch {worst[0]:.3e} at {worst[1]}"
+    gscale = max(float(np.abs(g).max()) for g in g64)
+    worst = (0.0, None, None)
+    for nm, gg, gc, gt in zip(names, grads_g, g32, g64):
+        scale = float(np.abs(gt).max())
+        e_gpu, e_cpu = float(np.abs(gg - gt).max()), float(np.abs(gc - gt).max())
+        bound = 5 * e_cpu + 2e-4 * scale + 1e-6 * gscale
+        ratio = e_gpu / bound
+        if ratio > worst[0]:
+            worst = (ratio, nm, (e_gpu, e_cpu, scale))
+    print(f"{name}: worst gradient error/bound = {worst[0]:.3f} at {worst[1]} (e_gpu, e_cpu32, scale) = {worst[2]}")
+    assert worst[0] <= 1.0, f"{name}: gradient of {worst[1]} off: (e_gpu, e_cpu32, scale) = {worst[2]}"
 
     # BN moving statistics after the training forward
     for i, p in enumerate(model.params):
         if not p.trainable:
-            np.testing.assert_allclose(ws1[i], P.tensors[i].detach().numpy(), rtol=1e-4, atol=1e-5, err_msg=p.name)
-    # one Keras-Adam step on the oracle side, compared with the engine's fused Adam
+            np.testing.assert_allclose(ws1[i], P32.tensors[i].detach().numpy(), rtol=1e-4, atol=1e-5, err_msg=p.name)
+    # one Keras-Adam step on the oracle side vs the engine's fused Adam.  The first Adam step is
+    # lr*g/(|g| + ~3e-6): compare where the gradient is well above that knee in both.
+    tr = P32.trainable_tensors()
     m = [torch.zeros_like(t) for t in tr]
     v = [torch.zeros_like(t) for t in tr]
     M.adam_step(tr, [t.grad for t in tr], m, v, t=1, lr=1e-3)
-    k = 0
-    bad = 0.0
+    k, worst_w, checked = 0, 0.0, 0
     for i, p in enumerate(model.params):
         if p.trainable:
-            # first Adam step moves every weight by ~lr*sign(g); compare the step, not just the weight
-            step_g = ws1[i] - ws0[i]
-            step_c = tr[k].detach().numpy() - ws0[i]
-            bad = max(bad, float(np.abs(step_g - step_c).max()))
-            k += 1
-    # weights whose gradient is ~0 can flip sign of the normalised step; bound by 2*lr and require the bulk to match
-    assert bad <= 2.1e-3
-    agree = []
-    k = 0
-    for i, p in enumerate(model.params):
-        if p.trainable:
-            g = tr[k].grad.numpy()
-            big = np.abs(g) > 1e-3 * max(float(np.abs(g).max()), 1e-12)
+            big = np.abs(g64[k]) > 1e-4
             if big.any():
-                agree.append(float(np.abs((ws1[i] - tr[k].detach().numpy()))[big].max()))
+                checked += int(big.sum())
+                worst_w = max(worst_w, float(np.abs(ws1[i] - tr[k].detach().numpy())[big].max()))
+            step = np.abs(ws1[i] - ws0[i])
+            assert float(step.max()) <= 1.0001e-3, f"{p.name}: first Adam step larger than lr"
             k += 1
-    assert max(agree) <= 2e-5, f"post-Adam weights differ by {max(agree):.3e}"
+    assert checked > 1000, f"only {checked} weights had a gradient above the Adam knee"
+    assert worst_w <= 2e-5, f"post-Adam weights differ by {worst_w:.3e}"
 
 
 def test_weights_roundtrip_and_errors(engine, tmp_path):

@@ -1,0 +1,71 @@
+"""predict.py tile loop + model_fuse.py vote on the engine vs their CPU restatement (oracle/pipeline.py)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import pipeline as OP
+from oracle import tfops as T
+
+pytestmark = pytest.mark.gpu
+
+
+def tiny_model():
+    """A 512x512 two-layer segmentation net: enough to drive the pipeline cheaply on both sides."""
+    from building_detection_amd import layers as L
+    from building_detection_amd.runtime import Model
+    inp = L.Input((512, 512, 3))
+    x = L.Conv2D(8, 3, padding="same", activation="relu")(inp)
+    x = L.Conv2D(8, 3, padding="same", dilation_rate=3, activation="relu")(x)
+    out = L.Conv2D(2, 1, activation="softmax")(x)
+    return Model(inp, out, name="tiny", seed=4)
+
+
+def oracle_predict_fn(ws):
+    w = [torch.tensor(a, dtype=torch.float64) for a in ws]
+
+    def fn(tile):
+        with torch.no_grad():
+            x = torch.from_numpy(np.asarray(tile, dtype=np.float64))
+            x = torch.relu(T.conv2d(x, w[0], w[1]))
+            x = torch.relu(T.conv2d(x, w[2], w[3], dilation=3))
+            return torch.softmax(T.conv2d(x, w[4], w[5]), -1).numpy()
+    return fn
+
+
+@pytest.mark.parametrize("h,w", [(512, 512), (700, 640), (400, 300), (600, 1000)])
+def test_detection_matches_reference_loop(engine, h, w):
+    from building_detection_amd import pipeline as PL
+    model = tiny_model()
+    ws = model.get_weights()
+    rng = np.random.default_rng(h * 7 + w)
+    ws[5] = np.array([0.0, 0.02], np.float32)  # bias the head so both classes occur
+    model.set_weights(ws)
+    img = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    # smooth blobs so the mask is not pure noise
+    img[h // 4:h // 2, w // 5:w // 2] //= 3
+    got = PL.detection(img, None, model, batch=3)
+    ref = OP.detection_ref(img, oracle_predict_fn(ws))
+    assert got.shape == ref.shape == (h, w) and got.dtype == np.uint8
+    mism = int((got != ref).sum())
+    # fp32 (engine) vs fp64 (restatement) can flip exact near-ties only
+    assert mism <= 1e-4 * h * w, f"{mism} of {h * w} mask pixels differ"
+    assert set(np.unique(got)) <= {0, 255}
+    if w > h + 360:  # the reference's column loop never reaches the right-hand tiles (predict.py:106)
+        assert got[:, 872:].max() == 0
+        fixed = PL.detection(img, None, model, batch=4, reference_jloop=False)
+        assert fixed[:, 872:].max() == 255
+
+
+def test_portrait_image_raises_like_reference(engine):
+    from building_detection_amd import pipeline as PL
+    with pytest.raises(ValueError, match="predict.py:106"):
+        PL.tile_origins(1300, 500, reference_jloop=True)
+    (ch, cw), origins = PL.tile_origins(1300, 500, reference_jloop=False)
+    assert (ch, cw) == (1592, 512) and len(origins) == 4
+
+
+def test_vote(engine):
+    from building_detection_amd import pipeline as PL
+    rng = np.random.default_rng(0)
+    masks = [(rng.random((300, 280)) > 0.5).astype(np.uint8) * 255 for _ in range(5)]
+    np.testing.assert_array_equal(PL.vote(masks, 3), OP.vote_ref(masks, 3))
