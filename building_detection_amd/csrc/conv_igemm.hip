@@ -21,7 +21,7 @@
 //   after them: one barrier per slab (guide §5.5 T3 "minimum 2-phase").  fp32 MFMA is 64 cycles/instr, so a
 //   slab is 64 MFMAs = 4096 cycles per wave against ~32 KB of staging: the loop is MFMA-bound by design.
 //   Block ids are remapped so each XCD owns a contiguous run of M-tiles (shared halo / weights hit one L2).
-#include "sg_common.h"
+#include "sg_reduce.h"
 
 namespace {
 
@@ -44,13 +44,15 @@ struct IgemmParams {
 };
 
 template <int BN, int WGM, int WGN, bool VEC>
-__global__ __launch_bounds__(256, 2) void igemm_conv_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kernel(const IgemmParams p) {
+  constexpr int NT = 64 * WGM * WGN;        // 4 or 8 waves; two workgroups per CU => 2 or 4 waves per SIMD
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LDB = BN;
-  constexpr int NB = (BK * BN / 4) / 256;  // float4 B chunks per thread
-  static_assert(WGM * WGN == 4, "4 waves");
-  static_assert(NB >= 1, "tile too small");
+  constexpr int NA = (BM * BK / 4) / NT;    // float4 A chunks per thread (rows r0 + RS*j)
+  constexpr int RS = NT / 8;
+  constexpr int NB = (BK * BN / 4) / NT;    // float4 B chunks per thread
+  static_assert(NA >= 1 && NB >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* As = reinterpret_cast<float*>(smem);  // [2][BM*LDA]
@@ -62,12 +64,12 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(const IgemmParams p)
   const uint32_t tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-  // ---- per-thread A rows: 4 rows (r0 + 32 j), one 4-wide k chunk (kc) -------------------------------
+  // ---- per-thread A rows: NA rows (r0 + RS j), one 4-wide k chunk (kc) ------------------------------
   const int kc = t & 7, r0 = t >> 3;
-  int row_base[4], row_oh[4], row_ow[4];
+  int row_base[NA], row_oh[NA], row_ow[NA];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int m = m0 + r0 + 32 * j;
+  for (int j = 0; j < NA; ++j) {
+    const int m = m0 + r0 + RS * j;
     if (m < p.M) {
       uint32_t n, rem, oh, ow;
       fd_divmod((uint32_t)m, p.fd_ohow, n, rem);
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(const IgemmParams p)
     }
   }
 
-  f32x4 ra[4];
+  f32x4 ra[NA];
   f32x4 rb[NB];
 
   auto gather_elem_addr = [&](int j, int dh, int dw, bool kvalid, int64_t& off) -> bool {
@@ -107,11 +109,14 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(const IgemmParams p)
       fd_divmod(tap, p.fd_kw, kh, kw);
       const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < NA; ++j) {
         int64_t off;
         const bool v = gather_elem_addr(j, dh, dw, kvalid, off);
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        ra[j] = v ? *reinterpret_cast<const f32x4*>(p.x + off + ci) : z;
+        // branch-free: out-of-range taps read element 0 of x (always mapped) and are zeroed by a select, so
+        // the whole slab stays one basic block and the loads schedule freely against the MFMAs
+        const f32x4 val = *reinterpret_cast<const f32x4*>(p.x + (v ? off + ci : 0));
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ra[j] = v ? val : z;
       }
     } else {
 #pragma unroll
@@ -123,10 +128,11 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(const IgemmParams p)
         fd_divmod(tap, p.fd_kw, kh, kw);
         const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NA; ++j) {
           int64_t off;
           const bool v = gather_elem_addr(j, dh, dw, kvalid, off);
-          ra[j][e] = v ? p.x[off + ci] : 0.f;
+          const float val = p.x[v ? off + ci : 0];
+          ra[j][e] = v ? val : 0.f;
         }
       }
     }
@@ -135,16 +141,21 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(const IgemmParams p)
   auto load_B = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int idx = t + 256 * i;
+      const int idx = t + NT * i;
       const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
       const int k = k0 + kr, n = n0 + 4 * c4;
       if constexpr (VEC) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        rb[i] = (k < p.K && n < p.Nout) ? *reinterpret_cast<const f32x4*>(p.w + (int64_t)k * p.Nout + n) : z;
+        const bool v = (k < p.K) && (n < p.Nout);
+        const f32x4 val = *reinterpret_cast<const f32x4*>(p.w + (v ? (int64_t)k * p.Nout + n : 0));
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        rb[i] = v ? val : z;
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          rb[i][e] = (k < p.K && n + e < p.Nout) ? p.w[(int64_t)k * p.Nout + n + e] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const bool v = (k < p.K) && (n + e < p.Nout);
+          const float val = p.w[v ? (int64_t)k * p.Nout + n + e : 0];
+          rb[i][e] = v ? val : 0.f;
+        }
       }
     }
   };
@@ -153,10 +164,10 @@ __global__ __launch_bounds__(256, 2) void igemm_conv_kernel(const IgemmParams p)
     float* a = As + buf * BM * LDA;
     float* b = Bs + buf * BK * LDB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(a + (r0 + 32 * j) * LDA + 4 * kc) = ra[j];
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(a + (r0 + RS * j) * LDA + 4 * kc) = ra[j];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int idx = t + 256 * i;
+      const int idx = t + NT * i;
       const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
       *reinterpret_cast<f32x4*>(b + kr * LDB + 4 * c4) = rb[i];
     }
@@ -267,12 +278,16 @@ struct WgradParams {
 };
 
 template <int BN, int WGM, int WGN, bool VEC>
-__global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const WgradParams p) {
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_kernel(const WgradParams p) {
+  constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int LDAW = BM;  // A' slab is [32 pixels][128 r], r contiguous
   constexpr int LDB = BN;
-  constexpr int NB = (BK * BN / 4) / 256;
+  constexpr int NA = (BK * BM / 4) / NT;   // float4 A' chunks per thread (pixel rows pr0 + PS*j)
+  constexpr int PS = NT / 32;
+  constexpr int NB = (BK * BN / 4) / NT;
+  static_assert(NA >= 1 && NB >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* As = reinterpret_cast<float*>(smem);  // [2][BK*LDAW]
@@ -284,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const WgradParams p
   const uint32_t tile_r = bid / ntn, tile_n = bid - tile_r * ntn;
   const int rbase = tile_r * BM, n0 = tile_n * BN;
 
-  // A' chunk owned by this thread: r = rbase + 4*rc (fixed tap / channel), pixel rows (t>>5) + 8 j
+  // A' chunk owned by this thread: r = rbase + 4*rc (fixed tap / channel), pixel rows (t>>5) + PS j
   const int rc = t & 31, pr0 = t >> 5;
   constexpr int NV = VEC ? 1 : 4;
   int dh[NV], dw[NV], ci_e[NV];
@@ -308,13 +323,13 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const WgradParams p
   int slab_end = slab_begin + p.slabs_per_split;
   if (slab_end > nslab_total) slab_end = nslab_total;
 
-  f32x4 ra[4];
+  f32x4 ra[NA];
   f32x4 rb[NB];
 
   auto load_A = [&](int p0) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int pp = p0 + pr0 + 8 * j;
+    for (int j = 0; j < NA; ++j) {
+      const int pp = p0 + pr0 + PS * j;
       const bool pv = pp < p.P;
       uint32_t n, rem, oh, ow;
       fd_divmod((uint32_t)(pv ? pp : 0), p.fd_ohow, n, rem);
@@ -323,14 +338,16 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const WgradParams p
       if constexpr (VEC) {
         const int ih = (int)oh * p.stride + dh[0], iw = (int)ow * p.stride + dw[0];
         const bool v = pv && rvalid[0] && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        ra[j] = v ? *reinterpret_cast<const f32x4*>(p.x + (int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[0]) : z;
+        const f32x4 val = *reinterpret_cast<const f32x4*>(p.x + (v ? (int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[0] : 0));
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ra[j] = v ? val : z;
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int ih = (int)oh * p.stride + dh[e], iw = (int)ow * p.stride + dw[e];
           const bool v = pv && rvalid[e] && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-          ra[j][e] = v ? p.x[(int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[e]] : 0.f;
+          const float val = p.x[v ? (int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[e] : 0];
+          ra[j][e] = v ? val : 0.f;
         }
       }
     }
@@ -339,16 +356,21 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const WgradParams p
   auto load_B = [&](int p0) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int idx = t + 256 * i;
+      const int idx = t + NT * i;
       const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
       const int pp = p0 + kr, n = n0 + 4 * c4;
       if constexpr (VEC) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        rb[i] = (pp < p.P && n < p.Cout) ? *reinterpret_cast<const f32x4*>(p.dy + (int64_t)pp * p.y_ld + n) : z;
+        const bool v = (pp < p.P) && (n < p.Cout);
+        const f32x4 val = *reinterpret_cast<const f32x4*>(p.dy + (v ? (int64_t)pp * p.y_ld + n : 0));
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        rb[i] = v ? val : z;
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-          rb[i][e] = (pp < p.P && n + e < p.Cout) ? p.dy[(int64_t)pp * p.y_ld + n + e] : 0.f;
+        for (int e = 0; e < 4; ++e) {
+          const bool v = (pp < p.P) && (n + e < p.Cout);
+          const float val = p.dy[v ? (int64_t)pp * p.y_ld + n + e : 0];
+          rb[i][e] = v ? val : 0.f;
+        }
       }
     }
   };
@@ -357,10 +379,10 @@ __global__ __launch_bounds__(256, 2) void igemm_wgrad_kernel(const WgradParams p
     float* a = As + buf * BK * LDAW;
     float* b = Bs + buf * BK * LDB;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(a + (pr0 + 8 * j) * LDAW + 4 * rc) = ra[j];
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(a + (pr0 + PS * j) * LDAW + 4 * rc) = ra[j];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      const int idx = t + 256 * i;
+      const int idx = t + NT * i;
       const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
       *reinterpret_cast<f32x4*>(b + kr * LDB + 4 * c4) = rb[i];
     }
@@ -437,30 +459,33 @@ __global__ void reduce_splits_kernel(const float* __restrict__ part, float* __re
   }
 }
 
-// column sums of a [rows][C] matrix with pixel stride ld: stage 1 writes part[by][c], stage 2 sums by.
-__global__ void colsum_stage1_kernel(const float* __restrict__ a, int64_t rows, int C, int ld, float* __restrict__ part) {
-  __shared__ float red[256];
-  const int TX = blockDim.x, TY = blockDim.y;  // TX*TY == 256
-  const int c = blockIdx.x * TX + threadIdx.x;
-  float s = 0.f;
-  if (c < C) {
-    for (int64_t r = (int64_t)blockIdx.y * TY + threadIdx.y; r < rows; r += (int64_t)gridDim.y * TY) s += a[r * ld + c];
+// bias gradient = column sums of dy[rows][C] (pixel stride ld), through the fixed-order segmented reducer
+struct ColSumOp {
+  static constexpr int NOUT = 1;
+  const float* __restrict__ a;
+  float* out;
+  int ld;
+  template <int V>
+  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[1][V]) const {
+    float v[V];
+    ldv<V>(a + r * ld + c, v);
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[0][k] += v[k];
   }
-  red[threadIdx.y * TX + threadIdx.x] = s;
-  __syncthreads();
-  if (threadIdx.y == 0 && c < C) {
-    float tot = 0.f;
-    for (int y = 0; y < TY; ++y) tot += red[y * TX + threadIdx.x];
-    part[(int64_t)blockIdx.y * C + c] = tot;
-  }
+  __device__ __forceinline__ void finalize(int, int c, const double (&s)[1]) const { out[c] = (float)s[0]; }
+};
+
+size_t colsum_ws_bytes(int num_cus, int64_t rows, int C) {
+  const SegPlan a = seg_plan<1>(num_cus, 1, rows, C, true), b = seg_plan<1>(num_cus, 1, rows, C, false);
+  return a.part_bytes > b.part_bytes ? a.part_bytes : b.part_bytes;
 }
 
-__global__ void colsum_stage2_kernel(const float* __restrict__ part, int nparts, int C, float* __restrict__ out) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int i = 0; i < nparts; ++i) s += (double)part[(int64_t)i * C + c];
-  out[c] = (float)s;
+int launch_colsum(int num_cus, const float* dy, int64_t rows, int C, int ld, float* out, float* part, hipStream_t st) {
+  const bool vec = (C % 4 == 0) && (ld % 4 == 0) && sg_aligned16(dy);
+  const SegPlan pl = seg_plan<1>(num_cus, 1, rows, C, vec);
+  ColSumOp op;
+  op.a = dy; op.out = out; op.ld = ld;
+  return seg_reduce_launch(op, pl, 1, rows, C, part, st, "colsum");
 }
 
 template <typename KernelT>
@@ -487,14 +512,33 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     sg_set_error("igemm: bad tile count %lld", (long long)tiles);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL((igemm_conv_kernel<BN, WGM, WGN, VEC>), dim3((unsigned)tiles), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((igemm_conv_kernel<BN, WGM, WGN, VEC>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("igemm_conv_kernel");
   return 0;
 }
 
-int dispatch_igemm(const IgemmParams& p, bool vec, hipStream_t st) {
-  if (p.Nout > 64) return vec ? launch_igemm<128, 2, 2, true>(p, st) : launch_igemm<128, 2, 2, false>(p, st);
-  if (p.Nout > 32) return vec ? launch_igemm<64, 2, 2, true>(p, st) : launch_igemm<64, 2, 2, false>(p, st);
+// Tile width by wave quantisation: two workgroups fit a CU (LDS), so one "wave" of the grid is 2*CUs tiles; pick
+// the BN in {128, 64} whose tile count wastes the least of its last wave and of its last column tile (e.g.
+// M = 16384, N = 728: 128-wide = 768 tiles = 1.5 waves (75 %), 64-wide = 1536 tiles = 3.0 waves (100 %)).
+int pick_bn(int64_t M, int N, int num_cus) {
+  if (N <= 32) return 32;
+  if (N <= 64) return 64;
+  const int64_t slots = 2 * (int64_t)num_cus;
+  double best = -1.0;
+  int best_bn = 128;
+  for (int bn : {128, 64}) {
+    const int64_t tiles = sg_cdiv(M, BM) * sg_cdiv(N, bn);
+    const double eff = (double)tiles / (double)(sg_cdiv(tiles, slots) * slots) * (double)N / (double)(sg_cdiv(N, bn) * bn) *
+                       (bn == 128 ? 1.0 : 0.93);  // the wider tile re-reads A half as often
+    if (eff > best) { best = eff; best_bn = bn; }
+  }
+  return best_bn;
+}
+
+int dispatch_igemm(const IgemmParams& p, bool vec, int num_cus, hipStream_t st) {
+  const int bn = pick_bn(p.M, p.Nout, num_cus);
+  if (bn == 128) return vec ? launch_igemm<128, 2, 4, true>(p, st) : launch_igemm<128, 2, 4, false>(p, st);
+  if (bn == 64) return vec ? launch_igemm<64, 4, 2, true>(p, st) : launch_igemm<64, 4, 2, false>(p, st);
   return vec ? launch_igemm<32, 4, 1, true>(p, st) : launch_igemm<32, 4, 1, false>(p, st);
 }
 
@@ -508,14 +552,14 @@ int launch_wgrad(const WgradParams& p, int S, hipStream_t st) {
     attr_done = true;
   }
   const int64_t tiles = sg_cdiv(p.K, BM) * sg_cdiv(p.Cout, BN);
-  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, VEC>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(256), lds, st, p);
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, VEC>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("igemm_wgrad_kernel");
   return 0;
 }
 
 int dispatch_wgrad(const WgradParams& p, int S, bool vec, hipStream_t st) {
-  if (p.Cout > 64) return vec ? launch_wgrad<128, 2, 2, true>(p, S, st) : launch_wgrad<128, 2, 2, false>(p, S, st);
-  if (p.Cout > 32) return vec ? launch_wgrad<64, 2, 2, true>(p, S, st) : launch_wgrad<64, 2, 2, false>(p, S, st);
+  if (p.Cout > 64) return vec ? launch_wgrad<128, 2, 4, true>(p, S, st) : launch_wgrad<128, 2, 4, false>(p, S, st);
+  if (p.Cout > 32) return vec ? launch_wgrad<64, 4, 2, true>(p, S, st) : launch_wgrad<64, 4, 2, false>(p, S, st);
   return vec ? launch_wgrad<32, 4, 1, true>(p, S, st) : launch_wgrad<32, 4, 1, false>(p, S, st);
 }
 
@@ -539,7 +583,6 @@ struct WgradPlan {
   int S;
   int slabs_per_split;
   size_t dw_part_bytes;
-  int bias_parts;
   size_t bias_part_bytes;
 };
 
@@ -550,7 +593,8 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
   const int bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
   const int64_t tiles = sg_cdiv(K, BM) * sg_cdiv(d->Cout, bn);
   const int64_t nslab = sg_cdiv(P, BK);
-  int64_t S = sg_cdiv((int64_t)2 * num_cus, tiles);
+  // fill the 2*CUs workgroup slots once: S = floor(slots / tiles) keeps tiles*S <= slots (no ragged second wave)
+  int64_t S = ((int64_t)2 * num_cus) / tiles;
   if (S > nslab / 4) S = nslab / 4;  // at least 4 slabs per split
   if (S < 1) S = 1;
   // keep the partial slab under 256 MiB
@@ -558,11 +602,7 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
   pl.slabs_per_split = (int)sg_cdiv(nslab, S);
   pl.S = (int)sg_cdiv(nslab, pl.slabs_per_split);
   pl.dw_part_bytes = pl.S > 1 ? (size_t)pl.S * K * d->Cout * 4 : 0;
-  int64_t parts = sg_cdiv(P, 256 * 8);
-  if (parts > 256) parts = 256;
-  if (parts < 1) parts = 1;
-  pl.bias_parts = (int)parts;
-  pl.bias_part_bytes = (size_t)parts * d->Cout * 4;
+  pl.bias_part_bytes = colsum_ws_bytes(num_cus, P, d->Cout);
   return pl;
 }
 
@@ -595,7 +635,7 @@ int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, c
   p.fd_c = make_fastdiv((uint32_t)d->Cin);
   p.fd_kw = make_fastdiv((uint32_t)d->KW);
   const bool vec = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
-  return dispatch_igemm(p, vec, (hipStream_t)stream);
+  return dispatch_igemm(p, vec, ctx->num_cus, (hipStream_t)stream);
 }
 
 size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d) {
@@ -645,13 +685,13 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   p.fd_c = make_fastdiv((uint32_t)d->Cout);
   p.fd_kw = make_fastdiv((uint32_t)d->KW);
   const bool vec = (d->Cout % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy);
-  return dispatch_igemm(p, vec, st);
+  return dispatch_igemm(p, vec, ctx->num_cus, st);
 }
 
 size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
   if (!ctx || !d) return 0;
   WgradPlan pl = plan_wgrad(ctx->num_cus, d);
-  return pl.dw_part_bytes + pl.bias_part_bytes + 256;
+  return pl.dw_part_bytes + pl.bias_part_bytes + 512;
 }
 
 int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
@@ -662,7 +702,7 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   if (rc) return rc;
   SG_CHECK_ARG(x && dy && dw, "sg_conv2d_wgrad: null tensor");
   const WgradPlan pl = plan_wgrad(ctx->num_cus, d);
-  const size_t need = pl.dw_part_bytes + pl.bias_part_bytes + 256;
+  const size_t need = pl.dw_part_bytes + pl.bias_part_bytes + 512;
   if (!ws || ws_bytes < need) {
     sg_set_error("sg_conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
     return SG_EWORKSPACE;
@@ -697,29 +737,15 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   if (dbias) {
     // 256-byte aligned region after the dw partials
     float* part = (float*)((char*)ws + ((pl.dw_part_bytes + 255) & ~(size_t)255));
-    const int C = d->Cout;
-    int TX = 1;
-    while (TX < C && TX < 64) TX <<= 1;
-    const int TY = 256 / TX;
-    dim3 grid((unsigned)sg_cdiv(C, TX), (unsigned)pl.bias_parts);
-    hipLaunchKernelGGL(colsum_stage1_kernel, grid, dim3(TX, TY), 0, st, (const float*)dy, (int64_t)p.P, C, p.y_ld, part);
-    SG_LAUNCH_CHECK("colsum_stage1_kernel");
-    hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)sg_cdiv(C, 64)), dim3(64), 0, st, (const float*)part, pl.bias_parts, C, (float*)dbias);
-    SG_LAUNCH_CHECK("colsum_stage2_kernel");
+    rc = launch_colsum(ctx->num_cus, (const float*)dy, (int64_t)p.P, d->Cout, p.y_ld, (float*)dbias, part, st);
+    if (rc) return rc;
   }
   return 0;
 }
 
-static int bias_parts_for(int64_t rows) {
-  int64_t parts = sg_cdiv(rows, 256 * 8);
-  if (parts > 256) parts = 256;
-  if (parts < 1) parts = 1;
-  return (int)parts;
-}
-
 size_t sg_bias_grad_ws_bytes(const sg_ctx* ctx, int64_t rows, int C) {
   if (!ctx) return 0;
-  return (size_t)bias_parts_for(rows) * C * sizeof(float) + 256;
+  return colsum_ws_bytes(ctx->num_cus, rows, C) + 256;
 }
 
 int sg_bias_grad(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, int ld, const void* dy, void* dbias,
@@ -727,21 +753,12 @@ int sg_bias_grad(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, int 
   SG_CHECK_ARG(ctx && dtype == SG_F32 && dy && dbias && rows > 0 && C > 0, "sg_bias_grad: bad argument");
   if (ld == 0) ld = C;
   SG_CHECK_ARG(ld >= C, "sg_bias_grad: ld < C");
-  const int parts = bias_parts_for(rows);
-  if (!ws || ws_bytes < (size_t)parts * C * sizeof(float)) {
-    sg_set_error("sg_bias_grad: workspace %zu < %zu", ws_bytes, (size_t)parts * C * sizeof(float));
+  const size_t need = colsum_ws_bytes(ctx->num_cus, rows, C);
+  if (!ws || ws_bytes < need) {
+    sg_set_error("sg_bias_grad: workspace %zu < %zu", ws_bytes, need);
     return SG_EWORKSPACE;
   }
-  hipStream_t st = (hipStream_t)stream;
-  int TX = 1;
-  while (TX < C && TX < 64) TX <<= 1;
-  const int TY = 256 / TX;
-  dim3 grid((unsigned)sg_cdiv(C, TX), (unsigned)parts);
-  hipLaunchKernelGGL(colsum_stage1_kernel, grid, dim3(TX, TY), 0, st, (const float*)dy, rows, C, ld, (float*)ws);
-  SG_LAUNCH_CHECK("colsum_stage1_kernel");
-  hipLaunchKernelGGL(colsum_stage2_kernel, dim3((unsigned)sg_cdiv(C, 64)), dim3(64), 0, st, (const float*)ws, parts, C, (float*)dbias);
-  SG_LAUNCH_CHECK("colsum_stage2_kernel");
-  return 0;
+  return launch_colsum(ctx->num_cus, (const float*)dy, rows, C, ld, (float*)dbias, (float*)ws, (hipStream_t)stream);
 }
 
 int sg_dense_fwd(sg_ctx* ctx, void* stream, int dtype, int rows, int in, int out, const void* x, const void* w,
