@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--model", default="v3plus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--force-dp", action="store_true",
+                    help="run the RCCL data-parallel path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -80,9 +82,11 @@ def main():
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dp:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from building_detection_amd import zoo
     from building_detection_amd.data import synthetic_batch
@@ -95,7 +99,7 @@ def main():
     else:
         model = zoo.BUILDERS[args.model]((args.size, args.size, 3))
     model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
-    if world > 1:
+    if dist is not None:
         from building_detection_amd.dist import DataParallel
         DataParallel(model)
 

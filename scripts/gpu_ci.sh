@@ -33,6 +33,10 @@ for s in $STAGES; do
            # keep only the small summaries
            find "$OUT/rocprof" -name '*kernel_stats*.csv' -exec cp {} "$OUT/kernel_stats.csv" \; 2>/dev/null
            find "$OUT/rocprof" -name '*kernel_trace*.csv' -size +20M -delete 2>/dev/null ;;
+    dp1)   run_stage dp1 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --force-dp ;;
+    pmc)   # HBM traffic of the dilated-conv kernels: separate passes (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
+           run_stage pmc_fetch 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 scripts/dilated_bench.py
+           run_stage pmc_write 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 scripts/dilated_bench.py ;;
     *) echo "unknown stage $s" ;;
   esac
 done
