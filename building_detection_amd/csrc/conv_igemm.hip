@@ -9,25 +9,33 @@
 // One gather formula serves forward and dgrad (and therefore Conv2DTranspose forward):
 //     ih = (oh * a_mul + kh * k_mul + off_h);  valid iff ih % div == 0 and 0 <= ih/div < H
 //   forward: a_mul = stride, k_mul = dilation,  off = -pad_before, div = 1
-//   dgrad  : a_mul = 1,      k_mul = -dilation, off = +pad_before, div = stride
+//   dgrad  : a_mul = 1,      k_mul = -dilation, off = +pad_before, div = stride (1 or 2)
 //
-// Tiling (wave64, 4 waves / 256 threads per workgroup, BK = 32):
-//   128x128 (waves 2x2, 64x64 each = 2x2 MFMA tiles), 128x64 (waves 2x2, 64x32), 128x32 (waves 4x1, 32x32).
+// Tiling (wave64; BM = 128 rows, BK = 32):
+//   128x128 and 128x64 tiles with 8 waves (2 waves per SIMD from ONE workgroup, so one wave's gather /
+//   LDS traffic overlaps its partner's MFMAs even at one workgroup per CU) or 4 waves; 128x32 with 4 waves.
 //   A slab [128][32] is staged k-contiguous in LDS with a 36-float row stride (ds_read_b128 conflict-free:
 //   16-B slot = 9*row mod 16), the B slab [32][BN] n-contiguous (ds_read_b32, lanes = consecutive dwords).
 //   The k index inside a group of 8 is split across the two lane halves (lanes 0-31: k..k+3, lanes 32-63:
 //   k+4..k+7) so one ds_read_b128 feeds four MFMAs; A and B use the same split, so the GEMM is unchanged.
-//   Global loads for slab s+1 are issued before the MFMAs of slab s and written to the other LDS buffer
-//   after them: one barrier per slab (guide §5.5 T3 "minimum 2-phase").  fp32 MFMA is 64 cycles/instr, so a
-//   slab is 64 MFMAs = 4096 cycles per wave against ~32 KB of staging: the loop is MFMA-bound by design.
+//   Global -> register -> LDS staging with the loads of slab s+PF issued before the MFMAs of slab s (PF = 1 or 2
+//   register sets; fp32 MFMA makes a slab only ~1.7 us of work, so two slabs in flight cover HBM/MALL latency
+//   under load), LDS double-buffered, ONE barrier per slab.  All gathers are branch-free (out-of-range taps
+//   read element 0 and are zeroed by a select) so a slab is a single basic block for the scheduler.
 //   Block ids are remapped so each XCD owns a contiguous run of M-tiles (shared halo / weights hit one L2).
+//   Tile width and the wgrad split are chosen per launch to fill whole "waves" of 2 workgroups per CU.
 #include "sg_reduce.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int BM = 128;
 constexpr int BK = 32;
 constexpr int LDA = BK + 4;  // floats; 144-byte rows
+
+template <int V>
+using IC = std::integral_constant<int, V>;
 
 struct IgemmParams {
   const float* __restrict__ x;
@@ -40,10 +48,15 @@ struct IgemmParams {
   int a_mul, k_mul, off_h, off_w, div;
   int K, M;
   int flags;
+  int stagger;  // waves in the upper half of the workgroup issue their gathers AFTER their MFMAs
   FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
 };
 
-template <int BN, int WGM, int WGN, bool VEC>
+// UT ("uniform tap"): Cin % 32 == 0 or a 1x1 kernel, so every 32-deep slab lies inside ONE filter tap.  The
+// per-row source offsets and bounds flags then change only when the slab stream crosses a tap boundary (every
+// Cin/32 slabs) and a slab's gather costs a handful of adds instead of ~170 VALU/SALU instructions of
+// div/mod, bounds and 64-bit address arithmetic ahead of the first MFMA.
+template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kernel(const IgemmParams p) {
   constexpr int NT = 64 * WGM * WGN;        // 4 or 8 waves; two workgroups per CU => 2 or 4 waves per SIMD
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -53,6 +66,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
   constexpr int RS = NT / 8;
   constexpr int NB = (BK * BN / 4) / NT;    // float4 B chunks per thread
   static_assert(NA >= 1 && NB >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
+  static_assert(PF == 1 || PF == 2, "prefetch depth");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* As = reinterpret_cast<float*>(smem);  // [2][BM*LDA]
@@ -84,8 +98,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
     }
   }
 
-  f32x4 ra[NA];
-  f32x4 rb[NB];
+  f32x4 ra[PF][NA];
+  f32x4 rb[PF][NB];
 
   auto gather_elem_addr = [&](int j, int dh, int dw, bool kvalid, int64_t& off) -> bool {
     int ih = row_oh[j] + dh, iw = row_ow[j] + dw;
@@ -100,7 +114,57 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
     return v;
   };
 
-  auto load_A = [&](int k0) {
+  // running state of the slab stream (UT mode): current tap and, per row, its source offset / validity
+  int cur_tap = -1;
+  int64_t tap_off[NA];
+  bool tap_ok[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) { tap_off[j] = 0; tap_ok[j] = false; }
+  const int ntaps = p.K / p.C;
+  bool bn_ok[NB];
+  int64_t b_off[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int idx = t + NT * i;
+    const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+    bn_ok[i] = (n0 + 4 * c4) < p.Nout;
+    b_off[i] = (int64_t)kr * p.Nout + n0 + 4 * c4;
+  }
+
+  // loads of slab k0 into register set S (compile-time): branch-free, invalid lanes read element 0
+  auto load_AB = [&](int k0, auto SET) {
+    constexpr int S = decltype(SET)::value;
+    if constexpr (VEC && UT) {
+      const int tap = (int)fd_div((uint32_t)k0, p.fd_c);  // uniform: scalar unit
+      if (tap != cur_tap) {                                // uniform branch, taken once per Cin/32 slabs
+        cur_tap = tap;
+        uint32_t kh, kw;
+        fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+        const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) tap_ok[j] = gather_elem_addr(j, dh, dw, tap < ntaps, tap_off[j]);
+      }
+      const int k = k0 + 4 * kc;
+      const int ci = k - tap * p.C;
+      const bool kvalid = k < p.K;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const bool v = kvalid && tap_ok[j];
+        const f32x4 val = *reinterpret_cast<const f32x4*>(p.x + (v ? tap_off[j] + ci : 0));
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        ra[S][j] = v ? val : z;
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int idx = t + NT * i;
+        const int kr = idx / (BN / 4);
+        const bool v = bn_ok[i] && (k0 + kr < p.K);
+        const f32x4 val = *reinterpret_cast<const f32x4*>(p.w + (v ? b_off[i] + (int64_t)k0 * p.Nout : 0));
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        rb[S][i] = v ? val : z;
+      }
+      return;
+    }
     if constexpr (VEC) {
       const int k = k0 + 4 * kc;
       const bool kvalid = k < p.K;
@@ -112,11 +176,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
       for (int j = 0; j < NA; ++j) {
         int64_t off;
         const bool v = gather_elem_addr(j, dh, dw, kvalid, off);
-        // branch-free: out-of-range taps read element 0 of x (always mapped) and are zeroed by a select, so
-        // the whole slab stays one basic block and the loads schedule freely against the MFMAs
         const f32x4 val = *reinterpret_cast<const f32x4*>(p.x + (v ? off + ci : 0));
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        ra[j] = v ? val : z;
+        ra[S][j] = v ? val : z;
       }
     } else {
 #pragma unroll
@@ -132,13 +194,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
           int64_t off;
           const bool v = gather_elem_addr(j, dh, dw, kvalid, off);
           const float val = p.x[v ? off + ci : 0];
-          ra[j][e] = v ? val : 0.f;
+          ra[S][j][e] = v ? val : 0.f;
         }
       }
     }
-  };
-
-  auto load_B = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int idx = t + NT * i;
@@ -148,28 +207,29 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
         const bool v = (k < p.K) && (n < p.Nout);
         const f32x4 val = *reinterpret_cast<const f32x4*>(p.w + (v ? (int64_t)k * p.Nout + n : 0));
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        rb[i] = v ? val : z;
+        rb[S][i] = v ? val : z;
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool v = (k < p.K) && (n + e < p.Nout);
           const float val = p.w[v ? (int64_t)k * p.Nout + n + e : 0];
-          rb[i][e] = v ? val : 0.f;
+          rb[S][i][e] = v ? val : 0.f;
         }
       }
     }
   };
 
-  auto store_AB = [&](int buf) {
+  auto store_AB = [&](int buf, auto SET) {
+    constexpr int S = decltype(SET)::value;
     float* a = As + buf * BM * LDA;
     float* b = Bs + buf * BK * LDB;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(a + (r0 + RS * j) * LDA + 4 * kc) = ra[j];
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(a + (r0 + RS * j) * LDA + 4 * kc) = ra[S][j];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int idx = t + NT * i;
       const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-      *reinterpret_cast<f32x4*>(b + kr * LDB + 4 * c4) = rb[i];
+      *reinterpret_cast<f32x4*>(b + kr * LDB + 4 * c4) = rb[S][i];
     }
   };
 
@@ -186,18 +246,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nslab = (p.K + BK - 1) / BK;
-  load_A(0);
-  load_B(0);
-  store_AB(0);
-  __syncthreads();
-
-  for (int s = 0; s < nslab; ++s) {
-    const int buf = s & 1;
-    if (s + 1 < nslab) {
-      load_A((s + 1) * BK);
-      load_B((s + 1) * BK);
-    }
+  auto compute = [&](int buf) {
     const float* a = As + buf * BM * LDA;
     const float* b = Bs + buf * BK * LDB;
 #pragma unroll
@@ -218,8 +267,46 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (s + 1 < nslab) store_AB(buf ^ 1);
+  };
+
+  const int nslab = (p.K + BK - 1) / BK;
+  const int last = nslab - 1;
+  // Stagger (MI355X_MICROARCH "two waves per SIMD", item 9): waves i and i + nwaves/2 share a SIMD and run the
+  // same program between the same barriers; the upper half defers its gather (address math + global loads)
+  // until after its MFMAs, so on every SIMD one wave's VALU phase overlaps its partner's matrix phase.
+  const bool late = (p.stagger != 0) && (__builtin_amdgcn_readfirstlane(t >> 6) >= (NT / 128));
+  if constexpr (PF == 1) {
+    load_AB(0, IC<0>{});
+    store_AB(0, IC<0>{});
     __syncthreads();
+    for (int s = 0; s < nslab; ++s) {
+      const int buf = s & 1;
+      load_AB((s < last ? s + 1 : last) * BK, IC<0>{});  // tail reloads the last slab (unused): no branch
+      compute(buf);
+      store_AB(buf ^ 1, IC<0>{});
+      __syncthreads();
+    }
+  } else {
+    // two register sets: while slab s is computed from LDS, slab s+1 sits in one set (landing) and slab s+2
+    // is being fetched into the other; the store of a set waits only for that set's (older) loads
+    load_AB(0, IC<0>{});
+    load_AB((1 < last ? 1 : last) * BK, IC<1>{});
+    store_AB(0, IC<0>{});
+    __syncthreads();
+    for (int s = 0; s < nslab; s += 2) {
+      const int ka = (s + 2 < last ? s + 2 : last) * BK, kb = (s + 3 < last ? s + 3 : last) * BK;
+      if (!late) load_AB(ka, IC<0>{});
+      compute(0);
+      if (late) load_AB(ka, IC<0>{});
+      store_AB(1, IC<1>{});
+      __syncthreads();
+      if (s + 1 >= nslab) break;
+      if (!late) load_AB(kb, IC<1>{});
+      compute(1);
+      if (late) load_AB(kb, IC<1>{});
+      store_AB(0, IC<0>{});
+      __syncthreads();
+    }
   }
 
   // ---- epilogue: bias, relu, store (each store: 2 x 128 contiguous bytes per wave) -------------------
@@ -274,10 +361,11 @@ struct WgradParams {
   int stride, dil, pad_t, pad_l;
   int K, P;
   int slabs_per_split;
+  int stagger;
   FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
 };
 
-template <int BN, int WGM, int WGN, bool VEC>
+template <int BN, int WGM, int WGN, int PF, bool VEC>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_kernel(const WgradParams p) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -304,18 +392,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
   constexpr int NV = VEC ? 1 : 4;
   int dh[NV], dw[NV], ci_e[NV];
   bool rvalid[NV];
-  {
 #pragma unroll
-    for (int e = 0; e < NV; ++e) {
-      const int r = rbase + 4 * rc + e;
-      rvalid[e] = r < p.K;
-      uint32_t tap, ci, kh, kw;
-      fd_divmod((uint32_t)r, p.fd_c, tap, ci);
-      fd_divmod(tap, p.fd_kw, kh, kw);
-      dh[e] = (int)kh * p.dil - p.pad_t;
-      dw[e] = (int)kw * p.dil - p.pad_l;
-      ci_e[e] = (int)ci;
-    }
+  for (int e = 0; e < NV; ++e) {
+    const int r = rbase + 4 * rc + e;
+    rvalid[e] = r < p.K;
+    uint32_t tap, ci, kh, kw;
+    fd_divmod((uint32_t)r, p.fd_c, tap, ci);
+    fd_divmod(tap, p.fd_kw, kh, kw);
+    dh[e] = (int)kh * p.dil - p.pad_t;
+    dw[e] = (int)kw * p.dil - p.pad_l;
+    ci_e[e] = (int)ci;
   }
 
   const int slab_begin = blockIdx.z * p.slabs_per_split;
@@ -323,10 +409,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
   int slab_end = slab_begin + p.slabs_per_split;
   if (slab_end > nslab_total) slab_end = nslab_total;
 
-  f32x4 ra[NA];
-  f32x4 rb[NB];
+  f32x4 ra[PF][NA];
+  f32x4 rb[PF][NB];
 
-  auto load_A = [&](int p0) {
+  auto load_AB = [&](int p0, auto SET) {
+    constexpr int S = decltype(SET)::value;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int pp = p0 + pr0 + PS * j;
@@ -340,20 +427,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
         const bool v = pv && rvalid[0] && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
         const f32x4 val = *reinterpret_cast<const f32x4*>(p.x + (v ? (int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[0] : 0));
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        ra[j] = v ? val : z;
+        ra[S][j] = v ? val : z;
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int ih = (int)oh * p.stride + dh[e], iw = (int)ow * p.stride + dw[e];
           const bool v = pv && rvalid[e] && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
           const float val = p.x[v ? (int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[e] : 0];
-          ra[j][e] = v ? val : 0.f;
+          ra[S][j][e] = v ? val : 0.f;
         }
       }
     }
-  };
-
-  auto load_B = [&](int p0) {
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int idx = t + NT * i;
@@ -363,28 +447,29 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
         const bool v = (pp < p.P) && (n < p.Cout);
         const f32x4 val = *reinterpret_cast<const f32x4*>(p.dy + (v ? (int64_t)pp * p.y_ld + n : 0));
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        rb[i] = v ? val : z;
+        rb[S][i] = v ? val : z;
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool v = (pp < p.P) && (n + e < p.Cout);
           const float val = p.dy[v ? (int64_t)pp * p.y_ld + n + e : 0];
-          rb[i][e] = v ? val : 0.f;
+          rb[S][i][e] = v ? val : 0.f;
         }
       }
     }
   };
 
-  auto store_AB = [&](int buf) {
+  auto store_AB = [&](int buf, auto SET) {
+    constexpr int S = decltype(SET)::value;
     float* a = As + buf * BK * LDAW;
     float* b = Bs + buf * BK * LDB;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(a + (pr0 + PS * j) * LDAW + 4 * rc) = ra[j];
+    for (int j = 0; j < NA; ++j) *reinterpret_cast<f32x4*>(a + (pr0 + PS * j) * LDAW + 4 * rc) = ra[S][j];
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int idx = t + NT * i;
       const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-      *reinterpret_cast<f32x4*>(b + kr * LDB + 4 * c4) = rb[i];
+      *reinterpret_cast<f32x4*>(b + kr * LDB + 4 * c4) = rb[S][i];
     }
   };
 
@@ -400,19 +485,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  if (slab_begin < slab_end) {
-    load_A(slab_begin * BK);
-    load_B(slab_begin * BK);
-    store_AB(0);
-  }
-  __syncthreads();
-
-  for (int s = slab_begin; s < slab_end; ++s) {
-    const int buf = (s - slab_begin) & 1;
-    if (s + 1 < slab_end) {
-      load_A((s + 1) * BK);
-      load_B((s + 1) * BK);
-    }
+  auto compute = [&](int buf) {
     const float* a = As + buf * BK * LDAW;
     const float* b = Bs + buf * BK * LDB;
 #pragma unroll
@@ -429,8 +502,43 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (s + 1 < slab_end) store_AB(buf ^ 1);
-    __syncthreads();
+  };
+
+  const int nslab = slab_end - slab_begin;  // >= 1 by construction of the split plan
+  const int last = slab_end - 1;
+  if (nslab > 0) {
+    if constexpr (PF == 1) {
+      load_AB(slab_begin * BK, IC<0>{});
+      store_AB(0, IC<0>{});
+      __syncthreads();
+      for (int s = slab_begin; s < slab_end; ++s) {
+        const int buf = (s - slab_begin) & 1;
+        load_AB((s < last ? s + 1 : last) * BK, IC<0>{});
+        compute(buf);
+        store_AB(buf ^ 1, IC<0>{});
+        __syncthreads();
+      }
+    } else {
+      load_AB(slab_begin * BK, IC<0>{});
+      load_AB((slab_begin + 1 < last ? slab_begin + 1 : last) * BK, IC<1>{});
+      store_AB(0, IC<0>{});
+      __syncthreads();
+      const bool late = (p.stagger != 0) && (__builtin_amdgcn_readfirstlane(t >> 6) >= (NT / 128));
+      for (int s = slab_begin; s < slab_end; s += 2) {
+        const int pa = (s + 2 < last ? s + 2 : last) * BK, pb = (s + 3 < last ? s + 3 : last) * BK;
+        if (!late) load_AB(pa, IC<0>{});
+        compute(0);
+        if (late) load_AB(pa, IC<0>{});
+        store_AB(1, IC<1>{});
+        __syncthreads();
+        if (s + 1 >= slab_end) break;
+        if (!late) load_AB(pb, IC<1>{});
+        compute(1);
+        if (late) load_AB(pb, IC<1>{});
+        store_AB(0, IC<0>{});
+        __syncthreads();
+      }
+    }
   }
 
   float* out = p.out + (int64_t)blockIdx.z * p.K * p.Cout;
@@ -498,12 +606,23 @@ int set_dyn_lds(KernelT k, size_t bytes) {
   return 0;
 }
 
-template <int BN, int WGM, int WGN, bool VEC>
-int launch_igemm(const IgemmParams& p, hipStream_t st) {
+// Experiment switch (A/B runs of the micro-benchmark): SG_CONV_VARIANT bit 0 = 8-wave workgroups,
+// bit 1 = two-slab prefetch, bit 2 = staggered wave halves (needs bit 1).  Default = all (7).
+int conv_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SG_CONV_VARIANT");
+    v = e ? atoi(e) & 7 : 7;
+  }
+  return v;
+}
+
+template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT>
+int launch_igemm_ut(const IgemmParams& p, hipStream_t st) {
   constexpr size_t lds = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float);
   static bool attr_done = false;  // idempotent; racing threads set the same value
   if (!attr_done) {
-    int rc = set_dyn_lds(igemm_conv_kernel<BN, WGM, WGN, VEC>, lds);
+    int rc = set_dyn_lds(igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT>, lds);
     if (rc) return rc;
     attr_done = true;
   }
@@ -512,9 +631,18 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
     sg_set_error("igemm: bad tile count %lld", (long long)tiles);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL((igemm_conv_kernel<BN, WGM, WGN, VEC>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("igemm_conv_kernel");
   return 0;
+}
+
+template <int BN, int WGM, int WGN, int PF, bool VEC>
+int launch_igemm(const IgemmParams& p, hipStream_t st) {
+  if constexpr (VEC) {
+    const bool ut = (p.C % BK == 0) || (p.K == p.C);  // slab never straddles a tap
+    if (ut) return launch_igemm_ut<BN, WGM, WGN, PF, true, true>(p, st);
+  }
+  return launch_igemm_ut<BN, WGM, WGN, PF, VEC, false>(p, st);
 }
 
 // Tile width by wave quantisation: two workgroups fit a CU (LDS), so one "wave" of the grid is 2*CUs tiles; pick
@@ -523,7 +651,9 @@ int launch_igemm(const IgemmParams& p, hipStream_t st) {
 int pick_bn(int64_t M, int N, int num_cus) {
   if (N <= 32) return 32;
   if (N <= 64) return 64;
-  const int64_t slots = 2 * (int64_t)num_cus;
+  // quantum = one workgroup per CU: an 8-wave workgroup keeps a CU's matrix pipes fed on its own, and tiles
+  // beyond the resident ones are dispatched as CUs free up, so the makespan is ceil(tiles / CUs) tile-times
+  const int64_t slots = (int64_t)num_cus;
   double best = -1.0;
   int best_bn = 128;
   for (int bn : {128, 64}) {
@@ -535,32 +665,79 @@ int pick_bn(int64_t M, int N, int num_cus) {
   return best_bn;
 }
 
-int dispatch_igemm(const IgemmParams& p, bool vec, int num_cus, hipStream_t st) {
+int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t st) {
+  IgemmParams p = p_in;
   const int bn = pick_bn(p.M, p.Nout, num_cus);
-  if (bn == 128) return vec ? launch_igemm<128, 2, 4, true>(p, st) : launch_igemm<128, 2, 4, false>(p, st);
-  if (bn == 64) return vec ? launch_igemm<64, 4, 2, true>(p, st) : launch_igemm<64, 4, 2, false>(p, st);
-  return vec ? launch_igemm<32, 4, 1, true>(p, st) : launch_igemm<32, 4, 1, false>(p, st);
+  const int var = conv_variant() & 3;
+  p.stagger = (conv_variant() >> 2) & 1;
+  if (!vec) {
+    if (bn == 128) return launch_igemm<128, 2, 4, 1, false>(p, st);
+    if (bn == 64) return launch_igemm<64, 4, 2, 1, false>(p, st);
+    return launch_igemm<32, 4, 1, 1, false>(p, st);
+  }
+  if (bn == 128) {
+    switch (var) {
+      case 0: return launch_igemm<128, 2, 2, 1, true>(p, st);
+      case 1: return launch_igemm<128, 2, 4, 1, true>(p, st);
+      case 2: return launch_igemm<128, 2, 2, 2, true>(p, st);
+      default: return launch_igemm<128, 2, 4, 2, true>(p, st);
+    }
+  }
+  if (bn == 64) {
+    switch (var) {
+      case 0: return launch_igemm<64, 2, 2, 1, true>(p, st);
+      case 1: return launch_igemm<64, 4, 2, 1, true>(p, st);
+      case 2: return launch_igemm<64, 2, 2, 2, true>(p, st);
+      default: return launch_igemm<64, 4, 2, 2, true>(p, st);
+    }
+  }
+  return (var & 2) ? launch_igemm<32, 4, 1, 2, true>(p, st) : launch_igemm<32, 4, 1, 1, true>(p, st);
 }
 
-template <int BN, int WGM, int WGN, bool VEC>
+template <int BN, int WGM, int WGN, int PF, bool VEC>
 int launch_wgrad(const WgradParams& p, int S, hipStream_t st) {
   constexpr size_t lds = (size_t)(2 * BK * BM + 2 * BK * BN) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(igemm_wgrad_kernel<BN, WGM, WGN, VEC>, lds);
+    int rc = set_dyn_lds(igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC>, lds);
     if (rc) return rc;
     attr_done = true;
   }
   const int64_t tiles = sg_cdiv(p.K, BM) * sg_cdiv(p.Cout, BN);
-  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, VEC>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("igemm_wgrad_kernel");
   return 0;
 }
 
-int dispatch_wgrad(const WgradParams& p, int S, bool vec, hipStream_t st) {
-  if (p.Cout > 64) return vec ? launch_wgrad<128, 2, 4, true>(p, S, st) : launch_wgrad<128, 2, 4, false>(p, S, st);
-  if (p.Cout > 32) return vec ? launch_wgrad<64, 4, 2, true>(p, S, st) : launch_wgrad<64, 4, 2, false>(p, S, st);
-  return vec ? launch_wgrad<32, 4, 1, true>(p, S, st) : launch_wgrad<32, 4, 1, false>(p, S, st);
+inline int wgrad_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
+
+int dispatch_wgrad(const WgradParams& p_in, int S, bool vec, hipStream_t st) {
+  WgradParams p = p_in;
+  const int bn = wgrad_bn(p.Cout);
+  const int var = conv_variant() & 3;
+  p.stagger = (conv_variant() >> 2) & 1;
+  if (!vec) {
+    if (bn == 128) return launch_wgrad<128, 2, 4, 1, false>(p, S, st);
+    if (bn == 64) return launch_wgrad<64, 4, 2, 1, false>(p, S, st);
+    return launch_wgrad<32, 4, 1, 1, false>(p, S, st);
+  }
+  if (bn == 128) {
+    switch (var) {
+      case 0: return launch_wgrad<128, 2, 2, 1, true>(p, S, st);
+      case 1: return launch_wgrad<128, 2, 4, 1, true>(p, S, st);
+      case 2: return launch_wgrad<128, 2, 2, 2, true>(p, S, st);
+      default: return launch_wgrad<128, 2, 4, 2, true>(p, S, st);
+    }
+  }
+  if (bn == 64) {
+    switch (var) {
+      case 0: return launch_wgrad<64, 2, 2, 1, true>(p, S, st);
+      case 1: return launch_wgrad<64, 4, 2, 1, true>(p, S, st);
+      case 2: return launch_wgrad<64, 2, 2, 2, true>(p, S, st);
+      default: return launch_wgrad<64, 4, 2, 2, true>(p, S, st);
+    }
+  }
+  return (var & 2) ? launch_wgrad<32, 4, 1, 2, true>(p, S, st) : launch_wgrad<32, 4, 1, 1, true>(p, S, st);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -575,7 +752,6 @@ int check_desc(const sg_conv_desc* d, const char* who) {
   SG_CHECK_ARG(xl >= d->Cin && yl >= d->Cout, "%s: pixel stride smaller than channel count", who);
   SG_CHECK_ARG((int64_t)d->N * d->H * d->W * xl < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo * yl < (1ll << 31),
                "%s: tensor exceeds 2^31 elements", who);
-  // the last tap of the last output position must not need more than pad_after < kernel extent
   return 0;
 }
 
@@ -586,20 +762,32 @@ struct WgradPlan {
   size_t bias_part_bytes;
 };
 
+// Split of the pixel reduction over S workgroups per tile.  Modelled time = MFMA work / (fraction of the
+// 2*CUs workgroup slots kept busy over whole waves) + the traffic of writing and re-adding S partial slabs;
+// the S with the smallest modelled time wins (e.g. ASPP: 288 tiles -> S = 7: 2016 workgroups = 3.94 waves).
 WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
   WgradPlan pl;
   const int64_t K = (int64_t)d->KH * d->KW * d->Cin;
   const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
-  const int bn = d->Cout > 64 ? 128 : (d->Cout > 32 ? 64 : 32);
+  const int bn = wgrad_bn(d->Cout);
   const int64_t tiles = sg_cdiv(K, BM) * sg_cdiv(d->Cout, bn);
   const int64_t nslab = sg_cdiv(P, BK);
-  // fill the 2*CUs workgroup slots once: S = floor(slots / tiles) keeps tiles*S <= slots (no ragged second wave)
-  int64_t S = ((int64_t)2 * num_cus) / tiles;
-  if (S > nslab / 4) S = nslab / 4;  // at least 4 slabs per split
-  if (S < 1) S = 1;
-  // keep the partial slab under 256 MiB
-  while (S > 1 && S * K * d->Cout * 4 > (256ll << 20)) --S;
-  pl.slabs_per_split = (int)sg_cdiv(nslab, S);
+  const int64_t slots = 2 * (int64_t)num_cus;
+  const double flops = 2.0 * (double)tiles * BM * bn * (double)P;  // padded tile work
+  int64_t maxS = nslab / 8;  // at least 8 slabs per split
+  if (maxS < 1) maxS = 1;
+  if (maxS > 512) maxS = 512;
+  double best_t = 1e300;
+  int64_t best_S = 1;
+  for (int64_t S = 1; S <= maxS; ++S) {
+    const int64_t wgs = tiles * S;
+    const double eff = (double)wgs / (double)(sg_cdiv(wgs, slots) * slots);
+    const double part_bytes = S > 1 ? (double)S * (double)K * d->Cout * 4.0 : 0.0;
+    if (part_bytes > (double)(384ll << 20)) break;
+    const double t = flops / (eff * 110e12) + 2.0 * part_bytes / 3.0e12 + (S > 1 ? 3e-6 : 0.0);
+    if (t < best_t * 0.999) { best_t = t; best_S = S; }
+  }
+  pl.slabs_per_split = (int)sg_cdiv(nslab, best_S);
   pl.S = (int)sg_cdiv(nslab, pl.slabs_per_split);
   pl.dw_part_bytes = pl.S > 1 ? (size_t)pl.S * K * d->Cout * 4 : 0;
   pl.bias_part_bytes = colsum_ws_bytes(num_cus, P, d->Cout);
