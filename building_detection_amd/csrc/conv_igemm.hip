@@ -49,6 +49,7 @@ struct IgemmParams {
   int K, M;
   int flags;
   int stagger;  // waves in the upper half of the workgroup issue their gathers AFTER their MFMAs
+  int ablate;   // timing-only diagnostics (results wrong): 1 = no global loads in the loop, 2 = no LDS store/barrier
   FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
 };
 
@@ -293,19 +294,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
     load_AB((1 < last ? 1 : last) * BK, IC<1>{});
     store_AB(0, IC<0>{});
     __syncthreads();
+    const bool do_ld = !(p.ablate & 1), do_st = !(p.ablate & 2);
     for (int s = 0; s < nslab; s += 2) {
       const int ka = (s + 2 < last ? s + 2 : last) * BK, kb = (s + 3 < last ? s + 3 : last) * BK;
-      if (!late) load_AB(ka, IC<0>{});
+      if (!late && do_ld) load_AB(ka, IC<0>{});
       compute(0);
-      if (late) load_AB(ka, IC<0>{});
-      store_AB(1, IC<1>{});
-      __syncthreads();
+      if (late && do_ld) load_AB(ka, IC<0>{});
+      if (do_st) {
+        store_AB(1, IC<1>{});
+        __syncthreads();
+      }
       if (s + 1 >= nslab) break;
-      if (!late) load_AB(kb, IC<1>{});
+      if (!late && do_ld) load_AB(kb, IC<1>{});
       compute(1);
-      if (late) load_AB(kb, IC<1>{});
-      store_AB(0, IC<0>{});
-      __syncthreads();
+      if (late && do_ld) load_AB(kb, IC<1>{});
+      if (do_st) {
+        store_AB(0, IC<0>{});
+        __syncthreads();
+      }
     }
   }
 
@@ -670,6 +676,14 @@ int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t s
   const int bn = pick_bn(p.M, p.Nout, num_cus);
   const int var = conv_variant() & 3;
   p.stagger = (conv_variant() >> 2) & 1;
+  {
+    static int abl = -1;
+    if (abl < 0) {
+      const char* e = getenv("SG_CONV_ABLATE");
+      abl = e ? atoi(e) & 3 : 0;
+    }
+    p.ablate = abl;
+  }
   if (!vec) {
     if (bn == 128) return launch_igemm<128, 2, 4, 1, false>(p, st);
     if (bn == 64) return launch_igemm<64, 4, 2, 1, false>(p, st);

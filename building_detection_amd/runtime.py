@@ -222,6 +222,23 @@ class Model:
             rt.release()
         return np.concatenate(outs, 0)
 
+    def _last_use(self):
+        lu = getattr(self, "_lu", None)
+        if lu is None:
+            lu = {}
+            for i, n in enumerate(self.nodes):
+                for t in n.inputs:
+                    lu[id(t)] = i
+            lu.pop(id(self.outputs[0]), None)
+            self._lu = lu
+        return lu
+
+    def capture_predict(self, batch: int):
+        """hipGraph-captured inference forward for a fixed batch (BASELINE config 5): returns a callable
+        `f(x_dev[batch,H,W,3]) -> probs_dev` that replays ONE graph launch instead of several hundred kernel
+        launches.  Every libsegengine entry point is capture-safe (no allocation / synchronisation inside)."""
+        return GraphedPredict(self, batch)
+
     def predict_device(self, x_dev):
         """Device tensor in, device tensor out (used by the tile pipeline and the benchmark)."""
         rt = self._runtime()
@@ -341,6 +358,30 @@ class Model:
         return self.fit_generator(gen(), steps_per_epoch=steps, epochs=epochs, **kw)
 
 
+class GraphedPredict:
+    """Static-shape inference forward captured into a hipGraph (stream capture of the engine's launches)."""
+
+    def __init__(self, model: Model, batch: int):
+        import torch
+        rt = model._runtime()
+        self.torch, self.rt = torch, rt
+        shape = (batch,) + tuple(model.inputs[0].shape[1:])
+        self.x = rt.eng.zeros(*shape)
+        for _ in range(2):  # warm-up outside capture: workspace growth, first-launch attribute calls
+            rt.forward(self.x, training=False)
+            rt.release()
+        torch.cuda.synchronize(rt.eng.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.y = rt.forward(self.x, training=False)
+        rt.values = {}
+
+    def __call__(self, x_dev):
+        self.x.copy_(x_dev, non_blocking=True)
+        self.graph.replay()
+        return self.y
+
+
 class _Runtime:
     """Device state of one model: arenas, saved activations, gradient bookkeeping."""
 
@@ -416,9 +457,21 @@ class _Runtime:
         if tuple(x.shape[1:]) != tuple(exp):
             raise ValueError(f"input shape {tuple(x.shape)} does not match the model's {(None,) + tuple(exp)}")
         self.values = {id(m.inputs[0]): x.contiguous()}
-        for n in m.nodes:
+        if training:
+            for n in m.nodes:
+                xs = [self.values[id(t)] for t in n.inputs]
+                self.values[id(n.output)] = n.forward(self, xs, training)
+            return self.values[id(m.outputs[0])]
+        # inference: an activation is dropped as soon as its last consumer has run (the allocator - or the
+        # hipGraph's private pool under capture - reuses the block), so peak memory is the live set, not the sum
+        last_use = m._last_use()
+        for i, n in enumerate(m.nodes):
             xs = [self.values[id(t)] for t in n.inputs]
-            self.values[id(n.output)] = n.forward(self, xs, training)
+            self.values[id(n.output)] = n.forward(self, xs, False)
+            for t in n.inputs:
+                if last_use.get(id(t)) == i:
+                    self.values.pop(id(t), None)
+            del xs
         return self.values[id(m.outputs[0])]
 
     def backward(self, dout):
