@@ -50,6 +50,7 @@ struct IgemmParams {
   int flags;
   int stagger;  // waves in the upper half of the workgroup issue their gathers AFTER their MFMAs
   int ablate;   // timing-only diagnostics (results wrong): 1 = no global loads in the loop, 2 = no LDS store/barrier
+  uint32_t x_bytes, w_bytes;  // extents for the buffer descriptors of the UT path (both < 2^31)
   FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
 };
 
@@ -115,21 +116,30 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
     return v;
   };
 
-  // running state of the slab stream (UT mode): current tap and, per row, its source offset / validity
+  // ---- UT path: hardware buffer addressing ------------------------------------------------------------
+  // Per row, the byte offset of the current tap's source pixel (plus this lane's 16-byte chunk) lives in a
+  // VGPR for the whole tap; the slab's channel advance is the scalar soffset of the buffer load; rows whose tap
+  // is out of bounds carry an offset beyond num_records, for which the hardware returns 0 (no select, no
+  // branch).
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr unsigned OOB = 0x80000000u;
   int cur_tap = -1;
-  int64_t tap_off[NA];
-  bool tap_ok[NA];
+  unsigned tap_voff[NA];
+  unsigned b_voff[NB];
 #pragma unroll
-  for (int j = 0; j < NA; ++j) { tap_off[j] = 0; tap_ok[j] = false; }
-  const int ntaps = p.K / p.C;
-  bool bn_ok[NB];
-  int64_t b_off[NB];
+  for (int j = 0; j < NA; ++j) tap_voff[j] = OOB;
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int idx = t + NT * i;
     const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-    bn_ok[i] = (n0 + 4 * c4) < p.Nout;
-    b_off[i] = (int64_t)kr * p.Nout + n0 + 4 * c4;
+    b_voff[i] = (n0 + 4 * c4) < p.Nout ? (unsigned)(kr * p.Nout + n0 + 4 * c4) * 4u : OOB;
+  }
+  const int ntaps = p.K / p.C;
+  const bool ktail = (p.K % BK) != 0;
+  __amdgpu_buffer_rsrc_t rsrc_x, rsrc_w;
+  if constexpr (VEC && UT) {
+    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.w), 0, (int)p.w_bytes, 0x00020000);
   }
 
   // loads of slab k0 into register set S (compile-time): branch-free, invalid lanes read element 0
@@ -143,26 +153,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
         fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
         const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) tap_ok[j] = gather_elem_addr(j, dh, dw, tap < ntaps, tap_off[j]);
+        for (int j = 0; j < NA; ++j) {
+          int64_t off;
+          const bool ok = gather_elem_addr(j, dh, dw, tap < ntaps, off);
+          tap_voff[j] = ok ? (unsigned)off * 4u + 16u * kc : OOB;
+        }
       }
-      const int k = k0 + 4 * kc;
-      const int ci = k - tap * p.C;
-      const bool kvalid = k < p.K;
+      const int soff_a = (k0 - tap * p.C) * 4;             // channel offset inside the tap, bytes (scalar)
+      const int soff_b = k0 * p.Nout * 4;
+      const bool kvalid = !ktail || (k0 + 4 * kc < p.K);   // only a ragged last slab (e.g. K = 728) masks lanes
 #pragma unroll
       for (int j = 0; j < NA; ++j) {
-        const bool v = kvalid && tap_ok[j];
-        const f32x4 val = *reinterpret_cast<const f32x4*>(p.x + (v ? tap_off[j] + ci : 0));
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        ra[S][j] = v ? val : z;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
+        ra[S][j] = __builtin_bit_cast(f32x4, v);
       }
 #pragma unroll
       for (int i = 0; i < NB; ++i) {
-        const int idx = t + NT * i;
-        const int kr = idx / (BN / 4);
-        const bool v = bn_ok[i] && (k0 + kr < p.K);
-        const f32x4 val = *reinterpret_cast<const f32x4*>(p.w + (v ? b_off[i] + (int64_t)k0 * p.Nout : 0));
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        rb[S][i] = v ? val : z;
+        // the scalar offset takes no part in the hardware range check, so a ragged last slab masks its rows
+        const bool bv = !ktail || (k0 + (t + NT * i) / (BN / 4) < p.K);
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)(bv ? b_voff[i] : OOB), soff_b, 0);
+        rb[S][i] = __builtin_bit_cast(f32x4, v);
       }
       return;
     }
@@ -368,10 +378,15 @@ struct WgradParams {
   int K, P;
   int slabs_per_split;
   int stagger;
+  uint32_t x_bytes, dy_bytes;  // extents for the buffer descriptors of the FAST path (both < 2^31)
   FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
 };
 
-template <int BN, int WGM, int WGN, int PF, bool VEC>
+// FAST: stride-1 "same" convolution (H == Ho, W == Wo) with 16-byte-aligned channel runs: the source pixel of
+// output pixel p under tap (dh,dw) is p + dh*W + dw, i.e. LINEAR in p, so the gather offset advances by a constant
+// per slab; only the tap's bounds flags depend on (oh, ow), which are carried incrementally (no div/mod), and
+// invalid taps / rows are sent to an out-of-range buffer offset (hardware returns 0).
+template <int BN, int WGM, int WGN, int PF, bool VEC, bool FAST>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_kernel(const WgradParams p) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -418,8 +433,67 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
   f32x4 ra[PF][NA];
   f32x4 rb[PF][NB];
 
+  // ---- FAST path state --------------------------------------------------------------------------------
+  typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+  constexpr unsigned OOB = 0x80000000u;
+  int f_oh[NA], f_ow[NA], f_p[NA];   // (oh, ow) and pixel index of this thread's rows in the NEXT slab to load
+  unsigned f_voff[NA];               // byte offset of x[p + dh*W + dw][ci] for that slab
+  unsigned b_voff[NB];
+  int f_next = slab_begin * BK;      // pixel index the running state corresponds to
+  __amdgpu_buffer_rsrc_t rsrc_x, rsrc_dy;
+  const int adv_oh = BK / p.OW, adv_ow = BK % p.OW;
+  if constexpr (FAST) {
+    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const int pp = f_next + pr0 + PS * j;
+      uint32_t n, rem, oh, ow;
+      fd_divmod((uint32_t)pp, p.fd_ohow, n, rem);
+      fd_divmod(rem, p.fd_ow, oh, ow);
+      f_oh[j] = (int)oh; f_ow[j] = (int)ow; f_p[j] = pp;
+      f_voff[j] = (unsigned)((pp + dh[0] * p.W + dw[0]) * p.x_ld + ci_e[0]) * 4u;  // may wrap when the tap is invalid
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + NT * i;
+      const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+      b_voff[i] = (n0 + 4 * c4) < p.Cout ? (unsigned)(kr * p.y_ld + n0 + 4 * c4) * 4u : OOB;
+    }
+  }
+
   auto load_AB = [&](int p0, auto SET) {
     constexpr int S = decltype(SET)::value;
+    if constexpr (FAST) {
+      // the slab stream is sequential except for the repeated (unused) tail slab: advance only when it moves on
+      if (p0 != f_next) {  // uniform
+        f_next = p0;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          f_p[j] += BK;
+          f_voff[j] += (unsigned)(BK * p.x_ld) * 4u;
+          f_ow[j] += adv_ow;
+          f_oh[j] += adv_oh;
+          if (f_ow[j] >= p.OW) { f_ow[j] -= p.OW; f_oh[j] += 1; }
+          while (f_oh[j] >= p.OH) f_oh[j] -= p.OH;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const int ih = f_oh[j] + dh[0], iw = f_ow[j] + dw[0];
+        const bool v = rvalid[0] && (f_p[j] < p.P) && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+        const u32x4 val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? f_voff[j] : OOB), 0, 0);
+        ra[S][j] = __builtin_bit_cast(f32x4, val);
+      }
+      const int soff_b = p0 * p.y_ld * 4;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const bool bv = (p0 + (t + NT * i) / (BN / 4)) < p.P;  // soffset is not range-checked
+        const u32x4 val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)(bv ? b_voff[i] : OOB), soff_b, 0);
+        rb[S][i] = __builtin_bit_cast(f32x4, val);
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int pp = p0 + pr0 + PS * j;
@@ -645,7 +719,8 @@ int launch_igemm_ut(const IgemmParams& p, hipStream_t st) {
 template <int BN, int WGM, int WGN, int PF, bool VEC>
 int launch_igemm(const IgemmParams& p, hipStream_t st) {
   if constexpr (VEC) {
-    const bool ut = (p.C % BK == 0) || (p.K == p.C);  // slab never straddles a tap
+    // slab never straddles a tap, and both operands fit a 2 GiB buffer descriptor
+    const bool ut = ((p.C % BK == 0) || (p.K == p.C)) && p.x_bytes != 0 && p.w_bytes != 0;
     if (ut) return launch_igemm_ut<BN, WGM, WGN, PF, true, true>(p, st);
   }
   return launch_igemm_ut<BN, WGM, WGN, PF, VEC, false>(p, st);
@@ -708,19 +783,28 @@ int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t s
   return (var & 2) ? launch_igemm<32, 4, 1, 2, true>(p, st) : launch_igemm<32, 4, 1, 1, true>(p, st);
 }
 
-template <int BN, int WGM, int WGN, int PF, bool VEC>
-int launch_wgrad(const WgradParams& p, int S, hipStream_t st) {
+template <int BN, int WGM, int WGN, int PF, bool VEC, bool FAST>
+int launch_wgrad_f(const WgradParams& p, int S, hipStream_t st) {
   constexpr size_t lds = (size_t)(2 * BK * BM + 2 * BK * BN) * sizeof(float);
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC>, lds);
+    int rc = set_dyn_lds(igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST>, lds);
     if (rc) return rc;
     attr_done = true;
   }
   const int64_t tiles = sg_cdiv(p.K, BM) * sg_cdiv(p.Cout, BN);
-  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("igemm_wgrad_kernel");
   return 0;
+}
+
+template <int BN, int WGM, int WGN, int PF, bool VEC>
+int launch_wgrad(const WgradParams& p, int S, hipStream_t st) {
+  if constexpr (VEC && PF == 2) {
+    const bool fast = p.stride == 1 && p.OH == p.H && p.OW == p.W && p.x_bytes != 0 && p.dy_bytes != 0;
+    if (fast) return launch_wgrad_f<BN, WGM, WGN, PF, true, true>(p, S, st);
+  }
+  return launch_wgrad_f<BN, WGM, WGN, PF, VEC, false>(p, S, st);
 }
 
 inline int wgrad_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
@@ -836,6 +920,11 @@ int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, c
   p.fd_ow = make_fastdiv((uint32_t)d->Wo);
   p.fd_c = make_fastdiv((uint32_t)d->Cin);
   p.fd_kw = make_fastdiv((uint32_t)d->KW);
+  {
+    const int64_t xb = (((int64_t)d->N * d->H * d->W - 1) * p.x_ld + d->Cin) * 4, wb = (int64_t)p.K * d->Cout * 4;
+    p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
+    p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
+  }
   const bool vec = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
   return dispatch_igemm(p, vec, ctx->num_cus, (hipStream_t)stream);
 }
@@ -886,6 +975,11 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   p.fd_ow = make_fastdiv((uint32_t)d->W);
   p.fd_c = make_fastdiv((uint32_t)d->Cout);
   p.fd_kw = make_fastdiv((uint32_t)d->KW);
+  {
+    const int64_t xb = (((int64_t)d->N * d->Ho * d->Wo - 1) * p.x_ld + d->Cout) * 4, wb = (int64_t)p.K * d->Cin * 4;
+    p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
+    p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
+  }
   const bool vec = (d->Cout % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy);
   return dispatch_igemm(p, vec, ctx->num_cus, st);
 }
@@ -925,6 +1019,12 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   p.fd_ow = make_fastdiv((uint32_t)d->Wo);
   p.fd_c = make_fastdiv((uint32_t)d->Cin);
   p.fd_kw = make_fastdiv((uint32_t)d->KW);
+  {
+    const int64_t xb = (((int64_t)d->N * d->H * d->W - 1) * p.x_ld + d->Cin) * 4;
+    const int64_t yb = (((int64_t)p.P - 1) * p.y_ld + d->Cout) * 4;
+    p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
+    p.dy_bytes = yb < (1ll << 31) ? (uint32_t)yb : 0;
+  }
   const bool vec = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cout % 4 == 0) && (p.y_ld % 4 == 0) &&
                    aligned16(x) && aligned16(dy);
   rc = dispatch_wgrad(p, pl.S, vec, st);
