@@ -32,6 +32,8 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
     const int64_t rb = (int64_t)z * per;
     int64_t re = rb + per;
     if (re > rows) re = rows;
+    // four rows per trip so four independent 16-byte loads per operand are in flight per thread
+#pragma unroll 4
     for (int64_t r = rb + ty; r < re; r += TY) op.template accum<V>(seg, r, c, acc);
   }
   float* mine = red + ((size_t)(ty * TX + tx)) * (NO * V);

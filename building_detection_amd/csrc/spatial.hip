@@ -130,6 +130,140 @@ struct DwWgradOp {
   }
 };
 
+// ---- stride-1 3x3 'same' fast paths: each thread owns one 16-byte channel chunk and a run of 4 output columns,
+// so the 3 x 6 input window is loaded once (18 loads for 4 outputs instead of 36) and the 9 kernel taps live in
+// registers.  Forward and dgrad are the same stencil (dgrad: kernel flipped, dy as input, optional [x > 0] mask).
+struct DwRunParams {
+  const float* __restrict__ in;    // x (fwd) or dy (dgrad)
+  const float* __restrict__ w;     // [3][3][C]
+  const float* __restrict__ mask;  // dgrad with pre_relu: forward input, else null
+  float* __restrict__ out;
+  int N, H, W, C, in_ld, out_ld, mask_ld, relu_in, flip;
+  int runs_per_row;                // W / 4
+  int64_t nruns;                   // N * H * runs_per_row
+  FastDiv fd_rpr, fd_h;
+};
+
+__global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams p) {
+  const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  if (c >= p.C) return;
+  f32x4 wt[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (p.flip ? 8 - t : t) * p.C + c);
+  const int64_t stride = (int64_t)gridDim.y * 4;
+  for (int64_t run = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); run < p.nruns; run += stride) {
+    uint32_t rowi, q, n, oh;
+    fd_divmod((uint32_t)run, p.fd_rpr, rowi, q);
+    fd_divmod(rowi, p.fd_h, n, oh);
+    const int ow0 = (int)q * 4;
+    f32x4 acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int ih = (int)oh - 1 + a;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      const float* rowp = p.in + ((int64_t)(n * p.H + ih) * p.W) * p.in_ld + c;
+      f32x4 v[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int iw = ow0 - 1 + b;
+        const bool ok = (unsigned)iw < (unsigned)p.W;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(rowp + (int64_t)(ok ? iw : 0) * p.in_ld);
+        v[b] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (p.relu_in) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[b][e] = fmaxf(v[b][e], 0.f);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) acc[k] += v[k + b] * wt[a * 3 + b];
+    }
+    const int64_t opix = ((int64_t)(n * p.H + oh) * p.W + ow0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      f32x4 o = acc[k];
+      if (p.mask) {
+        const f32x4 m = *reinterpret_cast<const f32x4*>(p.mask + (opix + k) * p.mask_ld + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = m[e] > 0.f ? o[e] : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(p.out + (opix + k) * p.out_ld + c) = o;
+    }
+  }
+}
+
+// wgrad, same window: a "row" of the segmented reducer is a run of 4 output pixels
+struct DwWgradRunOp {
+  static constexpr int NOUT = 9;
+  const float* __restrict__ x;
+  const float* __restrict__ dy;
+  float* dw;
+  int H, W, C, x_ld, y_ld, pre_relu;
+  FastDiv fd_rpr, fd_h;
+  template <int V>
+  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[9][V]) const {
+    if constexpr (V != 4) {
+      return;  // the run path is only planned with 16-byte chunks (seg_plan vec_ok = true, C % 4 == 0)
+    } else {
+    uint32_t rowi, q, n, oh;
+    fd_divmod((uint32_t)r, fd_rpr, rowi, q);
+    fd_divmod(rowi, fd_h, n, oh);
+    const int ow0 = (int)q * 4;
+    f32x4 g[4];
+    const float* gp = dy + ((int64_t)(n * H + oh) * W + ow0) * y_ld + c;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) g[k] = *reinterpret_cast<const f32x4*>(gp + (int64_t)k * y_ld);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int ih = (int)oh - 1 + a;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      const float* rowp = x + ((int64_t)(n * H + ih) * W) * x_ld + c;
+      f32x4 v[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const int iw = ow0 - 1 + b;
+        const bool ok = (unsigned)iw < (unsigned)W;
+        const f32x4 t = *reinterpret_cast<const f32x4*>(rowp + (int64_t)(ok ? iw : 0) * x_ld);
+        v[b] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (pre_relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[b][e] = fmaxf(v[b][e], 0.f);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 3; ++b)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[a * 3 + b][e] = fmaf(v[k + b][e], g[k][e], acc[a * 3 + b][e]);
+    }
+    }
+  }
+  __device__ __forceinline__ void finalize(int, int c, const double (&s)[9]) const {
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dw[t * C + c] = (float)s[t];
+  }
+};
+
+inline bool dw_run_ok(const sg_conv_desc* d) {
+  return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dilation == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+         d->Ho == d->H && d->Wo == d->W && (d->W % 4 == 0) && (d->Cin % 4 == 0);
+}
+
+int launch_dw_run(const DwRunParams& p, hipStream_t st) {
+  const unsigned gx = (unsigned)sg_cdiv(p.C / 4, 64);
+  int64_t gy = sg_cdiv(p.nruns, 4);
+  const int64_t cap = sg_cdiv(16384, gx);
+  if (gy > cap) gy = cap;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(dw_s1_run_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
+  SG_LAUNCH_CHECK("dw_s1_run_kernel");
+  return 0;
+}
+
 // ---------------------------------------------------------------------------------------------- pooling
 struct PoolParams {
   const float* __restrict__ x;
@@ -365,6 +499,14 @@ int sg_dwconv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   dw_fill(p, d);
   p.x = (const float*)x; p.w = (const float*)w; p.dy = nullptr; p.out = (float*)y; p.pre_relu = pre_relu;
   const bool vec = (p.C % 4 == 0) && (p.x_ld % 4 == 0) && (p.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(w) && sg_aligned16(y);
+  if (vec && dw_run_ok(d)) {
+    DwRunParams r;
+    r.in = (const float*)x; r.w = (const float*)w; r.mask = nullptr; r.out = (float*)y;
+    r.N = d->N; r.H = d->H; r.W = d->W; r.C = p.C; r.in_ld = p.x_ld; r.out_ld = p.y_ld; r.mask_ld = 0;
+    r.relu_in = pre_relu; r.flip = 0; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
+    r.fd_rpr = make_fastdiv((uint32_t)r.runs_per_row); r.fd_h = make_fastdiv((uint32_t)d->H);
+    return launch_dw_run(r, (hipStream_t)stream);
+  }
   const int V = vec ? 4 : 1;
   p.fd_cv = make_fastdiv((uint32_t)(p.C / V)); p.fd_w = make_fastdiv((uint32_t)p.Wo); p.fd_h = make_fastdiv((uint32_t)p.Ho);
   const unsigned blocks = ew_blocks((int64_t)p.N * p.Ho * p.Wo * (p.C / V));
@@ -385,6 +527,14 @@ int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
   p.x = (const float*)x_for_mask; p.w = (const float*)w; p.dy = (const float*)dy; p.out = (float*)dx; p.pre_relu = pre_relu;
   const bool vec = (p.C % 4 == 0) && (p.x_ld % 4 == 0) && (p.y_ld % 4 == 0) && sg_aligned16(dy) && sg_aligned16(w) &&
                    sg_aligned16(dx) && (!pre_relu || sg_aligned16(x_for_mask));
+  if (vec && dw_run_ok(d)) {  // stride-1 dgrad = the same stencil with the kernel flipped
+    DwRunParams r;
+    r.in = (const float*)dy; r.w = (const float*)w; r.mask = pre_relu ? (const float*)x_for_mask : nullptr; r.out = (float*)dx;
+    r.N = d->N; r.H = d->H; r.W = d->W; r.C = p.C; r.in_ld = p.y_ld; r.out_ld = p.x_ld; r.mask_ld = p.x_ld;
+    r.relu_in = 0; r.flip = 1; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
+    r.fd_rpr = make_fastdiv((uint32_t)r.runs_per_row); r.fd_h = make_fastdiv((uint32_t)d->H);
+    return launch_dw_run(r, (hipStream_t)stream);
+  }
   const int V = vec ? 4 : 1;
   p.fd_cv = make_fastdiv((uint32_t)(p.C / V)); p.fd_w = make_fastdiv((uint32_t)p.W); p.fd_h = make_fastdiv((uint32_t)p.H);
   const unsigned blocks = ew_blocks((int64_t)p.N * p.H * p.W * (p.C / V));
@@ -398,7 +548,10 @@ size_t sg_dwconv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
   if (!ctx || !d) return 0;
   const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
   const SegPlan a = seg_plan<9>(ctx->num_cus, 1, rows, d->Cin, true), b = seg_plan<9>(ctx->num_cus, 1, rows, d->Cin, false);
-  return (a.part_bytes > b.part_bytes ? a.part_bytes : b.part_bytes) + 256;
+  const SegPlan r = seg_plan<9>(ctx->num_cus, 1, sg_cdiv(rows, 4), d->Cin, true);
+  size_t m = a.part_bytes > b.part_bytes ? a.part_bytes : b.part_bytes;
+  if (r.part_bytes > m) m = r.part_bytes;
+  return m + 256;
 }
 
 int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
@@ -415,6 +568,19 @@ int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
   op.fd_w = make_fastdiv((uint32_t)d->Wo); op.fd_h = make_fastdiv((uint32_t)d->Ho);
   const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
   const bool vec = (op.C % 4 == 0) && (op.x_ld % 4 == 0) && (op.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy);
+  if (vec && dw_run_ok(d)) {
+    DwWgradRunOp ro;
+    ro.x = (const float*)x; ro.dy = (const float*)dy; ro.dw = (float*)dw; ro.H = d->H; ro.W = d->W; ro.C = op.C;
+    ro.x_ld = op.x_ld; ro.y_ld = op.y_ld; ro.pre_relu = pre_relu;
+    ro.fd_rpr = make_fastdiv((uint32_t)(d->W / 4)); ro.fd_h = make_fastdiv((uint32_t)d->H);
+    const int64_t nruns = rows / 4;
+    const SegPlan rp = seg_plan<9>(ctx->num_cus, 1, nruns, op.C, true);
+    if (!ws || ws_bytes < rp.part_bytes) {
+      sg_set_error("sg_dwconv2d_wgrad: workspace %zu < %zu", ws_bytes, rp.part_bytes);
+      return SG_EWORKSPACE;
+    }
+    return seg_reduce_launch(ro, rp, 1, nruns, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad_run");
+  }
   const SegPlan pl = seg_plan<9>(ctx->num_cus, 1, rows, op.C, vec);
   if (!ws || ws_bytes < pl.part_bytes) {
     sg_set_error("sg_dwconv2d_wgrad: workspace %zu < %zu", ws_bytes, pl.part_bytes);

@@ -165,6 +165,37 @@ __global__ void vote_kernel(const VoteArgs a, int64_t n, int k, unsigned char* _
   }
 }
 
+// train_data_gen label channels (train_model/DeepLabv3plus.py:70-100): one-hot by integer truncation (only
+// label == 1.0 is class 1), 5 x erode / dilate with a 3x3 kernel == 11x11 min / max box (out-of-image cells are
+// ignored, as cv.erode / cv.dilate's default border does), p_edge = 2 where label - erode == 1, f_edge = 2
+// where dilate - label == 1; channel order (bg, fg, f_edge, p_edge).
+__global__ void edge_labels_kernel(const float* __restrict__ lab, float* __restrict__ y, int N, int H, int W, int radius) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)N * H * W) return;
+  const int w = (int)(i % W), h = (int)((i / W) % H);
+  const int64_t base = i - (int64_t)h * W - w;
+  const float m = lab[i];
+  float er = m, di = m;
+  for (int a = -radius; a <= radius; ++a) {
+    const int hh = h + a;
+    if ((unsigned)hh >= (unsigned)H) continue;
+    for (int b = -radius; b <= radius; ++b) {
+      const int ww = w + b;
+      if ((unsigned)ww >= (unsigned)W) continue;
+      const float v = lab[base + (int64_t)hh * W + ww];
+      er = fminf(er, v);
+      di = fmaxf(di, v);
+    }
+  }
+  const float fg = ((int)m == 1) ? 1.f : 0.f;
+  float4 o;
+  o.x = 1.f - fg;
+  o.y = fg;
+  o.z = (di - m == 1.f) ? 2.f : 1.f;
+  o.w = (m - er == 1.f) ? 2.f : 1.f;
+  *reinterpret_cast<float4*>(y + 4 * i) = o;
+}
+
 inline int loss_parts(int64_t rows) {
   int64_t b = sg_cdiv(rows, 256 * 4);
   if (b > 2048) b = 2048;
@@ -235,6 +266,15 @@ int sg_adam_step(sg_ctx* ctx, void* stream, int64_t n, void* w, void* m, void* v
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, (float*)w, (float*)m,
                      (float*)v, (const float*)g, lr_t, beta1, beta2, eps, grad_scale);
   SG_LAUNCH_CHECK("adam_kernel");
+  return 0;
+}
+
+int sg_edge_labels(sg_ctx* ctx, void* stream, int N, int H, int W, int iterations, const void* label, void* y_true4) {
+  SG_CHECK_ARG(ctx && label && y_true4 && N > 0 && H > 0 && W > 0 && iterations >= 0, "sg_edge_labels: bad argument");
+  const int64_t n = (int64_t)N * H * W;
+  hipLaunchKernelGGL(edge_labels_kernel, dim3((unsigned)sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)label, (float*)y_true4, N, H, W, iterations);
+  SG_LAUNCH_CHECK("edge_labels_kernel");
   return 0;
 }
 

@@ -412,6 +412,14 @@ class Engine:
         check(self.lib.sg_adam_step(self.h, self.stream, w.numel(), _ptr(w), _ptr(m), _ptr(v), _ptr(g), float(lr_t), beta1,
                                     beta2, eps, float(grad_scale)), "sg_adam_step")
 
+    def edge_labels(self, label, iterations=5):
+        """label [N,H,W] float (gray/255) -> y_true [N,H,W,4] as train_data_gen builds it (DeepLabv3plus.py:70-100)."""
+        _chk(label, "label")
+        n, h, w = label.shape
+        y = self.empty(n, h, w, 4)
+        check(self.lib.sg_edge_labels(self.h, self.stream, n, h, w, iterations, _ptr(label), _ptr(y)), "sg_edge_labels")
+        return y
+
     # -------------------------------------------------------------------------------------- inference tail
     def argmax_accumulate(self, p, canvas, y0, x0):
         th, tw = p.shape[-3], p.shape[-2]

@@ -240,6 +240,13 @@ int sg_confusion_counts(sg_ctx* ctx, void* stream, int64_t rows, int y_cols, con
 int sg_adam_step(sg_ctx* ctx, void* stream, int64_t n, void* w, void* m, void* v, const void* g,
                  float lr_t, float beta1, float beta2, float eps, float grad_scale);
 
+/* Label channels of train_data_gen (DeepLabv3plus.py:70-100) from label[N,H,W] (gray/255, float): y[N,H,W,4] =
+ * (1-fg, fg, f_edge, p_edge); fg = 1 iff label == 1.0 (to_categorical truncation); `iterations` (5 in the
+ * reference) erosions / dilations with a 3x3 kernel = (2*iterations+1)^2 min / max box ignoring out-of-image
+ * cells; p_edge = 2 where label - erode == 1 else 1; f_edge = 2 where dilate - label == 1 else 1. */
+int sg_edge_labels(sg_ctx* ctx, void* stream, int N, int H, int W, int iterations, const void* label,
+                   void* y_true4);
+
 /* ------------------------------------------------------------------------------------ inference tail
  * predict.py:110-114: mask = argmax(p) (ties -> 0) added as int8 into the canvas window at (y0,x0) of a
  * [CH,CW] canvas; tile is [TH,TW] probabilities p[TH*TW,2]. */

@@ -134,6 +134,23 @@ def test_depthwise(engine, c, stride, pre_relu):
     close(dw, wr.grad, what="dw wgrad")
 
 
+@pytest.mark.parametrize("c,h,w,pre_relu", [(728, 12, 16, True), (64, 9, 20, False), (128, 32, 32, True), (4, 5, 4, False)])
+def test_depthwise_stride1_register_window_path(engine, c, h, w, pre_relu):
+    """W % 4 == 0, stride 1: the run kernels (4 outputs per thread) for forward, dgrad (flipped taps + mask), wgrad."""
+    g = torch.Generator().manual_seed(c + h + w)
+    x = rnd(g, 3, h, w, c)
+    wt = rnd(g, 3, 3, c, 1)
+    xr, wr = x.clone().requires_grad_(), wt.clone().requires_grad_()
+    yr = T.depthwise_conv2d(torch.relu(xr) if pre_relu else xr, wr, 1)
+    dy = rnd(g, *yr.shape)
+    yr.backward(dy)
+    xd, wd, dyd = x.cuda(), wt.cuda(), dy.cuda()
+    close(engine.dwconv_fwd(xd, wd, 1, pre_relu), yr, what="dw run fwd")
+    d = engine.conv_desc(x.shape, c, 3, 3, 1, 1, "same")
+    close(engine.dwconv_dgrad(dyd, wd, d, x=xd, pre_relu=pre_relu), xr.grad, what="dw run dgrad")
+    close(engine.dwconv_wgrad(xd, dyd, d, pre_relu), wr.grad, what="dw run wgrad")
+
+
 @pytest.mark.parametrize("shape,relu", [((4, 16, 16, 728), True), ((2, 9, 7, 45), False), ((16, 24), True),
                                          ((2, 64, 64, 64), True)])
 def test_batchnorm(engine, shape, relu):
@@ -346,6 +363,19 @@ def test_adam(engine):
     close(md, m2, what="adam m")
     close(vd, v2, what="adam v")
     close(wd, w2, what="adam w")
+
+
+def test_edge_labels_match_generator(engine):
+    """sg_edge_labels vs the host restatement of train_data_gen's label channels (building_detection_amd.data)."""
+    from building_detection_amd.data import synthetic_batch
+    _, y = synthetic_batch(3, 96, 80, seed=4)
+    lab = torch.from_numpy(np.ascontiguousarray(y[..., 1])).cuda()
+    got = engine.edge_labels(lab).cpu().numpy()
+    assert np.array_equal(got, y)
+    soft = lab.clone()
+    soft[0, 10:20, 10:20] = 0.5  # anti-aliased label values are background for to_categorical's truncation
+    g2 = engine.edge_labels(soft).cpu().numpy()
+    assert (g2[0, 10:20, 10:20, 1] == 0).all() and (g2[0, 10:20, 10:20, 0] == 1).all()
 
 
 def test_inference_tail(engine):
