@@ -51,7 +51,8 @@ struct IgemmParams {
   int stagger;  // waves in the upper half of the workgroup issue their gathers AFTER their MFMAs
   int ablate;   // timing-only diagnostics (results wrong): 1 = no global loads in the loop, 2 = no LDS store/barrier
   uint32_t x_bytes, w_bytes;  // extents for the buffer descriptors of the UT path (both < 2^31)
-  FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
+  int skip_taps;              // drop taps that are pure padding for the whole tile (dilated convs)
+  FastDiv fd_ohow, fd_ow, fd_c, fd_kw, fd_spt;
 };
 
 // UT ("uniform tap"): Cin % 32 == 0 or a 1x1 kernel, so every 32-deep slab lies inside ONE filter tap.  The
@@ -280,19 +281,59 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
     }
   };
 
-  const int nslab = (p.K + BK - 1) / BK;
+  // ---- slab stream ------------------------------------------------------------------------------------
+  // Dilated convolutions on small maps gather mostly zero padding (rate 18 on 32x32: only 39 % of the taps are in
+  // bounds).  A tap for which ALL 128 rows of this tile fall outside the input contributes exactly nothing, so
+  // its Cin/32 slabs are dropped from the stream: one block-wide vote per tap up front, then the slab index
+  // runs over the surviving taps only (tapinfo[] in LDS maps it back to k0).
+  int nslab = (p.K + BK - 1) / BK;
+  int spt = 1;
+  bool use_map = false;
+  int* tapinfo = reinterpret_cast<int*>(Bs + 2 * BK * LDB);
+  if constexpr (VEC && UT) {
+    if (p.skip_taps && ntaps > 1) {  // uniform
+      spt = p.C / BK;
+      int nact = 0;
+      for (int tap = 0; tap < ntaps; ++tap) {
+        uint32_t kh, kw;
+        fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+        const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
+        bool any = false;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+          int64_t off;
+          any = any || gather_elem_addr(j, dh, dw, true, off);
+        }
+        if (__syncthreads_or(any ? 1 : 0)) {
+          if (t == 0) tapinfo[nact] = tap;
+          ++nact;
+        }
+      }
+      __syncthreads();
+      nslab = nact * spt;
+      use_map = true;
+    }
+  }
+  auto k0_of = [&](int s) -> int {
+    if (use_map) {
+      const int ti = (int)fd_div((uint32_t)s, p.fd_spt);
+      return tapinfo[ti] * p.C + (s - ti * spt) * BK;
+    }
+    return s * BK;
+  };
   const int last = nslab - 1;
   // Stagger (MI355X_MICROARCH "two waves per SIMD", item 9): waves i and i + nwaves/2 share a SIMD and run the
   // same program between the same barriers; the upper half defers its gather (address math + global loads)
   // until after its MFMAs, so on every SIMD one wave's VALU phase overlaps its partner's matrix phase.
   const bool late = (p.stagger != 0) && (__builtin_amdgcn_readfirstlane(t >> 6) >= (NT / 128));
+  if (nslab > 0) {
   if constexpr (PF == 1) {
-    load_AB(0, IC<0>{});
+    load_AB(k0_of(0), IC<0>{});
     store_AB(0, IC<0>{});
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
       const int buf = s & 1;
-      load_AB((s < last ? s + 1 : last) * BK, IC<0>{});  // tail reloads the last slab (unused): no branch
+      load_AB(k0_of(s < last ? s + 1 : last), IC<0>{});  // tail reloads the last slab (unused): no branch
       compute(buf);
       store_AB(buf ^ 1, IC<0>{});
       __syncthreads();
@@ -300,13 +341,13 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
   } else {
     // two register sets: while slab s is computed from LDS, slab s+1 sits in one set (landing) and slab s+2
     // is being fetched into the other; the store of a set waits only for that set's (older) loads
-    load_AB(0, IC<0>{});
-    load_AB((1 < last ? 1 : last) * BK, IC<1>{});
+    load_AB(k0_of(0), IC<0>{});
+    load_AB(k0_of(1 < last ? 1 : last), IC<1>{});
     store_AB(0, IC<0>{});
     __syncthreads();
     const bool do_ld = !(p.ablate & 1), do_st = !(p.ablate & 2);
     for (int s = 0; s < nslab; s += 2) {
-      const int ka = (s + 2 < last ? s + 2 : last) * BK, kb = (s + 3 < last ? s + 3 : last) * BK;
+      const int ka = k0_of(s + 2 < last ? s + 2 : last), kb = k0_of(s + 3 < last ? s + 3 : last);
       if (!late && do_ld) load_AB(ka, IC<0>{});
       compute(0);
       if (late && do_ld) load_AB(ka, IC<0>{});
@@ -324,6 +365,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
       }
     }
   }
+  }  // nslab > 0
 
   // ---- epilogue: bias, relu, store (each store: 2 x 128 contiguous bytes per wave) -------------------
   const bool has_bias = (p.flags & SG_EPI_BIAS) != 0;
@@ -379,6 +421,8 @@ struct WgradParams {
   int slabs_per_split;
   int stagger;
   uint32_t x_bytes, dy_bytes;  // extents for the buffer descriptors of the FAST path (both < 2^31)
+  int skip_slabs;              // drop 32-pixel slabs that are pure padding for every tap of the tile (dilated convs)
+  int KH_KW;
   FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
 };
 
@@ -404,7 +448,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
 
   const int t = threadIdx.x;
   const uint32_t ntn = (p.Cout + BN - 1) / BN;
-  const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  // with slab elimination the work per tile depends on its tap (centre-row taps skip nothing), and an
+  // XCD-contiguous order would park all the heavy taps on two XCDs: spread tiles round-robin instead
+  const uint32_t bid = p.skip_slabs ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
   const uint32_t tile_r = bid / ntn, tile_n = bid - tile_r * ntn;
   const int rbase = tile_r * BM, n0 = tile_n * BN;
 
@@ -466,7 +512,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
     constexpr int S = decltype(SET)::value;
     if constexpr (FAST) {
       // the slab stream is sequential except for the repeated (unused) tail slab: advance only when it moves on
-      if (p0 != f_next) {  // uniform
+      if (p.skip_slabs) {  // uniform: slabs are visited with gaps, so derive the state from p0 directly
+        if (p0 != f_next) {
+          f_next = p0;
+#pragma unroll
+          for (int j = 0; j < NA; ++j) {
+            const int pp = p0 + pr0 + PS * j;
+            uint32_t n, rem, oh, ow;
+            fd_divmod((uint32_t)pp, p.fd_ohow, n, rem);
+            fd_divmod(rem, p.fd_ow, oh, ow);
+            f_oh[j] = (int)oh; f_ow[j] = (int)ow; f_p[j] = pp;
+            f_voff[j] = (unsigned)((pp + dh[0] * p.W + dw[0]) * p.x_ld + ci_e[0]) * 4u;
+          }
+        }
+      } else if (p0 != f_next) {  // uniform
         f_next = p0;
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
@@ -584,34 +643,76 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
     }
   };
 
-  const int nslab = slab_end - slab_begin;  // >= 1 by construction of the split plan
-  const int last = slab_end - 1;
+  // ---- slab stream: with dilation, whole 32-pixel slabs can be padding for every tap this tile covers
+  // (rate 18 on a 32x32 map: 18 of 32 image rows per vertical tap); those are dropped.  Each thread classifies
+  // slabs in parallel, thread 0 compacts the survivors into an LDS list that the stream then walks.
+  int nslab = slab_end - slab_begin;  // >= 1 by construction of the split plan
+  int* slist = reinterpret_cast<int*>(Bs + 2 * BK * LDB);  // [1 + 1024]
+  bool use_list = false;
+  if constexpr (FAST) {
+    if (p.skip_slabs && nslab <= 1024) {  // uniform
+      use_list = true;
+      const int tap_lo = rbase / p.Cin;
+      int tap_hi = (rbase + BM - 1 < p.K ? rbase + BM - 1 : p.K - 1) / p.Cin;
+      if (tap_hi >= p.KH_KW) tap_hi = p.KH_KW - 1;
+      int* flags = slist + 1 + 1024;  // [1024]
+      for (int i = t; i < nslab; i += NT) {
+        const int pa = (slab_begin + i) * BK;
+        int pb = pa + BK - 1;
+        if (pb > p.P - 1) pb = p.P - 1;
+        uint32_t na, ra_, nb, rb_, oha, ohb, tmp;
+        fd_divmod((uint32_t)pa, p.fd_ohow, na, ra_);
+        fd_divmod((uint32_t)pb, p.fd_ohow, nb, rb_);
+        fd_divmod(ra_, p.fd_ow, oha, tmp);
+        fd_divmod(rb_, p.fd_ow, ohb, tmp);
+        bool act = na != nb;
+        for (int tap = tap_lo; tap <= tap_hi && !act; ++tap) {
+          uint32_t kh, kw;
+          fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+          const int ddh = (int)kh * p.dil - p.pad_t, ddw = (int)kw * p.dil - p.pad_l;
+          act = ((int)ohb + ddh >= 0) && ((int)oha + ddh < p.H) && (ddw > -p.W) && (ddw < p.W);
+        }
+        flags[i] = act ? 1 : 0;
+      }
+      __syncthreads();
+      if (t == 0) {
+        int n = 0;
+        for (int i = 0; i < nslab; ++i)
+          if (flags[i]) slist[1 + n++] = slab_begin + i;
+        slist[0] = n;
+      }
+      __syncthreads();
+      nslab = slist[0];
+    }
+  }
+  auto slab_of = [&](int i) -> int { return use_list ? slist[1 + i] : slab_begin + i; };
+  const int lasti = nslab - 1;
   if (nslab > 0) {
     if constexpr (PF == 1) {
-      load_AB(slab_begin * BK, IC<0>{});
+      load_AB(slab_of(0) * BK, IC<0>{});
       store_AB(0, IC<0>{});
       __syncthreads();
-      for (int s = slab_begin; s < slab_end; ++s) {
-        const int buf = (s - slab_begin) & 1;
-        load_AB((s < last ? s + 1 : last) * BK, IC<0>{});
+      for (int s = 0; s < nslab; ++s) {
+        const int buf = s & 1;
+        load_AB(slab_of(s < lasti ? s + 1 : lasti) * BK, IC<0>{});
         compute(buf);
         store_AB(buf ^ 1, IC<0>{});
         __syncthreads();
       }
     } else {
-      load_AB(slab_begin * BK, IC<0>{});
-      load_AB((slab_begin + 1 < last ? slab_begin + 1 : last) * BK, IC<1>{});
+      load_AB(slab_of(0) * BK, IC<0>{});
+      load_AB(slab_of(1 < lasti ? 1 : lasti) * BK, IC<1>{});
       store_AB(0, IC<0>{});
       __syncthreads();
       const bool late = (p.stagger != 0) && (__builtin_amdgcn_readfirstlane(t >> 6) >= (NT / 128));
-      for (int s = slab_begin; s < slab_end; s += 2) {
-        const int pa = (s + 2 < last ? s + 2 : last) * BK, pb = (s + 3 < last ? s + 3 : last) * BK;
+      for (int s = 0; s < nslab; s += 2) {
+        const int pa = slab_of(s + 2 < lasti ? s + 2 : lasti) * BK, pb = slab_of(s + 3 < lasti ? s + 3 : lasti) * BK;
         if (!late) load_AB(pa, IC<0>{});
         compute(0);
         if (late) load_AB(pa, IC<0>{});
         store_AB(1, IC<1>{});
         __syncthreads();
-        if (s + 1 >= slab_end) break;
+        if (s + 1 >= nslab) break;
         if (!late) load_AB(pb, IC<1>{});
         compute(1);
         if (late) load_AB(pb, IC<1>{});
@@ -699,7 +800,7 @@ int conv_variant() {
 
 template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT>
 int launch_igemm_ut(const IgemmParams& p, hipStream_t st) {
-  constexpr size_t lds = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float);
+  constexpr size_t lds = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 256;  // + tapinfo[64]
   static bool attr_done = false;  // idempotent; racing threads set the same value
   if (!attr_done) {
     int rc = set_dyn_lds(igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT>, lds);
@@ -748,6 +849,13 @@ int pick_bn(int64_t M, int N, int num_cus) {
 
 int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t st) {
   IgemmParams p = p_in;
+  {
+    static int noskip = -1;
+    if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;  // A/B switch for the padding-tap elimination
+    const int ntaps = p.K / p.C;
+    p.skip_taps = (!noskip && (p.k_mul > 1 || p.k_mul < -1) && ntaps > 1 && ntaps <= 64) ? 1 : 0;
+    p.fd_spt = make_fastdiv((uint32_t)(p.C / BK > 0 ? p.C / BK : 1));
+  }
   const int bn = pick_bn(p.M, p.Nout, num_cus);
   const int var = conv_variant() & 3;
   p.stagger = (conv_variant() >> 2) & 1;
@@ -785,7 +893,7 @@ int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t s
 
 template <int BN, int WGM, int WGN, int PF, bool VEC, bool FAST>
 int launch_wgrad_f(const WgradParams& p, int S, hipStream_t st) {
-  constexpr size_t lds = (size_t)(2 * BK * BM + 2 * BK * BN) * sizeof(float);
+  constexpr size_t lds = (size_t)(2 * BK * BM + 2 * BK * BN) * sizeof(float) + (FAST ? (2 * 1024 + 4) * sizeof(int) : 0);
   static bool attr_done = false;
   if (!attr_done) {
     int rc = set_dyn_lds(igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST>, lds);
@@ -811,6 +919,12 @@ inline int wgrad_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); 
 
 int dispatch_wgrad(const WgradParams& p_in, int S, bool vec, hipStream_t st) {
   WgradParams p = p_in;
+  {
+    static int noskip = -1;
+    if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;
+    p.KH_KW = p.K / p.Cin;
+    p.skip_slabs = (!noskip && p.dil > 1 && p.KH_KW > 1) ? 1 : 0;
+  }
   const int bn = wgrad_bn(p.Cout);
   const int var = conv_variant() & 3;
   p.stagger = (conv_variant() >> 2) & 1;
