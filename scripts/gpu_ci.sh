@@ -35,8 +35,12 @@ for s in $STAGES; do
            find "$OUT/rocprof" -name '*kernel_trace*.csv' -size +20M -delete 2>/dev/null ;;
     dp1)   run_stage dp1 600 python bench.py --steps 4 --warmup 2 --no-cpu-baseline --force-dp ;;
     pmc)   # HBM traffic of the dilated-conv kernels: separate passes (FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2)
+           export ONLY_DILATED=1 ITERS=1   # every launch of the set runs exactly twice (warm-up + 1)
            run_stage pmc_fetch 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 scripts/dilated_bench.py
-           run_stage pmc_write 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 scripts/dilated_bench.py ;;
+           run_stage pmc_write 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 scripts/dilated_bench.py
+           unset ONLY_DILATED ITERS ;;
+    full)  run_stage full 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -s -p no:cacheprovider ;;
+    infer) run_stage infer 600 python scripts/bench_infer.py ;;
     *) echo "unknown stage $s" ;;
   esac
 done
