@@ -101,7 +101,10 @@ static inline SegPlan seg_plan(int num_cus, int nseg, int64_t rows, int C, bool 
   pl.TX = tx;
   pl.TY = 256 / tx;
   pl.gx = (int)sg_cdiv(chunks, tx);
-  int64_t S = sg_cdiv((int64_t)4 * num_cus, (int64_t)pl.gx * nseg);
+  // S depends on the segment's own size only, never on how many segments (images) the launch carries: a
+  // per-image reduction then adds in the same order whatever the batch, so inference is bit-exactly
+  // batch-slice invariant (tests/test_fullsize_gpu.py)
+  int64_t S = sg_cdiv((int64_t)4 * num_cus, (int64_t)pl.gx);
   const int64_t maxS = sg_cdiv(rows, (int64_t)pl.TY * 4);
   if (S > maxS) S = maxS;
   if (S > 256) S = 256;

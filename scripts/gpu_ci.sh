@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench, rocprof summary.  Every stage runs under its own timeout; a
 # stage that times out or is killed aborts the session (no further GPU step after a hang).
-#   usage: scripts/gpu_ci.sh <tag> [stages...]      stages: tests smoke bench prof pmc
+#   usage: scripts/gpu_ci.sh <tag> [stages...]      stages: tests smoke bench prof dp1 pmc full infer census
 set -u
 TAG=${1:-run}; shift || true
 STAGES=${*:-"tests smoke bench prof"}
@@ -41,6 +41,8 @@ for s in $STAGES; do
            unset ONLY_DILATED ITERS ;;
     full)  run_stage full 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -s -p no:cacheprovider ;;
     infer) run_stage infer 600 python scripts/bench_infer.py ;;
+    census) run_stage census 600 python scripts/conv_census.py ;;
+    nodes) run_stage nodes 600 python scripts/node_census.py ;;
     *) echo "unknown stage $s" ;;
   esac
 done
