@@ -136,6 +136,16 @@ def main():
         dil_ms = prof.get("dilated_conv", 0.0) / max(args.steps, 1)
         dil_tflop = DILATED_GFLOP_PER_TILE * args.batch / 1e3 * (args.size / 512.0) ** 2
         achieved = dil_tflop / (dil_ms / 1e3) if dil_ms > 0 else None
+        # fabric-side bytes of the same kernel set per step, from the committed PMC passes (separate rocprofv3
+        # --pmc runs of scripts/dilated_bench.py at this very configuration; scripts/pmc_traffic.py)
+        traffic, traffic_note = None, "PMC passes exist for the 512x512 bs16 configuration only"
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        if args.batch == 16 and args.size == 512 and os.path.exists(tj):
+            with open(tj) as f:
+                tr = json.load(f)
+            traffic = int(tr["set_bytes_per_step"])
+            traffic_note = ("bytes per step of the kernel set, L2-miss side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits "
+                            "included); algorithmic bytes of the set = %d" % int(tr["algorithmic_bytes_per_step"]))
         out = {
             "metric": "512x512 tiles/sec fwd+bwd DeepLabv3+ (full train step: fwd+loss+bwd+Adam)",
             "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
@@ -149,7 +159,7 @@ def main():
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
-                         "traffic": None,
+                         "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": "igemm_conv_kernel / igemm_wgrad_kernel on the 6 dilated 3x3 convs (fwd+dgrad+wgrad)",
                          "ms_per_step": round(dil_ms, 3), "launches_per_step": prof.get("dilated_conv_launches", 0) // max(args.steps, 1)},
         }

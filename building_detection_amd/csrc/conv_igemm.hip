@@ -52,8 +52,13 @@ struct IgemmParams {
   int ablate;   // timing-only diagnostics (results wrong): 1 = no global loads in the loop, 2 = no LDS store/barrier
   uint32_t x_bytes, w_bytes;  // extents for the buffer descriptors of the UT path (both < 2^31)
   int skip_taps;              // drop taps that are pure padding for the whole tile (dilated convs)
-  FastDiv fd_ohow, fd_ow, fd_c, fd_kw, fd_spt;
+  int group_m;                // > 1: tiles are walked in groups of group_m row tiles, row tile fastest (L2 reuse of B)
+  int cb;                     // > 0: K order = (channel block of cb slabs) x tap x slab, so the 9 taps of a
+                              //      channel block re-read x from L2 instead of the fabric; 0: tap-major
+  FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
 };
+
+__device__ __forceinline__ int spt_of(const IgemmParams& p) { return p.C / BK; }  // slabs per tap (UT)
 
 // UT ("uniform tap"): Cin % 32 == 0 or a 1x1 kernel, so every 32-deep slab lies inside ONE filter tap.  The
 // per-row source offsets and bounds flags then change only when the slab stream crosses a tap boundary (every
@@ -77,13 +82,35 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
 
   const int t = threadIdx.x;
   const uint32_t ntn = (p.Nout + BN - 1) / BN;
+  // Tile order.  xcd_remap hands every XCD one contiguous range of the ordered tile ids; inside it either the
+  // column tile runs fastest (the few column tiles of a row tile run together and share its A rows), or - wide
+  // outputs, ntn >= 4 - tiles are walked in groups of group_m row tiles with the ROW tile fastest, so that the
+  // ~64 tiles an XCD has in flight form a block that shares both operands through its L2 (ASPP dgrad: the
+  // 18 MB transposed kernel is fetched once per XCD instead of once per four row tiles).
   const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-  const uint32_t tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+  uint32_t tile_m, tile_n;
+  if (p.group_m > 1) {
+    const uint32_t ntm = gridDim.x / ntn, gm = (uint32_t)p.group_m;
+    const uint32_t per = gm * ntn, g = bid / per, r = bid - g * per;
+    const uint32_t left = ntm - g * gm, gsz = left < gm ? left : gm;
+    tile_n = r / gsz;
+    tile_m = g * gm + (r - tile_n * gsz);
+  } else {
+    tile_m = bid / ntn;
+    tile_n = bid - tile_m * ntn;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- per-thread A rows: NA rows (r0 + RS j), one 4-wide k chunk (kc) ------------------------------
   const int kc = t & 7, r0 = t >> 3;
-  int row_base[NA], row_oh[NA], row_ow[NA];
+  // (oh, ow) of a row, scaled and offset, are packed as two signed 16-bit halves of one register (maps are at
+  // most a few thousand pixels wide): the kernel runs at the 128-VGPR cap of 4 waves per SIMD and every live
+  // register counts (a spill inside the MFMA loop costs a vmcnt(0) that drains the prefetch).
+  // row_lin = n*H*W + oh'*W + ow' (the source pixel of tap (0,0) when div == 1) is needed only when the tap
+  // changes: it lives in LDS (one private slot per thread and row), not in a register - and not in scratch,
+  // whose reload would wait on vmcnt(0) and drain the prefetched slabs.
+  int row_hw[NA];
+  int* row_lin_lds = reinterpret_cast<int*>(Bs + 2 * BK * LDB) + 64;  // [NA][NT], after tapinfo[64]
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
     const int m = m0 + r0 + RS * j;
@@ -91,13 +118,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
       uint32_t n, rem, oh, ow;
       fd_divmod((uint32_t)m, p.fd_ohow, n, rem);
       fd_divmod(rem, p.fd_ow, oh, ow);
-      row_base[j] = n * p.H * p.W;
-      row_oh[j] = (int)oh * p.a_mul + p.off_h;
-      row_ow[j] = (int)ow * p.a_mul + p.off_w;
+      const int ohs = (int)oh * p.a_mul + p.off_h, ows = (int)ow * p.a_mul + p.off_w;
+      row_lin_lds[j * NT + t] = (int)n * p.H * p.W + ohs * p.W + ows;
+      row_hw[j] = (ohs << 16) | (ows & 0xffff);
     } else {
-      row_base[j] = 0;
-      row_oh[j] = -(1 << 28);
-      row_ow[j] = -(1 << 28);
+      row_lin_lds[j * NT + t] = 0;
+      row_hw[j] = (int)0x80008000u;  // (-32768, -32768): out of bounds for every tap
     }
   }
 
@@ -105,15 +131,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
   f32x4 rb[PF][NB];
 
   auto gather_elem_addr = [&](int j, int dh, int dw, bool kvalid, int64_t& off) -> bool {
-    int ih = row_oh[j] + dh, iw = row_ow[j] + dw;
+    const int ohs = row_hw[j] >> 16, ows = (int)(short)(row_hw[j] & 0xffff);
+    int ih = ohs + dh, iw = ows + dw;
     bool v = kvalid;
+    const int rl = row_lin_lds[j * NT + t];
+    int pix = rl + dh * p.W + dw;
     if (p.div == 2) {  // only strides 1 and 2 occur on this path (host rejects others for dgrad)
       v = v && (((ih | iw) & 1) == 0);
       ih >>= 1;
       iw >>= 1;
+      pix = rl - ohs * p.W - ows + ih * p.W + iw;
     }
     v = v && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-    off = (int64_t)(row_base[j] + ih * p.W + iw) * p.x_ld;
+    off = (int64_t)pix * p.x_ld;
     return v;
   };
 
@@ -258,9 +288,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  // The B fragment reads are 4-byte ds_read2st64 pairs whose immediate reaches 255 * 256 bytes from the address
+  // register.  Measured from LDS offset 0 the upper rows of B buffer 1 lie beyond that (A takes the first
+  // 36 KB), which cost three extra address registers - spilled, and reloaded behind a vmcnt(0) in the middle of
+  // the MFMA block.  So the lane's B base carries the region offset itself and is hidden from constant folding.
+  int b_lane_off = 2 * BM * LDA + (4 * lh) * LDB + wn + lr;  // floats from the start of LDS (= As)
+  asm volatile("" : "+v"(b_lane_off));
+  const float* b_lane = As + b_lane_off;
   auto compute = [&](int buf) {
     const float* a = As + buf * BM * LDA;
-    const float* b = Bs + buf * BK * LDB;
+    const float* b = b_lane + buf * BK * LDB;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       f32x4 af[TM];
@@ -271,7 +308,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
       for (int e = 0; e < 4; ++e) {
         float bf[TN];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = b[(kk * 8 + 4 * lh + e) * LDB + wn + 32 * j + lr];
+        for (int j = 0; j < TN; ++j) bf[j] = b[(kk * 8 + e) * LDB + 32 * j];
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -287,12 +324,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
   // its Cin/32 slabs are dropped from the stream: one block-wide vote per tap up front, then the slab index
   // runs over the surviving taps only (tapinfo[] in LDS maps it back to k0).
   int nslab = (p.K + BK - 1) / BK;
-  int spt = 1;
   bool use_map = false;
   int* tapinfo = reinterpret_cast<int*>(Bs + 2 * BK * LDB);
   if constexpr (VEC && UT) {
     if (p.skip_taps && ntaps > 1) {  // uniform
-      spt = p.C / BK;
       int nact = 0;
       for (int tap = 0; tap < ntaps; ++tap) {
         uint32_t kh, kw;
@@ -310,30 +345,54 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
         }
       }
       __syncthreads();
-      nslab = nact * spt;
+      nslab = __builtin_amdgcn_readfirstlane(nact) * spt_of(p);
       use_map = true;
     }
   }
-  auto k0_of = [&](int s) -> int {
-    if (use_map) {
-      const int ti = (int)fd_div((uint32_t)s, p.fd_spt);
-      return tapinfo[ti] * p.C + (s - ti * spt) * BK;
-    }
-    return s * BK;
-  };
+  // Slab iterator: the stream only ever asks for the next slab (the tail repeats the last one), so the
+  // (channel block, tap, slab-in-run) counters advance incrementally on the scalar unit.  Order: for every
+  // channel block of `run` slabs, for every surviving tap, the block's slabs.  run = Cin/32 gives the plain
+  // tap-major order; a short run (p.cb) makes the taps of one channel block consecutive in time, so that x is
+  // fetched over the fabric once and re-read by the other taps from L2.
   const int last = nslab - 1;
+  bool it_lin = true;
+  int it_run = 1, it_ntap = 1, it_ci = 0, it_ti = 0, it_cb = 0, it_s = 0;
+  if constexpr (VEC && UT) {
+    if (ntaps > 1) {  // uniform
+      it_lin = false;
+      it_ntap = use_map ? nslab / spt_of(p) : ntaps;
+      it_run = p.cb > 0 ? p.cb : spt_of(p);
+    }
+  }
+  auto next_k0 = [&]() -> int {
+    int k0;
+    if (it_lin) {
+      k0 = it_s * BK;
+    } else {
+      const int tap = use_map ? __builtin_amdgcn_readfirstlane(tapinfo[it_ti]) : it_ti;
+      k0 = tap * p.C + (it_cb * it_run + it_ci) * BK;
+    }
+    if (it_s < last) {
+      ++it_s;
+      if (!it_lin && ++it_ci == it_run) {
+        it_ci = 0;
+        if (++it_ti == it_ntap) { it_ti = 0; ++it_cb; }
+      }
+    }
+    return k0;
+  };
   // Stagger (MI355X_MICROARCH "two waves per SIMD", item 9): waves i and i + nwaves/2 share a SIMD and run the
   // same program between the same barriers; the upper half defers its gather (address math + global loads)
   // until after its MFMAs, so on every SIMD one wave's VALU phase overlaps its partner's matrix phase.
   const bool late = (p.stagger != 0) && (__builtin_amdgcn_readfirstlane(t >> 6) >= (NT / 128));
   if (nslab > 0) {
   if constexpr (PF == 1) {
-    load_AB(k0_of(0), IC<0>{});
+    load_AB(next_k0(), IC<0>{});
     store_AB(0, IC<0>{});
     __syncthreads();
     for (int s = 0; s < nslab; ++s) {
       const int buf = s & 1;
-      load_AB(k0_of(s < last ? s + 1 : last), IC<0>{});  // tail reloads the last slab (unused): no branch
+      load_AB(next_k0(), IC<0>{});  // tail reloads the last slab (unused): no branch
       compute(buf);
       store_AB(buf ^ 1, IC<0>{});
       __syncthreads();
@@ -341,13 +400,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
   } else {
     // two register sets: while slab s is computed from LDS, slab s+1 sits in one set (landing) and slab s+2
     // is being fetched into the other; the store of a set waits only for that set's (older) loads
-    load_AB(k0_of(0), IC<0>{});
-    load_AB(k0_of(1 < last ? 1 : last), IC<1>{});
+    load_AB(next_k0(), IC<0>{});
+    load_AB(next_k0(), IC<1>{});
     store_AB(0, IC<0>{});
     __syncthreads();
     const bool do_ld = !(p.ablate & 1), do_st = !(p.ablate & 2);
     for (int s = 0; s < nslab; s += 2) {
-      const int ka = k0_of(s + 2 < last ? s + 2 : last), kb = k0_of(s + 3 < last ? s + 3 : last);
+      const int ka = next_k0();
+      const int kb = next_k0();
       if (!late && do_ld) load_AB(ka, IC<0>{});
       compute(0);
       if (late && do_ld) load_AB(ka, IC<0>{});
@@ -423,14 +483,23 @@ struct WgradParams {
   uint32_t x_bytes, dy_bytes;  // extents for the buffer descriptors of the FAST path (both < 2^31)
   int skip_slabs;              // drop 32-pixel slabs that are pure padding for every tap of the tile (dilated convs)
   int KH_KW;
-  FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
+  int tap_inner;               // tile order (channel block, tap, column tile) instead of (tap, channel block, column tile)
+  FastDiv fd_ohow, fd_ow, fd_c, fd_kw, fd_oh;
 };
 
 // FAST: stride-1 "same" convolution (H == Ho, W == Wo) with 16-byte-aligned channel runs: the source pixel of
 // output pixel p under tap (dh,dw) is p + dh*W + dw, i.e. LINEAR in p, so the gather offset advances by a constant
 // per slab; only the tap's bounds flags depend on (oh, ow), which are carried incrementally (no div/mod), and
 // invalid taps / rows are sent to an out-of-range buffer offset (hardware returns 0).
-template <int BN, int WGM, int WGN, int PF, bool VEC, bool FAST>
+//
+// FAST == 2 ("aligned slabs"): additionally OW % 32 == 0, so a 32-pixel slab lies in ONE image row, and the
+// tile's 128 r-rows lie in ONE tap (1x1 kernel, or Cin % 128 == 0).  Then everything that changes from slab to
+// slab is wave-uniform: the image row (bounds of ih), the first column ow0 and the byte offset of the slab's
+// source pixels, all computed on the scalar unit and passed as the buffer load's soffset; a thread keeps only
+// two CONSTANT voffsets (pixel-in-slab x channel) and tests its column against W.  No per-thread running
+// state, no div/mod, ~10 fewer VGPRs: the kernel runs at the 128-VGPR cap and the state used to spill, and a
+// spill reload inside the slab loop waits on vmcnt(0), i.e. drains the prefetch.
+template <int BN, int WGM, int WGN, int PF, bool VEC, int FAST>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_kernel(const WgradParams p) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -448,10 +517,28 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
 
   const int t = threadIdx.x;
   const uint32_t ntn = (p.Cout + BN - 1) / BN;
-  // with slab elimination the work per tile depends on its tap (centre-row taps skip nothing), and an
-  // XCD-contiguous order would park all the heavy taps on two XCDs: spread tiles round-robin instead
-  const uint32_t bid = p.skip_slabs ? blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
-  const uint32_t tile_r = bid / ntn, tile_n = bid - tile_r * ntn;
+  // Workgroup order.  The hardware deals workgroups round-robin to the XCDs in linear (z, x) order; the remap
+  // gives each XCD one contiguous range of (split, tile) pairs, i.e. mostly ONE pixel split, whose dy stays in
+  // that XCD's L2 for the whole range.  Inside a split, with tap_inner the tiles of one 128-channel block come
+  // together: all taps x all column tiles read the same x columns (shifted by the tap) and share them through
+  // L2, and every XCD gets the same mix of cheap and expensive taps when padding slabs are skipped.
+  uint32_t bid, split;
+  {
+    const uint32_t lin = blockIdx.z * gridDim.x + blockIdx.x;
+    const uint32_t o = xcd_remap(lin, gridDim.x * gridDim.z);
+    split = o / gridDim.x;
+    bid = o - split * gridDim.x;
+  }
+  uint32_t tile_r, tile_n;
+  if (p.tap_inner) {
+    const uint32_t per = (uint32_t)p.KH_KW * ntn, ncib = (uint32_t)p.Cin / BM;
+    const uint32_t cib = bid / per, rem = bid - cib * per, tap = rem / ntn;
+    tile_n = rem - tap * ntn;
+    tile_r = tap * ncib + cib;
+  } else {
+    tile_r = bid / ntn;
+    tile_n = bid - tile_r * ntn;
+  }
   const int rbase = tile_r * BM, n0 = tile_n * BN;
 
   // A' chunk owned by this thread: r = rbase + 4*rc (fixed tap / channel), pixel rows (t>>5) + PS j
@@ -471,7 +558,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
     ci_e[e] = (int)ci;
   }
 
-  const int slab_begin = blockIdx.z * p.slabs_per_split;
+  const int slab_begin = (int)split * p.slabs_per_split;
   const int nslab_total = (p.P + BK - 1) / BK;
   int slab_end = slab_begin + p.slabs_per_split;
   if (slab_end > nslab_total) slab_end = nslab_total;
@@ -488,7 +575,35 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
   int f_next = slab_begin * BK;      // pixel index the running state corresponds to
   __amdgpu_buffer_rsrc_t rsrc_x, rsrc_dy;
   const int adv_oh = BK / p.OW, adv_ow = BK % p.OW;
-  if constexpr (FAST) {
+  // FAST == 2 state: constant voffsets; the descriptor's base sits SH pixels BEFORE x so that the scalar offset
+  // (p0 + dh*W + dw + SH) * x_ld * 4 is non-negative whenever a lane of the slab is in bounds
+  constexpr int SH = 32;
+  unsigned a_voffc[NA];
+  int s_dh = 0, s_dw = 0;
+  if constexpr (FAST == 2) {
+    // num_records spans the whole (shifted) tensor: whether or not the hardware adds soffset into its range
+    // check, in-bounds lanes pass and the OOB voffset fails
+    rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) - (int64_t)SH * p.x_ld, 0,
+                                               (int)(p.x_bytes + (uint32_t)(SH * p.x_ld * 4)), 0x00020000);
+    rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+    {
+      const int tap = rbase / p.Cin;  // uniform: the whole tile lies in this tap
+      uint32_t kh, kw;
+      fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+      s_dh = (int)kh * p.dil - p.pad_t;
+      s_dw = (int)kw * p.dil - p.pad_l;
+    }
+#pragma unroll
+    for (int j = 0; j < NA; ++j)
+      a_voffc[j] = rvalid[0] ? (unsigned)((pr0 + PS * j) * p.x_ld + ci_e[0]) * 4u : OOB;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + NT * i;
+      const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+      b_voff[i] = (n0 + 4 * c4) < p.Cout ? (unsigned)(kr * p.y_ld + n0 + 4 * c4) * 4u : OOB;
+    }
+  }
+  if constexpr (FAST == 1) {
     rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
 #pragma unroll
@@ -510,7 +625,29 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
 
   auto load_AB = [&](int p0, auto SET) {
     constexpr int S = decltype(SET)::value;
-    if constexpr (FAST) {
+    if constexpr (FAST == 2) {
+      uint32_t q, ow0, n_, oh;
+      fd_divmod((uint32_t)p0, p.fd_ow, q, ow0);   // all scalar: p0 is wave-uniform
+      fd_divmod(q, p.fd_oh, n_, oh);
+      const int ih = (int)oh + s_dh;
+      const bool row_ok = (unsigned)ih < (unsigned)p.H;
+      const int soff_a = row_ok ? (p0 + s_dh * p.W + s_dw + SH) * p.x_ld * 4 : 0;
+      const int col0 = (int)ow0 + s_dw + pr0;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        const bool v = row_ok && ((unsigned)(col0 + PS * j) < (unsigned)p.W);
+        const u32x4 val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a, 0);
+        ra[S][j] = __builtin_bit_cast(f32x4, val);
+      }
+      const int soff_b = p0 * p.y_ld * 4;
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const u32x4 val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b, 0);  // P % 32 == 0
+        rb[S][i] = __builtin_bit_cast(f32x4, val);
+      }
+      return;
+    }
+    if constexpr (FAST == 1) {
       // the slab stream is sequential except for the repeated (unused) tail slab: advance only when it moves on
       if (p.skip_slabs) {  // uniform: slabs are visited with gaps, so derive the state from p0 directly
         if (p0 != f_next) {
@@ -722,7 +859,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
     }
   }
 
-  float* out = p.out + (int64_t)blockIdx.z * p.K * p.Cout;
+  float* out = p.out + (int64_t)split * p.K * p.Cout;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn + 32 * j + lr;
@@ -798,9 +935,25 @@ int conv_variant() {
   return v;
 }
 
+int conv_l2() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SG_CONV_L2");
+    // default 2: measured on the ASPP convs (scripts/ab_l2.sh, 30 iterations, two interleaved rounds):
+    //   bit 1 (channel-block K order): forward fetch 1039 -> 451 MiB per launch, time unchanged      -> on
+    //   bit 0 (grouped tile order):    dgrad fetch 1808 -> 461 MiB, but 6-13 % SLOWER               -> off
+    //   bit 2 (wgrad tap-inner order): wgrad fetch 1018 -> 314 MiB, but 2-8 % SLOWER                 -> off
+    // The re-reads are served by the 256 MiB Infinity Cache (operands total < 150 MiB), not by HBM, and the
+    // orders that remove them make many CUs hit the same L2 lines at the same time.
+    v = e ? atoi(e) & 7 : 2;
+  }
+  return v;
+}
+
 template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT>
 int launch_igemm_ut(const IgemmParams& p, hipStream_t st) {
-  constexpr size_t lds = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 256;  // + tapinfo[64]
+  // + tapinfo[64] + row_lin[NA][NT] (NA * NT = BM * BK / 4 ints)
+  constexpr size_t lds = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 256 + (size_t)(BM * BK / 4) * sizeof(int);
   static bool attr_done = false;  // idempotent; racing threads set the same value
   if (!attr_done) {
     int rc = set_dyn_lds(igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT>, lds);
@@ -854,9 +1007,18 @@ int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t s
     if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;  // A/B switch for the padding-tap elimination
     const int ntaps = p.K / p.C;
     p.skip_taps = (!noskip && (p.k_mul > 1 || p.k_mul < -1) && ntaps > 1 && ntaps <= 64) ? 1 : 0;
-    p.fd_spt = make_fastdiv((uint32_t)(p.C / BK > 0 ? p.C / BK : 1));
   }
   const int bn = pick_bn(p.M, p.Nout, num_cus);
+  {
+    // L2 locality (A/B switch SG_CONV_L2: bit 0 grouped tile order, bit 1 channel-block K order, bit 2 wgrad order).
+    // An XCD owns 1/8 of the tiles and with them about 1/8 of the A operand's pixels.
+    const int ntaps = p.K / p.C, spt = p.C / BK;
+    const int64_t ntn = sg_cdiv(p.Nout, bn);
+    const int64_t a_per_xcd = p.x_bytes ? (int64_t)p.x_bytes / 8 : (1ll << 40);
+    p.group_m = ((conv_l2() & 1) && ntn >= 4) ? (a_per_xcd <= (2ll << 20) ? 16 : 8) : 1;
+    const bool ut = vec && (p.C % BK == 0) && p.x_bytes != 0 && p.w_bytes != 0;
+    p.cb = ((conv_l2() & 2) && ut && ntaps > 1 && spt > 4 && spt % 4 == 0 && a_per_xcd > (2ll << 20)) ? 4 : 0;
+  }
   const int var = conv_variant() & 3;
   p.stagger = (conv_variant() >> 2) & 1;
   {
@@ -891,7 +1053,7 @@ int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t s
   return (var & 2) ? launch_igemm<32, 4, 1, 2, true>(p, st) : launch_igemm<32, 4, 1, 1, true>(p, st);
 }
 
-template <int BN, int WGM, int WGN, int PF, bool VEC, bool FAST>
+template <int BN, int WGM, int WGN, int PF, bool VEC, int FAST>
 int launch_wgrad_f(const WgradParams& p, int S, hipStream_t st) {
   constexpr size_t lds = (size_t)(2 * BK * BM + 2 * BK * BN) * sizeof(float) + (FAST ? (2 * 1024 + 4) * sizeof(int) : 0);
   static bool attr_done = false;
@@ -910,9 +1072,13 @@ template <int BN, int WGM, int WGN, int PF, bool VEC>
 int launch_wgrad(const WgradParams& p, int S, hipStream_t st) {
   if constexpr (VEC && PF == 2) {
     const bool fast = p.stride == 1 && p.OH == p.H && p.OW == p.W && p.x_bytes != 0 && p.dy_bytes != 0;
-    if (fast) return launch_wgrad_f<BN, WGM, WGN, PF, true, true>(p, S, st);
+    static const bool force1 = getenv("SG_WGRAD_FAST1") != nullptr;  // A/B switch
+    const bool aligned = fast && !force1 && (p.OW % BK == 0) && (p.KH_KW == 1 || p.Cin % BM == 0) &&
+                         ((int64_t)p.x_bytes + 2 * 32 * (int64_t)p.x_ld * 4 < (1ll << 31));
+    if (aligned) return launch_wgrad_f<BN, WGM, WGN, PF, true, 2>(p, S, st);
+    if (fast) return launch_wgrad_f<BN, WGM, WGN, PF, true, 1>(p, S, st);
   }
-  return launch_wgrad_f<BN, WGM, WGN, PF, VEC, false>(p, S, st);
+  return launch_wgrad_f<BN, WGM, WGN, PF, VEC, 0>(p, S, st);
 }
 
 inline int wgrad_bn(int cout) { return cout > 64 ? 128 : (cout > 32 ? 64 : 32); }
@@ -924,6 +1090,7 @@ int dispatch_wgrad(const WgradParams& p_in, int S, bool vec, hipStream_t st) {
     if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;
     p.KH_KW = p.K / p.Cin;
     p.skip_slabs = (!noskip && p.dil > 1 && p.KH_KW > 1) ? 1 : 0;
+    p.tap_inner = ((conv_l2() & 4) && p.KH_KW > 1 && p.Cin % BM == 0) ? 1 : 0;
   }
   const int bn = wgrad_bn(p.Cout);
   const int var = conv_variant() & 3;
@@ -960,12 +1127,185 @@ int check_desc(const sg_conv_desc* d, const char* who) {
   SG_CHECK_ARG(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->dilation > 0, "%s: bad kernel geometry", who);
   SG_CHECK_ARG(d->Ho > 0 && d->Wo > 0, "%s: bad output dims", who);
   SG_CHECK_ARG(d->pad_t >= 0 && d->pad_l >= 0, "%s: negative pad", who);
+  // the gather packs a row's scaled (oh, ow) into signed 16-bit halves
+  SG_CHECK_ARG(d->H < 8192 && d->W < 8192 && (int64_t)d->Ho * d->stride < 16384 && (int64_t)d->Wo * d->stride < 16384 &&
+                   (int64_t)d->KH * d->dilation < 8192 && (int64_t)d->KW * d->dilation < 8192,
+               "%s: map or kernel extent beyond the 16-bit coordinate range", who);
   const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
   SG_CHECK_ARG(xl >= d->Cin && yl >= d->Cout, "%s: pixel stride smaller than channel count", who);
   SG_CHECK_ARG((int64_t)d->N * d->H * d->W * xl < (1ll << 31) && (int64_t)d->N * d->Ho * d->Wo * yl < (1ll << 31),
                "%s: tensor exceeds 2^31 elements", who);
   return 0;
 }
+
+
+// ---- "thin" 1x1 convolutions: Cout <= 4 ----------------------------------------------------------------
+// The sSE gate (C -> 1, sigmoid) and the softmax head (32 -> 2 at full resolution) are pixel-wise dot
+// products: 2*Cout FLOP per 4 bytes read, bandwidth-bound by two orders of magnitude.  A 128-wide MFMA tile
+// would spend 97 % of its columns on zero padding, so they get streaming kernels instead: forward = LP lanes
+// per pixel, each lane one 16-byte channel chunk, sub-wave shuffle reduction; dgrad = one 16-byte store per
+// thread; wgrad = the segmented column reducer with Cout outputs per channel.
+template <int CO>
+__global__ __launch_bounds__(256) void thin_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, float* __restrict__ y, int64_t P,
+                                                       int chunks, int x_ld, int y_ld, int LP, int flags) {
+  constexpr int PIX = 4;  // pixels per lane group: four independent 16-byte loads in flight
+  const int t = threadIdx.x;
+  const int gpb = 256 / LP;  // lane groups per block
+  const int li = t & (LP - 1), grp = t / LP;
+  float acc[PIX][CO];
+#pragma unroll
+  for (int i = 0; i < PIX; ++i)
+#pragma unroll
+    for (int o = 0; o < CO; ++o) acc[i][o] = 0.f;
+  int64_t pix[PIX];
+#pragma unroll
+  for (int i = 0; i < PIX; ++i) pix[i] = ((int64_t)blockIdx.x * PIX + i) * gpb + grp;
+  for (int c = li; c < chunks; c += LP) {
+    float wv[4][CO];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int o = 0; o < CO; ++o) wv[k][o] = w[(4 * c + k) * CO + o];
+    f32x4 xv[PIX];
+#pragma unroll
+    for (int i = 0; i < PIX; ++i) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+      xv[i] = pix[i] < P ? *reinterpret_cast<const f32x4*>(x + pix[i] * x_ld + 4 * c) : z;
+    }
+#pragma unroll
+    for (int i = 0; i < PIX; ++i)
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int o = 0; o < CO; ++o) acc[i][o] = fmaf(xv[i][k], wv[k][o], acc[i][o]);
+  }
+#pragma unroll
+  for (int i = 0; i < PIX; ++i)
+#pragma unroll
+    for (int o = 0; o < CO; ++o)
+      for (int off = LP >> 1; off > 0; off >>= 1) acc[i][o] += __shfl_xor(acc[i][o], off, 64);
+  if (li == 0) {
+#pragma unroll
+    for (int i = 0; i < PIX; ++i) {
+      if (pix[i] >= P) continue;
+#pragma unroll
+      for (int o = 0; o < CO; ++o) {
+        float v = acc[i][o] + ((flags & SG_EPI_BIAS) ? bias[o] : 0.f);
+        if (flags & SG_EPI_RELU) v = fmaxf(v, 0.f);
+        y[pix[i] * y_ld + o] = v;
+      }
+    }
+  }
+}
+
+template <int CO>
+__global__ __launch_bounds__(256) void thin_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                         float* __restrict__ dx, int64_t total, int chunks, int y_ld,
+                                                         int x_ld) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (gid >= total) return;
+  const int64_t pix = gid / chunks;
+  const int c = (int)(gid - pix * chunks);
+  float g[CO];
+#pragma unroll
+  for (int o = 0; o < CO; ++o) g[o] = dy[pix * y_ld + o];
+  f32x4 r;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    float a = 0.f;
+#pragma unroll
+    for (int o = 0; o < CO; ++o) a = fmaf(g[o], w[(4 * c + k) * CO + o], a);
+    r[k] = a;
+  }
+  *reinterpret_cast<f32x4*>(dx + pix * x_ld + 4 * c) = r;
+}
+
+template <int CO>
+struct ThinWgradOp {
+  static constexpr int NOUT = CO;
+  const float* __restrict__ x;
+  const float* __restrict__ dy;
+  float* dw;
+  int x_ld, y_ld;
+  template <int V>
+  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[CO][V]) const {
+    float v[V];
+    ldv<V>(x + r * x_ld + c, v);
+#pragma unroll
+    for (int o = 0; o < CO; ++o) {
+      const float g = dy[r * y_ld + o];
+#pragma unroll
+      for (int k = 0; k < V; ++k) acc[o][k] = fmaf(v[k], g, acc[o][k]);
+    }
+  }
+  __device__ __forceinline__ void finalize(int, int c, const double (&s)[CO]) const {
+#pragma unroll
+    for (int o = 0; o < CO; ++o) dw[c * CO + o] = (float)s[o];
+  }
+};
+
+inline bool thin_ok(const sg_conv_desc* d) {
+  static const bool off = getenv("SG_CONV_NOTHIN") != nullptr;  // A/B switch
+  const int xl = d->x_ld ? d->x_ld : d->Cin;
+  return !off && d->KH == 1 && d->KW == 1 && d->stride == 1 && d->Cout <= 4 && d->Ho == d->H && d->Wo == d->W &&
+         d->Cin % 4 == 0 && xl % 4 == 0 && d->Cin >= 16;
+}
+
+template <int NOUT>
+size_t thin_part_bytes_t(int num_cus, int64_t P, int Cin) { return seg_plan<NOUT>(num_cus, 1, P, Cin, true).part_bytes; }
+size_t thin_part_bytes(int num_cus, const sg_conv_desc* d) {
+  const int64_t P = (int64_t)d->N * d->H * d->W;
+  switch (d->Cout) {
+    case 1: return thin_part_bytes_t<1>(num_cus, P, d->Cin);
+    case 2: return thin_part_bytes_t<2>(num_cus, P, d->Cin);
+    case 3: return thin_part_bytes_t<3>(num_cus, P, d->Cin);
+    default: return thin_part_bytes_t<4>(num_cus, P, d->Cin);
+  }
+}
+
+template <int CO>
+int thin_fwd_t(const sg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int flags, hipStream_t st) {
+  const int64_t P = (int64_t)d->N * d->H * d->W;
+  const int chunks = d->Cin / 4;
+  int LP = 1;
+  while (LP * 2 <= chunks && LP < 64) LP <<= 1;
+  const int64_t groups = sg_cdiv(P, (int64_t)4 * (256 / LP));
+  hipLaunchKernelGGL((thin_fwd_kernel<CO>), dim3((unsigned)groups), dim3(256), 0, st, x, w, bias, y, P, chunks,
+                     d->x_ld ? d->x_ld : d->Cin, d->y_ld ? d->y_ld : d->Cout, LP, flags);
+  SG_LAUNCH_CHECK("thin_fwd_kernel");
+  return 0;
+}
+
+template <int CO>
+int thin_dgrad_t(const sg_conv_desc* d, const float* dy, const float* w, float* dx, hipStream_t st) {
+  const int64_t P = (int64_t)d->N * d->H * d->W;
+  const int chunks = d->Cin / 4;
+  const int64_t total = P * chunks;
+  hipLaunchKernelGGL((thin_dgrad_kernel<CO>), dim3((unsigned)sg_cdiv(total, 256)), dim3(256), 0, st, dy, w, dx, total, chunks,
+                     d->y_ld ? d->y_ld : d->Cout, d->x_ld ? d->x_ld : d->Cin);
+  SG_LAUNCH_CHECK("thin_dgrad_kernel");
+  return 0;
+}
+
+template <int CO>
+int thin_wgrad_t(int num_cus, const sg_conv_desc* d, const float* x, const float* dy, float* dw, float* part, hipStream_t st) {
+  const int64_t P = (int64_t)d->N * d->H * d->W;
+  const SegPlan pl = seg_plan<CO>(num_cus, 1, P, d->Cin, true);
+  ThinWgradOp<CO> op;
+  op.x = x; op.dy = dy; op.dw = dw;
+  op.x_ld = d->x_ld ? d->x_ld : d->Cin;
+  op.y_ld = d->y_ld ? d->y_ld : d->Cout;
+  return seg_reduce_launch(op, pl, 1, P, d->Cin, part, st, "thin_wgrad");
+}
+
+#define THIN_SWITCH(co, CALL)      \
+  switch (co) {                    \
+    case 1: return CALL(1);        \
+    case 2: return CALL(2);        \
+    case 3: return CALL(3);        \
+    default: return CALL(4);       \
+  }
 
 struct WgradPlan {
   int S;
@@ -981,6 +1321,13 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
   WgradPlan pl;
   const int64_t K = (int64_t)d->KH * d->KW * d->Cin;
   const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+  if (thin_ok(d)) {
+    pl.S = 1;
+    pl.slabs_per_split = 0;
+    pl.dw_part_bytes = thin_part_bytes(num_cus, d);
+    pl.bias_part_bytes = colsum_ws_bytes(num_cus, P, d->Cout);
+    return pl;
+  }
   const int bn = wgrad_bn(d->Cout);
   const int64_t tiles = sg_cdiv(K, BM) * sg_cdiv(d->Cout, bn);
   const int64_t nslab = sg_cdiv(P, BK);
@@ -1018,6 +1365,11 @@ int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, c
   if (rc) return rc;
   SG_CHECK_ARG(x && w && y, "sg_conv2d_fwd: null tensor");
   SG_CHECK_ARG(!(flags & SG_EPI_BIAS) || bias, "sg_conv2d_fwd: SG_EPI_BIAS without bias");
+  if (thin_ok(d) && aligned16(x)) {
+#define CALL(CO) thin_fwd_t<CO>(d, (const float*)x, (const float*)w, (const float*)bias, (float*)y, flags, (hipStream_t)stream)
+    THIN_SWITCH(d->Cout, CALL)
+#undef CALL
+  }
   IgemmParams p;
   p.x = (const float*)x;
   p.w = (const float*)w;
@@ -1067,6 +1419,11 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   }
   SG_CHECK_ARG(aligned16(ws), "sg_conv2d_dgrad: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  if (thin_ok(d) && aligned16(dx) && !(flags & (SG_EPI_BIAS | SG_EPI_RELU))) {
+#define CALL(CO) thin_dgrad_t<CO>(d, (const float*)dy, (const float*)w, (float*)dx, st)
+    THIN_SWITCH(d->Cout, CALL)
+#undef CALL
+  }
   float* wt = (float*)ws;
   {
     dim3 grid((unsigned)sg_cdiv(d->Cout, 32), (unsigned)sg_cdiv(d->Cin, 32), (unsigned)(d->KH * d->KW));
@@ -1119,6 +1476,21 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   }
   SG_CHECK_ARG(aligned16(ws), "sg_conv2d_wgrad: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  if (thin_ok(d) && aligned16(x)) {
+    auto run = [&]() -> int {
+#define CALL(CO) thin_wgrad_t<CO>(ctx->num_cus, d, (const float*)x, (const float*)dy, (float*)dw, (float*)ws, st)
+      THIN_SWITCH(d->Cout, CALL)
+#undef CALL
+    };
+    rc = run();
+    if (rc) return rc;
+    if (dbias) {
+      float* part = (float*)((char*)ws + ((pl.dw_part_bytes + 255) & ~(size_t)255));
+      return launch_colsum(ctx->num_cus, (const float*)dy, (int64_t)d->N * d->Ho * d->Wo, d->Cout, d->y_ld ? d->y_ld : d->Cout,
+                           (float*)dbias, part, st);
+    }
+    return 0;
+  }
   WgradParams p;
   p.x = (const float*)x;
   p.dy = (const float*)dy;
@@ -1133,6 +1505,7 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   p.fd_ow = make_fastdiv((uint32_t)d->Wo);
   p.fd_c = make_fastdiv((uint32_t)d->Cin);
   p.fd_kw = make_fastdiv((uint32_t)d->KW);
+  p.fd_oh = make_fastdiv((uint32_t)d->Ho);
   {
     const int64_t xb = (((int64_t)d->N * d->H * d->W - 1) * p.x_ld + d->Cin) * 4;
     const int64_t yb = (((int64_t)p.P - 1) * p.y_ld + d->Cout) * 4;

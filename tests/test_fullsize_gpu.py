@@ -104,12 +104,17 @@ def test_full_size_512_bs16(engine, name, oracle_fn):
         rt.release()
         return val
 
-    # h chosen so that the loss change is far above fp32 resolution yet the second-order term stays small
-    h = 2e-3
-    fd = (loss_at(w0 + h * d) - loss_at(w0 - h * d)) / (2 * h)
+    # central differences at two step sizes: the loss change must stay far above fp32 resolution, while the
+    # error terms of a piecewise-smooth network (ReLU / max-pool kinks crossed inside the step, third-order
+    # curvature) shrink with h; the smaller step is the one asserted, the larger one is printed for scale
+    fds = []
+    for h in (2e-3, 5e-4):
+        fds.append((loss_at(w0 + h * d) - loss_at(w0 - h * d)) / (2 * h))
     rt.w_train.copy_(w0)
     rt.w_frozen.copy_(f0)
-    print(f"{name} 512x512 bs16: loss {l1:.6f}; directional derivative fd {fd:.5e} vs <g,d> {gd:.5e}")
-    assert abs(fd - gd) <= 0.05 * max(abs(gd), abs(fd)) + 1e-6, (fd, gd)
+    fd = fds[-1]
+    print(f"{name} 512x512 bs16: loss {l1:.6f}; directional derivative fd(h=2e-3) {fds[0]:.5e}, fd(h=5e-4) {fd:.5e} "
+          f"vs <g,d> {gd:.5e}")
+    assert abs(fd - gd) <= 0.05 * max(abs(gd), abs(fd)) + 1e-6, (fds, gd)
     del g1, g2, d, w0, f0
     torch.cuda.empty_cache()

@@ -46,6 +46,14 @@ CONV_CASES = [
     (2, 12, 12, 64, 2, 3, 1, 1, "res34_head"),
     (3, 8, 8, 512, 96, 3, 1, 1, "cout96"),
     (16, 1, 1, 256, 16, 1, 1, 1, "gap_1x1"),
+    # thin 1x1 convs (Cout <= 4) take the streaming kernels; odd pixel counts, non-power-of-two chunk counts
+    (3, 13, 11, 64, 1, 1, 1, 1, "thin_sse_ragged"),
+    (2, 9, 7, 48, 2, 1, 1, 1, "thin_c48_cout2"),
+    (1, 8, 8, 256, 3, 1, 1, 1, "thin_c256_cout3"),
+    (2, 6, 5, 728, 4, 1, 1, 1, "thin_c728_cout4"),
+    # aligned-slab wgrad path (W % 32 == 0): pointwise with ragged channel tile, 3x3 with Cin % 128 == 0
+    (1, 32, 32, 200, 136, 1, 1, 1, "wgrad_aligned_pw_ragged"),
+    (1, 32, 64, 128, 64, 3, 1, 2, "wgrad_aligned_3x3_d2"),
 ]
 
 
