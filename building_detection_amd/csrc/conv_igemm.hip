@@ -1017,7 +1017,10 @@ int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t s
     const int64_t a_per_xcd = p.x_bytes ? (int64_t)p.x_bytes / 8 : (1ll << 40);
     p.group_m = ((conv_l2() & 1) && ntn >= 4) ? (a_per_xcd <= (2ll << 20) ? 16 : 8) : 1;
     const bool ut = vec && (p.C % BK == 0) && p.x_bytes != 0 && p.w_bytes != 0;
-    p.cb = ((conv_l2() & 2) && ut && ntaps > 1 && spt > 4 && spt % 4 == 0 && a_per_xcd > (2ll << 20)) ? 4 : 0;
+    // decided from ONE image's footprint, never from the batch: the K order fixes the rounding order, and
+    // inference must not depend on how many tiles travel together (tests/test_fullsize_gpu.py)
+    const int64_t img_bytes = (int64_t)p.H * p.W * p.x_ld * 4;
+    p.cb = ((conv_l2() & 2) && ut && ntaps > 1 && spt > 4 && spt % 4 == 0 && img_bytes > (2ll << 20)) ? 4 : 0;
   }
   const int var = conv_variant() & 3;
   p.stagger = (conv_variant() >> 2) & 1;
