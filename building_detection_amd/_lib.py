@@ -42,6 +42,8 @@ _SIGNATURES = {
     "sg_destroy": (_i, [_vp]),
     "sg_num_cus": (_i, [_vp]),
     "sg_conv2d_fwd": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i]),
+    "sg_conv2d_fwd_ws_bytes": (_sz, [_dp]),
+    "sg_conv2d_fwd_ws": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "sg_conv2d_dgrad_ws_bytes": (_sz, [_dp]),
     "sg_conv2d_dgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "sg_conv2d_wgrad_ws_bytes": (_sz, [_vp, _dp]),

@@ -56,6 +56,9 @@ struct IgemmParams {
   int cb;                     // > 0: K order = (channel block of cb slabs) x tap x slab, so the 9 taps of a
                               //      channel block re-read x from L2 instead of the fabric; 0: tap-major
   FastDiv fd_ohow, fd_ow, fd_c, fd_kw;
+  // x6 path (conv_x6.h): the weights as three bf16 planes [3][Npad][Kpad]; w_bytes then is their extent
+  const unsigned short* __restrict__ wq;
+  int Kpad, Npad;
 };
 
 __device__ __forceinline__ int spt_of(const IgemmParams& p) { return p.C / BK; }  // slabs per tap (UT)
@@ -1000,28 +1003,59 @@ int pick_bn(int64_t M, int N, int num_cus) {
   return best_bn;
 }
 
+// fields shared by the fp32 and the x6 kernel: padding-tap elimination, tile order, K order
+void plan_common(IgemmParams& p, bool vec, int bn) {
+  static int noskip = -1;
+  if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;  // A/B switch for the padding-tap elimination
+  const int ntaps = p.K / p.C, spt = p.C / BK;
+  p.skip_taps = (!noskip && (p.k_mul > 1 || p.k_mul < -1) && ntaps > 1 && ntaps <= 64) ? 1 : 0;
+  // L2 locality (A/B switch SG_CONV_L2: bit 0 grouped tile order, bit 1 channel-block K order, bit 2 wgrad order).
+  // An XCD owns 1/8 of the tiles and with them about 1/8 of the A operand's pixels.
+  const int64_t ntn = sg_cdiv(p.Nout, bn);
+  const int64_t a_per_xcd = p.x_bytes ? (int64_t)p.x_bytes / 8 : (1ll << 40);
+  p.group_m = ((conv_l2() & 1) && ntn >= 4) ? (a_per_xcd <= (2ll << 20) ? 16 : 8) : 1;
+  const bool ut = vec && (p.C % BK == 0) && p.x_bytes != 0 && p.w_bytes != 0;
+  // decided from ONE image's footprint, never from the batch: the K order fixes the rounding order, and
+  // inference must not depend on how many tiles travel together (tests/test_fullsize_gpu.py)
+  const int64_t img_bytes = (int64_t)p.H * p.W * p.x_ld * 4;
+  p.cb = ((conv_l2() & 2) && ut && ntaps > 1 && spt > 4 && spt % 4 == 0 && img_bytes > (2ll << 20)) ? 4 : 0;
+}
+
+#include "conv_x6.h"
+
+int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
+  IgemmParams p = p_in;
+  const int bn = pick_bn(p.M, p.Nout, num_cus);
+  plan_common(p, true, bn);
+  p.stagger = 0;
+  p.ablate = 0;
+  if (bn == 128) return launch_x6<128, 2, 4>(p, st);
+  if (bn == 64) return launch_x6<64, 4, 2>(p, st);
+  return launch_x6<32, 4, 1>(p, st);
+}
+
+// split the weights into the x6 planes (in `ws`) and run the x6 kernel
+int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void* ws, int num_cus, hipStream_t st) {
+  const int K = p.K, N = p.Nout;
+  p.Kpad = x6_kpad(K);
+  p.Npad = x6_npad(N);
+  p.wq = (const unsigned short*)ws;
+  p.w_bytes = (uint32_t)x6_planes_bytes(K, N);
+  dim3 grid((unsigned)(p.Kpad / 32), (unsigned)(p.Npad / 32));
+  if (!dgrad)
+    hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Cin,
+                       Cin * Cout, Cout, 1);
+  else
+    hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Cout,
+                       Cin * Cout, 1, Cout);
+  SG_LAUNCH_CHECK("split3_weights_kernel");
+  return dispatch_x6(p, num_cus, st);
+}
+
 int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t st) {
   IgemmParams p = p_in;
-  {
-    static int noskip = -1;
-    if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;  // A/B switch for the padding-tap elimination
-    const int ntaps = p.K / p.C;
-    p.skip_taps = (!noskip && (p.k_mul > 1 || p.k_mul < -1) && ntaps > 1 && ntaps <= 64) ? 1 : 0;
-  }
   const int bn = pick_bn(p.M, p.Nout, num_cus);
-  {
-    // L2 locality (A/B switch SG_CONV_L2: bit 0 grouped tile order, bit 1 channel-block K order, bit 2 wgrad order).
-    // An XCD owns 1/8 of the tiles and with them about 1/8 of the A operand's pixels.
-    const int ntaps = p.K / p.C, spt = p.C / BK;
-    const int64_t ntn = sg_cdiv(p.Nout, bn);
-    const int64_t a_per_xcd = p.x_bytes ? (int64_t)p.x_bytes / 8 : (1ll << 40);
-    p.group_m = ((conv_l2() & 1) && ntn >= 4) ? (a_per_xcd <= (2ll << 20) ? 16 : 8) : 1;
-    const bool ut = vec && (p.C % BK == 0) && p.x_bytes != 0 && p.w_bytes != 0;
-    // decided from ONE image's footprint, never from the batch: the K order fixes the rounding order, and
-    // inference must not depend on how many tiles travel together (tests/test_fullsize_gpu.py)
-    const int64_t img_bytes = (int64_t)p.H * p.W * p.x_ld * 4;
-    p.cb = ((conv_l2() & 2) && ut && ntaps > 1 && spt > 4 && spt % 4 == 0 && img_bytes > (2ll << 20)) ? 4 : 0;
-  }
+  plan_common(p, vec, bn);
   const int var = conv_variant() & 3;
   p.stagger = (conv_variant() >> 2) & 1;
   {
@@ -1360,8 +1394,18 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
 
 extern "C" {
 
+size_t sg_conv2d_fwd_ws_bytes(const sg_conv_desc* d) {
+  if (!d) return 0;
+  return x6_planes_bytes(d->KH * d->KW * d->Cin, d->Cout) + 256;
+}
+
 int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
                   const void* bias, void* y, int flags) {
+  return sg_conv2d_fwd_ws(ctx, stream, dtype, d, x, w, bias, y, flags, nullptr, 0);
+}
+
+int sg_conv2d_fwd_ws(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
+                     const void* bias, void* y, int flags, void* ws, size_t ws_bytes) {
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_fwd: null ctx");
   SG_CHECK_ARG(dtype == SG_F32, "sg_conv2d_fwd: only SG_F32 is implemented");
   int rc = check_desc(d, "sg_conv2d_fwd");
@@ -1395,12 +1439,16 @@ int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, c
     p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
   }
   const bool vec = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
+  if (ws && aligned16(ws) && ws_bytes >= x6_planes_bytes(p.K, p.Nout) && x6_ok(p, vec))
+    return run_x6(p, (const float*)w, false, d->Cin, d->Cout, ws, ctx->num_cus, (hipStream_t)stream);
   return dispatch_igemm(p, vec, ctx->num_cus, (hipStream_t)stream);
 }
 
 size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d) {
   if (!d) return 0;
-  return (size_t)d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+  const size_t native = (size_t)d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
+  const size_t x6 = x6_planes_bytes(d->KH * d->KW * d->Cout, d->Cin);
+  return native > x6 ? native : x6;
 }
 
 int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
@@ -1428,11 +1476,6 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
 #undef CALL
   }
   float* wt = (float*)ws;
-  {
-    dim3 grid((unsigned)sg_cdiv(d->Cout, 32), (unsigned)sg_cdiv(d->Cin, 32), (unsigned)(d->KH * d->KW));
-    hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, st, (const float*)w, wt, d->Cin, d->Cout);
-    SG_LAUNCH_CHECK("transpose_taps_kernel");
-  }
   IgemmParams p;
   p.x = (const float*)dy;
   p.w = wt;
@@ -1455,6 +1498,12 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
   }
   const bool vec = (d->Cout % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy);
+  if (x6_ok(p, vec)) return run_x6(p, (const float*)w, true, d->Cin, d->Cout, ws, ctx->num_cus, st);
+  {
+    dim3 grid((unsigned)sg_cdiv(d->Cout, 32), (unsigned)sg_cdiv(d->Cin, 32), (unsigned)(d->KH * d->KW));
+    hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, st, (const float*)w, wt, d->Cin, d->Cout);
+    SG_LAUNCH_CHECK("transpose_taps_kernel");
+  }
   return dispatch_igemm(p, vec, ctx->num_cus, st);
 }
 

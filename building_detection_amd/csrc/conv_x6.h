@@ -1,0 +1,368 @@
+// fp32 convolution on the bf16 matrix pipe ("x6"): included by conv_igemm.hip inside its anonymous namespace.
+//
+// CDNA4 runs v_mfma_f32_32x32x16_bf16 at 16x the FLOP rate of v_mfma_f32_32x32x2_f32 (2.4 PFLOP/s against
+// 155 TFLOP/s measured in bare loops on this part, profiles/r01_exp_bf16x6.txt).  An fp32 value is the exact sum of
+// three bf16 values (8 + 8 + 8 significand bits, round-to-nearest splits), a bf16 x bf16 product is exact in fp32
+// and the MFMA accumulates in fp32, so
+//     a*b = (a1+a2+a3)(b1+b2+b3) ~= a3*b1 + a1*b3 + a2*b2 + a2*b1 + a1*b2 + a1*b1      (six MFMA passes)
+// drops only terms below 2^-25 |a||b|.  Measured on the ASPP reduction length K = 18432 against fp64: max error
+// 1.6e-7 of sum|a||b| for the six passes, 2.0e-7 for the native fp32 MFMA (which equals a sequential fmaf chain):
+// the emulation is at least as accurate as the instruction it replaces, at 6/16 of its issue time.
+//
+// Data flow of one 128 x BN x 32 slab (512 threads, two workgroups per CU, single LDS buffer):
+//   A: the im2col gather of the fp32 kernel (hardware buffer addressing, padding taps skipped), two float4 per
+//      thread prefetched into registers one slab ahead; split into the three planes when written to LDS.
+//   B: the weights are split ONCE per launch by split3_weights_kernel into three bf16 planes [n][k] (k
+//      contiguous, zero-padded to whole tiles), so a thread stages one 16-byte chunk per plane, no arithmetic.
+//   LDS: per plane [row][80 bytes] (32 k = 64 B + 16 B pad: ds_read_b128 of 16 rows hits 16 distinct 16-byte
+//      bank groups); fragments are plain row reads for A and B alike (lane (r, h) takes k = 8h..8h+7 of row r).
+//   Per 16-deep k-step a wave (64 x 32 sub-tile) reads 9 fragments and issues 12 MFMAs (0.75 ds_read_b128 per
+//   MFMA; the LDS array saturates at 2).
+#pragma once
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int XPITCH = 80;  // bytes per LDS row of a plane slab
+
+// (x0, x1) -> three packed bf16 pairs (element 0 in the low half), x = h + m + l up to 2^-25 |x|
+__device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  f32x2_t v = {x0, x1};
+  h = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+  f32x2_t hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+  f32x2_t r = v - hf;
+  m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2_t));
+  f32x2_t mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+  f32x2_t s = r - mf;
+  l = __builtin_bit_cast(unsigned, __builtin_convertvector(s, bf16x2_t));
+}
+
+// B[k][n] = w[tap*s_tap + kk*s_k + n*s_n]  (k = tap*Ck + kk)  ->  planes[3][Npad][Kpad] bf16, zero padded.
+//   forward: Ck = Cin,  s_tap = Cin*Cout, s_k = Cout, s_n = 1      (w is HWIO)
+//   dgrad  : Ck = Cout, s_tap = Cin*Cout, s_k = 1,    s_n = Cout   (the per-tap transpose)
+__global__ __launch_bounds__(256) void split3_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
+                                                             int K, int N, int Kpad, int Npad, int Ck, int s_tap, int s_k,
+                                                             int s_n) {
+  __shared__ float tile[32][33];
+  const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    // read with the fast thread index along the contiguous source dimension
+    const int ky = (s_n == 1) ? i : tx, nx = (s_n == 1) ? tx : i;
+    const int k = k0 + ky, n = n0 + nx;
+    float v = 0.f;
+    if (k < K && n < N) {
+      const int tap = k / Ck, kk = k - tap * Ck;
+      v = w[(int64_t)tap * s_tap + (int64_t)kk * s_k + (int64_t)n * s_n];
+    }
+    tile[ky][nx] = v;
+  }
+  __syncthreads();
+  const int64_t plane = (int64_t)Npad * Kpad;
+  for (int i = ty; i < 32; i += 8) {
+    const int n = n0 + i, k = k0 + tx;  // always inside the padded planes (Kpad, Npad are multiples of 32)
+    const float x = tile[tx][i];
+    unsigned h, m, l;
+    split3_pair(x, 0.f, h, m, l);
+    const int64_t o = (int64_t)n * Kpad + k;
+    planes[o] = (unsigned short)(h & 0xffffu);
+    planes[plane + o] = (unsigned short)(m & 0xffffu);
+    planes[2 * plane + o] = (unsigned short)(l & 0xffffu);
+  }
+}
+
+inline int x6_kpad(int K) { return (int)(sg_cdiv(K, 32) * 32); }
+inline int x6_npad(int N) { return (int)(sg_cdiv(N, 128) * 128); }
+inline size_t x6_planes_bytes(int K, int N) { return (size_t)3 * x6_kpad(K) * x6_npad(N) * 2; }
+
+template <int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(const IgemmParams p) {
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NA = (BM * BK / 4) / NT;  // float4 A chunks per thread (rows r0 + RS*j)
+  constexpr int RS = NT / 8;
+  constexpr int NBC = BN * 4 * 3;         // 16-byte chunks of one B slab (3 planes x BN rows x 4)
+  constexpr int NB = (NBC + NT - 1) / NT;
+  static_assert(TM >= 1 && TN >= 1 && NA >= 1, "tile too small for the wave layout");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ap = smem;                          // [3][BM][XPITCH]
+  char* Bp = Ap + 3 * BM * XPITCH;          // [3][BN][XPITCH]
+  int* tapinfo = reinterpret_cast<int*>(Bp + 3 * BN * XPITCH);  // [64]
+  int* row_lin_lds = tapinfo + 64;          // [NA][NT]
+
+  const int t = threadIdx.x;
+  const uint32_t ntn = (p.Nout + BN - 1) / BN;
+  const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+  // ---- A rows (same gather as igemm_conv_kernel's UT path) ----------------------------------------------
+  const int kc = t & 7, r0 = t >> 3;
+  int row_hw[NA];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) {
+    const int m = m0 + r0 + RS * j;
+    if (m < p.M) {
+      uint32_t n, rem, oh, ow;
+      fd_divmod((uint32_t)m, p.fd_ohow, n, rem);
+      fd_divmod(rem, p.fd_ow, oh, ow);
+      const int ohs = (int)oh * p.a_mul + p.off_h, ows = (int)ow * p.a_mul + p.off_w;
+      row_lin_lds[j * NT + t] = (int)n * p.H * p.W + ohs * p.W + ows;
+      row_hw[j] = (ohs << 16) | (ows & 0xffff);
+    } else {
+      row_lin_lds[j * NT + t] = 0;
+      row_hw[j] = (int)0x80008000u;
+    }
+  }
+  auto gather_elem_addr = [&](int j, int dh, int dw, int64_t& off) -> bool {
+    const int ohs = row_hw[j] >> 16, ows = (int)(short)(row_hw[j] & 0xffff);
+    int ih = ohs + dh, iw = ows + dw;
+    bool v = true;
+    const int rl = row_lin_lds[j * NT + t];
+    int pix = rl + dh * p.W + dw;
+    if (p.div == 2) {
+      v = (((ih | iw) & 1) == 0);
+      ih >>= 1;
+      iw >>= 1;
+      pix = rl - ohs * p.W - ows + ih * p.W + iw;
+    }
+    v = v && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+    off = (int64_t)pix * p.x_ld;
+    return v;
+  };
+
+  constexpr unsigned OOB = 0x80000000u;
+  int cur_tap = -1;
+  unsigned tap_voff[NA];
+  unsigned b_voff[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) tap_voff[j] = OOB;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int idx = t + NT * i;
+    const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
+    const int row = rem >> 2, c = rem & 3;
+    b_voff[i] = idx < NBC ? (unsigned)(((pl * p.Npad + n0 + row) * p.Kpad + c * 8) * 2) : OOB;
+  }
+  const int ntaps = p.K / p.C;
+  const bool ktail = (p.K % BK) != 0;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wq), 0, (int)p.w_bytes, 0x00020000);
+
+  f32x4 ra[NA];
+  u32x4_t rb[NB];
+  auto load_AB = [&](int k0) {
+    const int tap = (int)fd_div((uint32_t)k0, p.fd_c);
+    if (tap != cur_tap) {  // uniform
+      cur_tap = tap;
+      uint32_t kh, kw;
+      fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+      const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        int64_t off;
+        const bool ok = gather_elem_addr(j, dh, dw, off) && tap < ntaps;
+        tap_voff[j] = ok ? (unsigned)off * 4u + 16u * kc : OOB;
+      }
+    }
+    const int soff_a = (k0 - tap * p.C) * 4;
+    const bool kvalid = !ktail || (k0 + 4 * kc < p.K);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
+      ra[j] = __builtin_bit_cast(f32x4, v);
+    }
+    const int soff_b = k0 * 2;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
+  };
+
+  auto store_AB = [&]() {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      unsigned h0, m0_, l0, h1, m1, l1;
+      split3_pair(ra[j][0], ra[j][1], h0, m0_, l0);
+      split3_pair(ra[j][2], ra[j][3], h1, m1, l1);
+      char* dst = Ap + (r0 + RS * j) * XPITCH + kc * 8;
+      *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
+      *reinterpret_cast<u32x2_t*>(dst + BM * XPITCH) = (u32x2_t){m0_, m1};
+      *reinterpret_cast<u32x2_t*>(dst + 2 * BM * XPITCH) = (u32x2_t){l0, l1};
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + NT * i;
+      if (idx < NBC) {
+        const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
+        const int row = rem >> 2, c = rem & 3;
+        *reinterpret_cast<u32x4_t*>(Bp + (pl * BN + row) * XPITCH + c * 16) = rb[i];
+      }
+    }
+  };
+
+  // ---- MFMA side --------------------------------------------------------------------------------------------
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const char* a_lane = Ap + (wm + lr) * XPITCH + lh * 16;
+  const char* b_lane = Bp + (wn + lr) * XPITCH + lh * 16;
+
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[TM][3], bf[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          af[i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane + (pl * BM + 32 * i) * XPITCH + ks * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bf[j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane + (pl * BN + 32 * j) * XPITCH + ks * 32);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // smallest terms first
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  // ---- slab stream (padding-tap elimination and channel-block order as in igemm_conv_kernel) ---------------
+  const int spt = p.C / BK;
+  int nslab = (p.K + BK - 1) / BK;
+  bool use_map = false;
+  if (p.skip_taps && ntaps > 1) {  // uniform
+    int nact = 0;
+    for (int tap = 0; tap < ntaps; ++tap) {
+      uint32_t kh, kw;
+      fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+      const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        int64_t off;
+        any = any || gather_elem_addr(j, dh, dw, off);
+      }
+      if (__syncthreads_or(any ? 1 : 0)) {
+        if (t == 0) tapinfo[nact] = tap;
+        ++nact;
+      }
+    }
+    __syncthreads();
+    nslab = __builtin_amdgcn_readfirstlane(nact) * spt;
+    use_map = true;
+  }
+  const int last = nslab - 1;
+  const bool it_lin = ntaps <= 1;
+  const int it_ntap = use_map ? nslab / (spt > 0 ? spt : 1) : ntaps;
+  const int it_run = p.cb > 0 ? p.cb : spt;
+  int it_ci = 0, it_ti = 0, it_cb = 0, it_s = 0;
+  auto next_k0 = [&]() -> int {
+    int k0;
+    if (it_lin) {
+      k0 = it_s * BK;
+    } else {
+      const int tap = use_map ? __builtin_amdgcn_readfirstlane(tapinfo[it_ti]) : it_ti;
+      k0 = tap * p.C + (it_cb * it_run + it_ci) * BK;
+    }
+    if (it_s < last) {
+      ++it_s;
+      if (!it_lin && ++it_ci == it_run) {
+        it_ci = 0;
+        if (++it_ti == it_ntap) { it_ti = 0; ++it_cb; }
+      }
+    }
+    return k0;
+  };
+
+  if (nslab > 0) {
+    load_AB(next_k0());
+    for (int s = 0; s < nslab; ++s) {
+      __syncthreads();  // every wave has finished reading the previous slab
+      store_AB();
+      __syncthreads();
+      load_AB(next_k0());  // the tail reloads the last slab (unused): no branch
+      compute();
+    }
+  }
+
+  // ---- epilogue ----------------------------------------------------------------------------------------------
+  const bool has_bias = (p.flags & SG_EPI_BIAS) != 0;
+  const bool do_relu = (p.flags & SG_EPI_RELU) != 0;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn + 32 * j + lr;
+    const bool cv = col < p.Nout;
+    const float bv = (has_bias && cv) ? p.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (cv && row < p.M) {
+          float v = acc[i][j][r] + bv;
+          if (do_relu) v = fmaxf(v, 0.f);
+          p.y[(int64_t)row * p.y_ld + col] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BN, int WGM, int WGN>
+int launch_x6(const IgemmParams& p, hipStream_t st) {
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr size_t lds = (size_t)3 * (BM + BN) * XPITCH + 256 + (size_t)(BM * BK / 4) * sizeof(int);
+  (void)NT;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = set_dyn_lds(conv_x6_kernel<BN, WGM, WGN>, lds);
+    if (rc) return rc;
+    attr_done = true;
+  }
+  const int64_t tiles = sg_cdiv(p.M, BM) * sg_cdiv(p.Nout, BN);
+  if (tiles <= 0 || tiles > 0x7fffffff) {
+    sg_set_error("conv_x6: bad tile count %lld", (long long)tiles);
+    return SG_EINVAL;
+  }
+  hipLaunchKernelGGL((conv_x6_kernel<BN, WGM, WGN>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
+  SG_LAUNCH_CHECK("conv_x6_kernel");
+  return 0;
+}
+
+// A/B switch: SG_CONV_X6=0 keeps every convolution on the native fp32 MFMA kernel.
+inline bool x6_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SG_CONV_X6");
+    v = e ? (atoi(e) != 0) : 1;
+  }
+  return v != 0;
+}
+
+// Can this launch take the x6 kernel?  (UT gather: every 32-deep slab inside one tap; 16-byte channel runs.)
+inline bool x6_ok(const IgemmParams& p, bool vec) {
+  const bool ut = (p.C % BK == 0) || (p.K == p.C);
+  return x6_enabled() && vec && ut && p.x_bytes != 0 && x6_planes_bytes(p.K, p.Nout) < (1ull << 31) && p.Nout >= 16;
+}

@@ -131,8 +131,10 @@ class Engine:
         assert d.Cin == cin, (d.Cin, cin)
         y = out if out is not None else self.empty(d.N, d.Ho, d.Wo, cout)
         flags = (_lib.SG_EPI_BIAS if b is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
-        check(self.lib.sg_conv2d_fwd(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags),
-              "sg_conv2d_fwd")
+        need = self.lib.sg_conv2d_fwd_ws_bytes(C.byref(d))
+        wsp, wsn = self.ws(need)
+        check(self.lib.sg_conv2d_fwd_ws(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags,
+                                        wsp, wsn), "sg_conv2d_fwd_ws")
         return y
 
     def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None):

@@ -77,6 +77,14 @@ typedef struct sg_conv_desc {
 int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
                   const void* w, const void* bias, void* y, int flags);
 
+/* The same forward with a caller-provided workspace of sg_conv2d_fwd_ws_bytes(d) bytes (16-byte aligned).
+ * With it the GEMM may run on the bf16 matrix pipe as six MFMA passes over a 3-way bf16 split of the fp32
+ * operands ("x6", csrc/conv_x6.h: at least as accurate as the fp32 MFMA, measured; the workspace holds the
+ * split kernel); without it (or when the shape does not qualify) the native fp32 MFMA kernel runs. */
+size_t sg_conv2d_fwd_ws_bytes(const sg_conv_desc* d);
+int sg_conv2d_fwd_ws(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
+                     const void* w, const void* bias, void* y, int flags, void* ws, size_t ws_bytes);
+
 /* Conv2D input gradient dx[N,H,W,Cin] (pixel stride d->x_ld) from dy[N,Ho,Wo,Cout] (pixel stride d->y_ld).
  * The same routine is Conv2DTranspose *forward* (y_T = dgrad of the SAME conv that maps the upsampled grid
  * back): v3plus.py:328,335, scse.py:71-89, res34.py:144 — hence the optional epilogue
