@@ -1132,6 +1132,11 @@ int dispatch_wgrad(const WgradParams& p_in, int S, bool vec, hipStream_t st) {
   const int bn = wgrad_bn(p.Cout);
   const int var = conv_variant() & 3;
   p.stagger = (conv_variant() >> 2) & 1;
+  if (wgrad_x6_ok(p, vec)) {
+    if (bn == 128) return launch_wgrad_x6<128, 2, 4>(p, S, st);
+    if (bn == 64) return launch_wgrad_x6<64, 4, 2>(p, S, st);
+    return launch_wgrad_x6<32, 4, 1>(p, S, st);
+  }
   if (!vec) {
     if (bn == 128) return launch_wgrad<128, 2, 4, 1, false>(p, S, st);
     if (bn == 64) return launch_wgrad<64, 4, 2, 1, false>(p, S, st);

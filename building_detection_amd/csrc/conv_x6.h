@@ -366,3 +366,273 @@ inline bool x6_ok(const IgemmParams& p, bool vec) {
   const bool ut = (p.C % BK == 0) || (p.K == p.C);
   return x6_enabled() && vec && ut && p.x_bytes != 0 && x6_planes_bytes(p.K, p.Nout) < (1ull << 31) && p.Nout >= 16;
 }
+
+// ---- wgrad on the bf16 pipe --------------------------------------------------------------------------------------
+// dw[r][co] = sum_p x[p + tap shift][ci] * dy[p][co]: the reduction index is the PIXEL, while both operands are
+// channel-contiguous in memory.  The slabs are therefore staged as they lie - [32 pixels][channels] per plane,
+// 8-byte writes - and the fragments (8 consecutive pixels of one channel per lane) are taken with the transposed
+// LDS read ds_read_b64_tr_b16: per 16-lane group a 4-pixel x 16-channel block, lane i receiving channel i of
+// the four pixels (mapping verified by scripts/exp_trread.hip).  Row pitch = channel bytes + 64 (an odd
+// multiple of 64 B modulo 256), which spreads the four pixel rows of a block over all 64 banks.
+// Loads follow the aligned-slab scheme of igemm_wgrad_kernel<FAST = 2>: constant per-thread voffsets, the slab's
+// position, image row and bounds on the scalar unit.  Requires OW % 32 == 0, stride 1, "same" geometry and the
+// tile's 128 r-rows inside one tap (1x1 kernel or Cin % 128 == 0).
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
+
+__device__ __forceinline__ bf16x8_t tr_frag(const char* lds_addr_a, const char* lds_addr_b) {
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds_addr_a));
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(lds_addr_b));
+  typedef short s16x8_t __attribute__((ext_vector_type(8)));
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+template <int BN>
+struct X6WPitch {
+  static constexpr int A = 2 * BM + 64;                       // 320
+  static constexpr int B = (BN == 128) ? 2 * BN + 64 : 192;   // 320 / 192 / 192
+};
+
+template <int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel(const WgradParams p) {
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TN = WN / 32;
+  constexpr int NA = (BK * BM / 4) / NT;  // float4 A' chunks per thread (pixel rows pr0 + PS*j)
+  constexpr int PS = NT / 32;
+  constexpr int NB = (BK * BN / 4 + NT - 1) / NT;
+  constexpr int NBC = BK * BN / 4;
+  constexpr int PA = X6WPitch<BN>::A, PB = X6WPitch<BN>::B;
+  static_assert(NA >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ap = smem;                     // [3][BK][PA]
+  char* Bp = Ap + 3 * BK * PA;         // [3][BK][PB]
+  int* slist = reinterpret_cast<int*>(Bp + 3 * BK * PB);  // [1 + 1024] + flags[1024]
+
+  const int t = threadIdx.x;
+  const uint32_t ntn = (p.Cout + BN - 1) / BN;
+  uint32_t bid, split;
+  {
+    const uint32_t lin = blockIdx.z * gridDim.x + blockIdx.x;
+    const uint32_t o = xcd_remap(lin, gridDim.x * gridDim.z);
+    split = o / gridDim.x;
+    bid = o - split * gridDim.x;
+  }
+  uint32_t tile_r, tile_n;
+  if (p.tap_inner) {
+    const uint32_t per = (uint32_t)p.KH_KW * ntn, ncib = (uint32_t)p.Cin / BM;
+    const uint32_t cib = bid / per, rem = bid - cib * per, tap = rem / ntn;
+    tile_n = rem - tap * ntn;
+    tile_r = tap * ncib + cib;
+  } else {
+    tile_r = bid / ntn;
+    tile_n = bid - tile_r * ntn;
+  }
+  const int rbase = tile_r * BM, n0 = tile_n * BN;
+
+  const int rc = t & 31, pr0 = t >> 5;
+  const int tap = rbase / p.Cin;  // uniform: the whole tile lies in this tap
+  int s_dh, s_dw;
+  {
+    uint32_t kh, kw;
+    fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+    s_dh = (int)kh * p.dil - p.pad_t;
+    s_dw = (int)kw * p.dil - p.pad_l;
+  }
+  const int r_first = rbase + 4 * rc;
+  const bool rvalid = r_first < p.K;
+  const int ci0 = r_first - tap * p.Cin;
+
+  const int slab_begin = (int)split * p.slabs_per_split;
+  const int nslab_total = (p.P + BK - 1) / BK;
+  int slab_end = slab_begin + p.slabs_per_split;
+  if (slab_end > nslab_total) slab_end = nslab_total;
+
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int SH = 32;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(p.x) - (int64_t)SH * p.x_ld, 0, (int)(p.x_bytes + (uint32_t)(SH * p.x_ld * 4)), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+  unsigned a_voffc[NA], b_voff[NB];
+#pragma unroll
+  for (int j = 0; j < NA; ++j) a_voffc[j] = rvalid ? (unsigned)((pr0 + PS * j) * p.x_ld + ci0) * 4u : OOB;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int idx = t + NT * i;
+    const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+    b_voff[i] = (idx < NBC && (n0 + 4 * c4) < p.Cout) ? (unsigned)(kr * p.y_ld + n0 + 4 * c4) * 4u : OOB;
+  }
+
+  f32x4 ra[NA], rb[NB];
+  auto load_AB = [&](int p0) {
+    uint32_t q, ow0, n_, oh;
+    fd_divmod((uint32_t)p0, p.fd_ow, q, ow0);
+    fd_divmod(q, p.fd_oh, n_, oh);
+    const int ih = (int)oh + s_dh;
+    const bool row_ok = (unsigned)ih < (unsigned)p.H;
+    const int soff_a = row_ok ? (p0 + s_dh * p.W + s_dw + SH) * p.x_ld * 4 : 0;
+    const int col0 = (int)ow0 + s_dw + pr0;
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      const bool v = row_ok && ((unsigned)(col0 + PS * j) < (unsigned)p.W);
+      const u32x4_t val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a, 0);
+      ra[j] = __builtin_bit_cast(f32x4, val);
+    }
+    const int soff_b = p0 * p.y_ld * 4;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const u32x4_t val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b, 0);
+      rb[i] = __builtin_bit_cast(f32x4, val);
+    }
+  };
+
+  auto store_AB = [&]() {
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+      unsigned h0, m0_, l0, h1, m1, l1;
+      split3_pair(ra[j][0], ra[j][1], h0, m0_, l0);
+      split3_pair(ra[j][2], ra[j][3], h1, m1, l1);
+      char* dst = Ap + (pr0 + PS * j) * PA + rc * 8;
+      *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
+      *reinterpret_cast<u32x2_t*>(dst + BK * PA) = (u32x2_t){m0_, m1};
+      *reinterpret_cast<u32x2_t*>(dst + 2 * BK * PA) = (u32x2_t){l0, l1};
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int idx = t + NT * i;
+      if (idx < NBC) {
+        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pair(rb[i][0], rb[i][1], h0, m0_, l0);
+        split3_pair(rb[i][2], rb[i][3], h1, m1, l1);
+        char* dst = Bp + kr * PB + c4 * 8;
+        *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
+        *reinterpret_cast<u32x2_t*>(dst + BK * PB) = (u32x2_t){m0_, m1};
+        *reinterpret_cast<u32x2_t*>(dst + 2 * BK * PB) = (u32x2_t){l0, l1};
+      }
+    }
+  };
+
+  const int wave = t >> 6, lane = t & 63;
+  const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // transposed-read addresses: lane = 16 g + i supplies pixel row 8 (g>>1) + (i>>2) [+4 for the second read],
+  // channels 16 (g&1) + 4 (i&3) .. +3 of its 32-channel tile
+  const int tg = lane >> 4, ti = lane & 15;
+  const int tr_row = 8 * (tg >> 1) + (ti >> 2), tr_col = 16 * (tg & 1) + 4 * (ti & 3);
+  const char* a_lane = Ap + tr_row * PA + (wm + tr_col) * 2;
+  const char* b_lane = Bp + tr_row * PB + (wn + tr_col) * 2;
+
+  auto compute = [&]() {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t af[TM][3], bf[TN][3];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const char* a = a_lane + (pl * BK + 16 * ks) * PA + 64 * i;
+          af[i][pl] = tr_frag(a, a + 4 * PA);
+        }
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const char* b = b_lane + (pl * BK + 16 * ks) * PB + 64 * j;
+          bf[j][pl] = tr_frag(b, b + 4 * PB);
+        }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  // ---- slab stream with padding-slab elimination (as igemm_wgrad_kernel) ----------------------------------------
+  int nslab = slab_end - slab_begin;
+  bool use_list = false;
+  if (p.skip_slabs && nslab <= 1024) {  // uniform
+    use_list = true;
+    int* flags = slist + 1 + 1024;
+    for (int i = t; i < nslab; i += NT) {
+      const int pa = (slab_begin + i) * BK;  // aligned slabs: one image row per slab
+      uint32_t q, tmp, n_, oh;
+      fd_divmod((uint32_t)pa, p.fd_ow, q, tmp);
+      fd_divmod(q, p.fd_oh, n_, oh);
+      const bool act = ((int)oh + s_dh >= 0) && ((int)oh + s_dh < p.H) && (s_dw > -p.W) && (s_dw < p.W);
+      flags[i] = act ? 1 : 0;
+    }
+    __syncthreads();
+    if (t == 0) {
+      int n = 0;
+      for (int i = 0; i < nslab; ++i)
+        if (flags[i]) slist[1 + n++] = slab_begin + i;
+      slist[0] = n;
+    }
+    __syncthreads();
+    nslab = slist[0];
+  }
+  auto slab_of = [&](int i) -> int { return use_list ? slist[1 + i] : slab_begin + i; };
+  const int lasti = nslab - 1;
+  if (nslab > 0) {
+    load_AB(slab_of(0) * BK);
+    for (int s = 0; s < nslab; ++s) {
+      __syncthreads();
+      store_AB();
+      __syncthreads();
+      load_AB(slab_of(s < lasti ? s + 1 : lasti) * BK);
+      compute();
+    }
+  }
+
+  float* out = p.out + (int64_t)split * p.K * p.Cout;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn + 32 * j + lr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = rbase + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (col < p.Cout && row < p.K) out[(int64_t)row * p.Cout + col] = acc[i][j][r];
+      }
+    }
+  }
+}
+
+template <int BN, int WGM, int WGN>
+int launch_wgrad_x6(const WgradParams& p, int S, hipStream_t st) {
+  constexpr size_t lds = (size_t)3 * BK * (X6WPitch<BN>::A + X6WPitch<BN>::B) + (2 * 1024 + 4) * sizeof(int);
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = set_dyn_lds(wgrad_x6_kernel<BN, WGM, WGN>, lds);
+    if (rc) return rc;
+    attr_done = true;
+  }
+  const int64_t tiles = sg_cdiv(p.K, BM) * sg_cdiv(p.Cout, BN);
+  hipLaunchKernelGGL((wgrad_x6_kernel<BN, WGM, WGN>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
+  SG_LAUNCH_CHECK("wgrad_x6_kernel");
+  return 0;
+}
+
+inline bool wgrad_x6_ok(const WgradParams& p, bool vec) {
+  const bool fast = p.stride == 1 && p.OH == p.H && p.OW == p.W && p.x_bytes != 0 && p.dy_bytes != 0;
+  return x6_enabled() && vec && fast && (p.OW % BK == 0) && (p.KH_KW == 1 || p.Cin % BM == 0) && p.Cout >= 16 &&
+         ((int64_t)p.x_bytes + 2 * 32 * (int64_t)p.x_ld * 4 < (1ll << 31));
+}
