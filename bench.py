@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
 DILATED_GFLOP_PER_TILE = 97.84  # fwd + dgrad + wgrad of the 6 dilated convs, SURVEY.md §8d
 
 
@@ -136,6 +137,14 @@ def main():
         dil_ms = prof.get("dilated_conv", 0.0) / max(args.steps, 1)
         dil_tflop = DILATED_GFLOP_PER_TILE * args.batch / 1e3 * (args.size / 512.0) ** 2
         achieved = dil_tflop / (dil_ms / 1e3) if dil_ms > 0 else None
+        # The fp32 products of these convolutions run as six bf16 MFMA passes over an exact 3-way bf16 split of the
+        # fp32 operands, fp32 accumulation (csrc/conv_x6.h; accuracy >= the fp32 MFMA, profiles/r01_exp_bf16x6.txt).
+        # The pipe that bounds them is therefore the bf16 one: 2500 TFLOP/s dense / 6 passes per fp32 FLOP.  With
+        # SG_CONV_X6=0 they run on the fp32 MFMA (157.3 TFLOP/s) instead.
+        x6 = os.environ.get("SG_CONV_X6", "1") != "0"
+        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x6 else FP32_MFMA_PEAK_TFLOPS
+        peak_note = ("bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMA passes per fp32 product (x6 path: fp32 in, fp32 accumulate, "
+                     "exact 3-way bf16 split); the native fp32 MFMA peak is 157.3 TFLOP/s") if x6 else "fp32 MFMA 32x32x2 dense peak"
         # fabric-side bytes of the same kernel set per step, from the committed PMC passes (separate rocprofv3
         # --pmc runs of scripts/dilated_bench.py at this very configuration; scripts/pmc_traffic.py)
         traffic, traffic_note = None, "PMC passes exist for the 512x512 bs16 configuration only"
@@ -151,16 +160,19 @@ def main():
             "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "dtype_note": "fp32 tensors, fp32 accumulation; conv products as 6 bf16 MFMA passes over an exact 3-way split" if x6 else "fp32 MFMA",
             "config": {"workload": f"DeepLabv3+ (v3plus.py) {args.size}x{args.size} bs={args.batch}/GPU fp32, "
                                    f"train step, {'dp%d' % world if world > 1 else 'single GPU'}",
                        "global_batch": world * args.batch, "model_flops_per_step_tflop": round(step_tflop, 3),
                        "step_achieved_tflops": round(step_tflop / (ms_per_step / 1e3), 2),
                        "final_loss": float(loss.item())},
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2),
-                         "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "peak": round(peak, 1), "unit": "TFLOP/s",
+                         "frac": None if achieved is None else round(achieved / peak, 4),
+                         "peak_note": peak_note,
+                         "frac_vs_fp32_mfma_peak": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
                          "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": "igemm_conv_kernel / igemm_wgrad_kernel on the 6 dilated 3x3 convs (fwd+dgrad+wgrad)",
+                         "kernel": ("conv_x6_kernel / wgrad_x6_kernel" if x6 else "igemm_conv_kernel / igemm_wgrad_kernel") + " on the 6 dilated 3x3 convs (fwd+dgrad+wgrad)",
                          "ms_per_step": round(dil_ms, 3), "launches_per_step": prof.get("dilated_conv_launches", 0) // max(args.steps, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:

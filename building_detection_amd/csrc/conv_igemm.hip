@@ -1028,10 +1028,32 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
   const int bn = pick_bn(p.M, p.Nout, num_cus);
   plan_common(p, true, bn);
   p.stagger = 0;
-  p.ablate = 0;
-  if (bn == 128) return launch_x6<128, 2, 4>(p, st);
-  if (bn == 64) return launch_x6<64, 4, 2>(p, st);
-  return launch_x6<32, 4, 1>(p, st);
+  {
+    static int abl = -1;
+    if (abl < 0) {
+      const char* e = getenv("SG_X6_ABLATE");
+      abl = e ? atoi(e) & 7 : 0;
+    }
+    p.ablate = abl;
+  }
+  const int var = x6_variant();
+  if (bn == 128) {
+    switch (var) {
+      case 0: return launch_x6<128, 2, 4, 1>(p, st);
+      case 1: return launch_x6<128, 2, 4, 2>(p, st);
+      case 2: return launch_x6<128, 2, 2, 1>(p, st);
+      default: return launch_x6<128, 2, 2, 2>(p, st);
+    }
+  }
+  if (bn == 64) {
+    switch (var) {
+      case 0: return launch_x6<64, 4, 2, 1>(p, st);
+      case 1: return launch_x6<64, 4, 2, 2>(p, st);
+      case 2: return launch_x6<64, 2, 2, 1>(p, st);
+      default: return launch_x6<64, 2, 2, 2>(p, st);
+    }
+  }
+  return (var & 1) ? launch_x6<32, 4, 1, 2>(p, st) : launch_x6<32, 4, 1, 1>(p, st);
 }
 
 // split the weights into the x6 planes (in `ws`) and run the x6 kernel
@@ -1349,6 +1371,17 @@ int thin_wgrad_t(int num_cus, const sg_conv_desc* d, const float* x, const float
     default: return CALL(4);       \
   }
 
+// images per sub-batch such that both activation tensors stay under 2 GiB (>= N: no split needed)
+inline int images_per_2gib(const sg_conv_desc* d) {
+  const int64_t xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+  const int64_t xi = (int64_t)d->H * d->W * xl * 4, yi = (int64_t)d->Ho * d->Wo * yl * 4;
+  const int64_t per = xi > yi ? xi : yi;
+  const int64_t lim = (1ll << 31) - (1ll << 20);
+  if (per * d->N < lim) return d->N;
+  const int64_t nb = lim / per;
+  return (int)(nb < 1 ? 0 : nb);
+}
+
 struct WgradPlan {
   int S;
   int slabs_per_split;
@@ -1417,6 +1450,24 @@ int sg_conv2d_fwd_ws(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d
   if (rc) return rc;
   SG_CHECK_ARG(x && w && y, "sg_conv2d_fwd: null tensor");
   SG_CHECK_ARG(!(flags & SG_EPI_BIAS) || bias, "sg_conv2d_fwd: SG_EPI_BIAS without bias");
+  {
+    // The fast kernels address their operands through 2 GiB buffer descriptors.  A larger batch is run as
+    // sub-batches of whole images (independent in a forward conv), so every image takes the same kernel - and
+    // therefore the same rounding - whatever batch it travels in.
+    const int nb = images_per_2gib(d);
+    if (nb < d->N && nb >= 1) {
+      const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+      for (int n0 = 0; n0 < d->N; n0 += nb) {
+        sg_conv_desc sub = *d;
+        sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
+        const float* xs = (const float*)x + (int64_t)n0 * d->H * d->W * xl;
+        float* ys = (float*)y + (int64_t)n0 * d->Ho * d->Wo * yl;
+        int rcs = sg_conv2d_fwd_ws(ctx, stream, dtype, &sub, xs, w, bias, ys, flags, ws, ws_bytes);
+        if (rcs) return rcs;
+      }
+      return 0;
+    }
+  }
   if (thin_ok(d) && aligned16(x)) {
 #define CALL(CO) thin_fwd_t<CO>(d, (const float*)x, (const float*)w, (const float*)bias, (float*)y, flags, (hipStream_t)stream)
     THIN_SWITCH(d->Cout, CALL)
@@ -1475,6 +1526,21 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   }
   SG_CHECK_ARG(aligned16(ws), "sg_conv2d_dgrad: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
+  {
+    const int nb = images_per_2gib(d);  // see sg_conv2d_fwd_ws
+    if (nb < d->N && nb >= 1) {
+      const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+      for (int n0 = 0; n0 < d->N; n0 += nb) {
+        sg_conv_desc sub = *d;
+        sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
+        const float* dys = (const float*)dy + (int64_t)n0 * d->Ho * d->Wo * yl;
+        float* dxs = (float*)dx + (int64_t)n0 * d->H * d->W * xl;
+        int rcs = sg_conv2d_dgrad(ctx, stream, dtype, &sub, dys, w, bias, dxs, flags, ws, ws_bytes);
+        if (rcs) return rcs;
+      }
+      return 0;
+    }
+  }
   if (thin_ok(d) && aligned16(dx) && !(flags & (SG_EPI_BIAS | SG_EPI_RELU))) {
 #define CALL(CO) thin_dgrad_t<CO>(d, (const float*)dy, (const float*)w, (float*)dx, st)
     THIN_SWITCH(d->Cout, CALL)

@@ -78,7 +78,7 @@ inline int x6_kpad(int K) { return (int)(sg_cdiv(K, 32) * 32); }
 inline int x6_npad(int N) { return (int)(sg_cdiv(N, 128) * 128); }
 inline size_t x6_planes_bytes(int K, int N) { return (size_t)3 * x6_kpad(K) * x6_npad(N) * 2; }
 
-template <int BN, int WGM, int WGN>
+template <int BN, int WGM, int WGN, int PF>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(const IgemmParams p) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
@@ -155,9 +155,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
   const __amdgpu_buffer_rsrc_t rsrc_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wq), 0, (int)p.w_bytes, 0x00020000);
 
-  f32x4 ra[NA];
-  u32x4_t rb[NB];
-  auto load_AB = [&](int k0) {
+  f32x4 ra[PF][NA];
+  u32x4_t rb[PF][NB];
+  auto load_AB = [&](int k0, auto SET) {
+    constexpr int S = decltype(SET)::value;
     const int tap = (int)fd_div((uint32_t)k0, p.fd_c);
     if (tap != cur_tap) {  // uniform
       cur_tap = tap;
@@ -176,19 +177,20 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
-      ra[j] = __builtin_bit_cast(f32x4, v);
+      ra[S][j] = __builtin_bit_cast(f32x4, v);
     }
     const int soff_b = k0 * 2;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
+    for (int i = 0; i < NB; ++i) rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
   };
 
-  auto store_AB = [&]() {
+  auto store_AB = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       unsigned h0, m0_, l0, h1, m1, l1;
-      split3_pair(ra[j][0], ra[j][1], h0, m0_, l0);
-      split3_pair(ra[j][2], ra[j][3], h1, m1, l1);
+      split3_pair(ra[S][j][0], ra[S][j][1], h0, m0_, l0);
+      split3_pair(ra[S][j][2], ra[S][j][3], h1, m1, l1);
       char* dst = Ap + (r0 + RS * j) * XPITCH + kc * 8;
       *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
       *reinterpret_cast<u32x2_t*>(dst + BM * XPITCH) = (u32x2_t){m0_, m1};
@@ -200,7 +202,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
       if (idx < NBC) {
         const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
         const int row = rem >> 2, c = rem & 3;
-        *reinterpret_cast<u32x4_t*>(Bp + (pl * BN + row) * XPITCH + c * 16) = rb[i];
+        *reinterpret_cast<u32x4_t*>(Bp + (pl * BN + row) * XPITCH + c * 16) = rb[S][i];
       }
     }
   };
@@ -219,32 +221,47 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
   const char* a_lane = Ap + (wm + lr) * XPITCH + lh * 16;
   const char* b_lane = Bp + (wn + lr) * XPITCH + lh * 16;
 
+  // All 18 (TM = 2, TN = 1) fragment reads of the slab's two k-steps are issued back to back, then the 24 MFMAs:
+  // the MFMAs of k-step 0 start when its nine fragments have landed and cover the flight of k-step 1's.  (Left to
+  // itself the scheduler sinks every read to just before its first MFMA behind an lgkmcnt(0) - minimal
+  // registers, but the LDS latency is then paid ~12 times per slab and the phase ran at 42 % of the MFMA rate.)
+  // (4-wave workgroups have the registers for both k-steps' fragments; 8-wave ones hoist one k-step at a time.)
+  constexpr int KH = (NT == 256) ? 2 : 1;  // k-steps whose fragments are in flight together
   auto compute = [&]() {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[TM][3], bf[TN][3];
+    for (int k0s = 0; k0s < 2; k0s += KH) {
+      bf16x8_t af[KH][TM][3], bf[KH][TN][3];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int kq = 0; kq < KH; ++kq) {
+        const int ks = k0s + kq;
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          af[i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane + (pl * BM + 32 * i) * XPITCH + ks * 32);
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+          for (int pl = 0; pl < 3; ++pl)
+            af[kq][i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane + (pl * BM + 32 * i) * XPITCH + ks * 32);
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          bf[j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane + (pl * BN + 32 * j) * XPITCH + ks * 32);
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int pl = 0; pl < 3; ++pl)
+            bf[kq][j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane + (pl * BN + 32 * j) * XPITCH + ks * 32);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          // smallest terms first
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-        }
+      for (int kq = 0; kq < KH; ++kq) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            // smallest terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][2], bf[kq][j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][0], bf[kq][j][2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][1], bf[kq][j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][1], bf[kq][j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][0], bf[kq][j][1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][0], bf[kq][j][0], acc[i][j], 0, 0, 0);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -297,13 +314,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
   };
 
   if (nslab > 0) {
-    load_AB(next_k0());
-    for (int s = 0; s < nslab; ++s) {
-      __syncthreads();  // every wave has finished reading the previous slab
-      store_AB();
-      __syncthreads();
-      load_AB(next_k0());  // the tail reloads the last slab (unused): no branch
-      compute();
+    if constexpr (PF == 1) {
+      // p.ablate (timing-only diagnostics, results wrong): 1 = no global loads in the loop, 2 = no LDS store and
+      // no barriers, 4 = no MFMA phase
+      const bool do_ld = !(p.ablate & 1), do_st = !(p.ablate & 2), do_mm = !(p.ablate & 4);
+      load_AB(next_k0(), IC<0>{});
+      for (int s = 0; s < nslab; ++s) {
+        if (do_st) {
+          __syncthreads();  // every wave has finished reading the previous slab
+          store_AB(IC<0>{});
+          __syncthreads();
+        }
+        const int kn = next_k0();
+        if (do_ld) load_AB(kn, IC<0>{});  // the tail reloads the last slab (unused): no branch
+        if (do_mm) compute();
+      }
+    } else {
+      // two register sets: slab s+1 is landing in one while slab s+2 is being fetched into the other, so a
+      // load has two compute phases (not one) to return from the fabric
+      load_AB(next_k0(), IC<0>{});
+      load_AB(next_k0(), IC<1>{});
+      for (int s = 0; s < nslab; s += 2) {
+        __syncthreads();
+        store_AB(IC<0>{});
+        __syncthreads();
+        load_AB(next_k0(), IC<0>{});
+        compute();
+        if (s + 1 >= nslab) break;
+        __syncthreads();
+        store_AB(IC<1>{});
+        __syncthreads();
+        load_AB(next_k0(), IC<1>{});
+        compute();
+      }
     }
   }
 
@@ -330,14 +373,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
   }
 }
 
-template <int BN, int WGM, int WGN>
+template <int BN, int WGM, int WGN, int PF>
 int launch_x6(const IgemmParams& p, hipStream_t st) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr size_t lds = (size_t)3 * (BM + BN) * XPITCH + 256 + (size_t)(BM * BK / 4) * sizeof(int);
   (void)NT;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(conv_x6_kernel<BN, WGM, WGN>, lds);
+    int rc = set_dyn_lds(conv_x6_kernel<BN, WGM, WGN, PF>, lds);
     if (rc) return rc;
     attr_done = true;
   }
@@ -346,9 +389,20 @@ int launch_x6(const IgemmParams& p, hipStream_t st) {
     sg_set_error("conv_x6: bad tile count %lld", (long long)tiles);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL((conv_x6_kernel<BN, WGM, WGN>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((conv_x6_kernel<BN, WGM, WGN, PF>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("conv_x6_kernel");
   return 0;
+}
+
+// Variant switch for A/B runs: SG_X6_VARIANT bit 0 = two-slab register prefetch, bit 1 = 4-wave workgroups
+// (64x64 sub-tile per wave: half the LDS fragment traffic per MFMA, 256 VGPRs per wave).
+inline int x6_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SG_X6_VARIANT");
+    v = e ? atoi(e) & 3 : 1;
+  }
+  return v;
 }
 
 // A/B switch: SG_CONV_X6=0 keeps every convolution on the native fp32 MFMA kernel.

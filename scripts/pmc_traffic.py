@@ -21,10 +21,10 @@ for kind, mul in (("fetch", 2 * 1024), ("write", 1024)):
     helpers = 0.0
     for r in rows:
         k, v = r["Kernel_Name"], float(r["Counter_Value"]) * mul
-        if "igemm_conv_kernel" in k:  # per case: 3 forward launches (1 + warm-up + 1 timed), then 2 dgrad
+        if "igemm_conv_kernel" in k or "conv_x6_kernel" in k:  # per case: 3 forward launches (1 + warm-up + 1 timed), then 2 dgrad
             per["fwd" if ci % 5 < 3 else "dgrad"].setdefault(ci // 5, []).append(v)
             ci += 1
-        elif "igemm_wgrad_kernel" in k:
+        elif "igemm_wgrad_kernel" in k or "wgrad_x6_kernel" in k:
             per["wgrad"].setdefault(wi // 2, []).append(v)
             wi += 1
         elif "copyBuffer" not in k:
