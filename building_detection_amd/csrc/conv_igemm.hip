@@ -1032,11 +1032,17 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
     static int abl = -1;
     if (abl < 0) {
       const char* e = getenv("SG_X6_ABLATE");
-      abl = e ? atoi(e) & 7 : 0;
+      abl = e ? atoi(e) & 15 : 0;
     }
     p.ablate = abl;
   }
-  const int var = x6_variant();
+  // Structure by tile count (measured, profiles/r01_ab_x6.txt): with at most one or two tiles per CU there is no
+  // second workgroup to overlap with, and the double-buffered one-workgroup-per-CU form wins (ASPP / SK forward:
+  // 1.00 -> 0.93 ms, 0.148 -> 0.138 ms); with many tiles the two-workgroups-per-CU single-buffer form does
+  // (ASPP dgrad 0.87 vs 0.97 ms).  SG_X6_VARIANT overrides.
+  const int64_t tiles = sg_cdiv(p.M, BM) * sg_cdiv(p.Nout, bn);
+  int var = x6_variant();
+  if (var < 0) var = (tiles <= 2 * (int64_t)num_cus) ? 1 : 0;
   if (bn == 128) {
     switch (var) {
       case 0: return launch_x6<128, 2, 4, 1>(p, st);

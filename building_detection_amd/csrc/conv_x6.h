@@ -78,9 +78,18 @@ inline int x6_kpad(int K) { return (int)(sg_cdiv(K, 32) * 32); }
 inline int x6_npad(int N) { return (int)(sg_cdiv(N, 128) * 128); }
 inline size_t x6_planes_bytes(int K, int N) { return (size_t)3 * x6_kpad(K) * x6_npad(N) * 2; }
 
+// PF == 1: single LDS buffer, two barriers per slab, two workgroups per CU (128 VGPRs per wave).
+// PF == 2: ONE workgroup per CU with the whole register file (256 VGPRs per wave): LDS double-buffered, one
+//   barrier per slab, two register sets (loads run two slabs ahead), and the wave halves staggered - waves
+//   0..n/2-1 split + store slab s+1 BEFORE their MFMAs of slab s, waves n/2..n-1 AFTER - so on every SIMD one
+//   wave's VALU / LDS-write phase runs under its partner's MFMA phase.  (With the single buffer both workgroups of
+//   a CU run in lockstep - store, barrier, compute - and the phases simply add up: measured store 0.41 ms +
+//   compute 0.66 ms = 1.02 ms on the ASPP forward; the bare read + MFMA loop reaches 80-88 % of the pipe,
+//   profiles/r01_exp_x6_loop.txt.)
 template <int BN, int WGM, int WGN, int PF>
-__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(const IgemmParams p) {
+__global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM * WGN / 2) void conv_x6_kernel(const IgemmParams p) {
   constexpr int NT = 64 * WGM * WGN;
+  constexpr int BUFSZ = 3 * (BM + BN) * XPITCH;  // one LDS buffer: A planes then B planes
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
   constexpr int NA = (BM * BK / 4) / NT;  // float4 A chunks per thread (rows r0 + RS*j)
@@ -90,9 +99,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
   static_assert(TM >= 1 && TN >= 1 && NA >= 1, "tile too small for the wave layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ap = smem;                          // [3][BM][XPITCH]
-  char* Bp = Ap + 3 * BM * XPITCH;          // [3][BN][XPITCH]
-  int* tapinfo = reinterpret_cast<int*>(Bp + 3 * BN * XPITCH);  // [64]
+  char* Ap = smem;                          // [PF buffers] x { A [3][BM][XPITCH], B [3][BN][XPITCH] }
+  char* Bp = Ap + 3 * BM * XPITCH;
+  int* tapinfo = reinterpret_cast<int*>(smem + PF * BUFSZ);  // [64]
   int* row_lin_lds = tapinfo + 64;          // [NA][NT]
 
   const int t = threadIdx.x;
@@ -184,14 +193,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
     for (int i = 0; i < NB; ++i) rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
   };
 
-  auto store_AB = [&](auto SET) {
+  auto store_AB = [&](auto SET, int buf) {
     constexpr int S = decltype(SET)::value;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       unsigned h0, m0_, l0, h1, m1, l1;
       split3_pair(ra[S][j][0], ra[S][j][1], h0, m0_, l0);
       split3_pair(ra[S][j][2], ra[S][j][3], h1, m1, l1);
-      char* dst = Ap + (r0 + RS * j) * XPITCH + kc * 8;
+      char* dst = Ap + buf * BUFSZ + (r0 + RS * j) * XPITCH + kc * 8;
       *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
       *reinterpret_cast<u32x2_t*>(dst + BM * XPITCH) = (u32x2_t){m0_, m1};
       *reinterpret_cast<u32x2_t*>(dst + 2 * BM * XPITCH) = (u32x2_t){l0, l1};
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
       if (idx < NBC) {
         const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
         const int row = rem >> 2, c = rem & 3;
-        *reinterpret_cast<u32x4_t*>(Bp + (pl * BN + row) * XPITCH + c * 16) = rb[S][i];
+        *reinterpret_cast<u32x4_t*>(Bp + buf * BUFSZ + (pl * BN + row) * XPITCH + c * 16) = rb[S][i];
       }
     }
   };
@@ -226,8 +235,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
   // itself the scheduler sinks every read to just before its first MFMA behind an lgkmcnt(0) - minimal
   // registers, but the LDS latency is then paid ~12 times per slab and the phase ran at 42 % of the MFMA rate.)
   // (4-wave workgroups have the registers for both k-steps' fragments; 8-wave ones hoist one k-step at a time.)
-  constexpr int KH = (NT == 256) ? 2 : 1;  // k-steps whose fragments are in flight together
-  auto compute = [&]() {
+  constexpr int KH = (NT == 256 || PF == 2) ? 2 : 1;  // k-steps whose fragments are in flight together
+  auto compute = [&](int buf) {
+    const char* a_lane_b = a_lane + buf * BUFSZ;
+    const char* b_lane_b = b_lane + buf * BUFSZ;
 #pragma unroll
     for (int k0s = 0; k0s < 2; k0s += KH) {
       bf16x8_t af[KH][TM][3], bf[KH][TN][3];
@@ -238,12 +249,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            af[kq][i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane + (pl * BM + 32 * i) * XPITCH + ks * 32);
+            af[kq][i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (pl * BM + 32 * i) * XPITCH + ks * 32);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            bf[kq][j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane + (pl * BN + 32 * j) * XPITCH + ks * 32);
+            bf[kq][j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (pl * BN + 32 * j) * XPITCH + ks * 32);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -322,30 +333,38 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
       for (int s = 0; s < nslab; ++s) {
         if (do_st) {
           __syncthreads();  // every wave has finished reading the previous slab
-          store_AB(IC<0>{});
+          store_AB(IC<0>{}, 0);
           __syncthreads();
         }
         const int kn = next_k0();
         if (do_ld) load_AB(kn, IC<0>{});  // the tail reloads the last slab (unused): no branch
-        if (do_mm) compute();
+        if (do_mm) compute(0);
       }
     } else {
-      // two register sets: slab s+1 is landing in one while slab s+2 is being fetched into the other, so a
-      // load has two compute phases (not one) to return from the fabric
+      const bool late = __builtin_amdgcn_readfirstlane(t >> 6) >= (NT / 128);
+      // p.ablate (timing-only diagnostics, results wrong): 1 = no global loads, 2 = no split + LDS store, 4 = no MFMA
+      // phase, 8 = no stagger (every wave stores after its MFMAs)
+      const bool do_ld = !(p.ablate & 1), do_st = !(p.ablate & 2), do_mm = !(p.ablate & 4);
+      const bool early = !late && !(p.ablate & 8);
       load_AB(next_k0(), IC<0>{});
       load_AB(next_k0(), IC<1>{});
+      store_AB(IC<0>{}, 0);
+      load_AB(next_k0(), IC<0>{});  // slab 2 (the iterator repeats the last slab past the end: stored, never read)
+      __syncthreads();
       for (int s = 0; s < nslab; s += 2) {
+        // slab s from buffer 0; slab s+1 (set 1) goes to buffer 1, set 1 then fetches slab s+3
+        const int ka = next_k0();
+        if (early) { if (do_st) store_AB(IC<1>{}, 1); if (do_ld) load_AB(ka, IC<1>{}); }
+        if (do_mm) compute(0);
+        if (!early) { if (do_st) store_AB(IC<1>{}, 1); if (do_ld) load_AB(ka, IC<1>{}); }
         __syncthreads();
-        store_AB(IC<0>{});
-        __syncthreads();
-        load_AB(next_k0(), IC<0>{});
-        compute();
         if (s + 1 >= nslab) break;
+        // slab s+1 from buffer 1; slab s+2 (set 0) goes to buffer 0, set 0 then fetches slab s+4
+        const int kb = next_k0();
+        if (early) { if (do_st) store_AB(IC<0>{}, 0); if (do_ld) load_AB(kb, IC<0>{}); }
+        if (do_mm) compute(1);
+        if (!early) { if (do_st) store_AB(IC<0>{}, 0); if (do_ld) load_AB(kb, IC<0>{}); }
         __syncthreads();
-        store_AB(IC<1>{});
-        __syncthreads();
-        load_AB(next_k0(), IC<1>{});
-        compute();
       }
     }
   }
@@ -376,7 +395,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_x6_kernel(
 template <int BN, int WGM, int WGN, int PF>
 int launch_x6(const IgemmParams& p, hipStream_t st) {
   constexpr int NT = 64 * WGM * WGN;
-  constexpr size_t lds = (size_t)3 * (BM + BN) * XPITCH + 256 + (size_t)(BM * BK / 4) * sizeof(int);
+  constexpr size_t lds = (size_t)PF * 3 * (BM + BN) * XPITCH + 256 + (size_t)(BM * BK / 4) * sizeof(int);
   (void)NT;
   static bool attr_done = false;
   if (!attr_done) {
@@ -394,13 +413,13 @@ int launch_x6(const IgemmParams& p, hipStream_t st) {
   return 0;
 }
 
-// Variant switch for A/B runs: SG_X6_VARIANT bit 0 = two-slab register prefetch, bit 1 = 4-wave workgroups
-// (64x64 sub-tile per wave: half the LDS fragment traffic per MFMA, 256 VGPRs per wave).
+// Variant switch for A/B runs: SG_X6_VARIANT bit 0 = the one-workgroup-per-CU structure (PF == 2 above), bit 1 =
+// 4-wave workgroups (64x64 sub-tile per wave: half the LDS fragment traffic per MFMA).
 inline int x6_variant() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("SG_X6_VARIANT");
-    v = e ? atoi(e) & 3 : 1;
+    v = e ? atoi(e) & 3 : -1;  // -1: chosen per launch (dispatch_x6)
   }
   return v;
 }

@@ -1,0 +1,139 @@
+// Experiment: ceiling of the x6 inner loop (LDS fragment reads + six-pass bf16 MFMAs) with no global traffic.
+// One workgroup = a 128x128 tile of the real kernel (planes [3][128 rows][80 B] for A and B in LDS); every
+// "slab" is two 16-deep k-steps.  Variants:
+//   MODE 0: reads(ks) ; MFMAs(ks)                      (what conv_x6_kernel does with 8 waves)
+//   MODE 1: fragments double-buffered: reads(ks+1) are issued before MFMAs(ks)
+//   MODE 2: as 1, and the reads are interleaved one per MFMA (sched_group_barrier)
+// BAR: a __syncthreads() per slab (as the real kernel has two).  Reports bf16 MFMA TFLOP/s and the fp32-equivalent.
+// Build: hipcc -O3 --offload-arch=gfx950 scripts/exp_x6_loop.hip -o build/exp_x6_loop
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int BM = 128, BN = 128, PITCH = 80;
+
+template <int WGM, int WGN, int MODE, int BAR>
+__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void loop_kernel(float* out, int slabs) {
+  constexpr int NT = 64 * WGM * WGN;
+  constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Ap = smem;
+  char* Bp = Ap + 3 * BM * PITCH;
+  for (int i = threadIdx.x; i < 3 * (BM + BN) * PITCH / 4; i += NT) reinterpret_cast<unsigned*>(smem)[i] = 0x3c003c00u + (i & 0xff);
+  __syncthreads();
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 31, lh = lane >> 5;
+  const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+  const char* a_lane = Ap + (wm + lr) * PITCH + lh * 16;
+  const char* b_lane = Bp + (wn + lr) * PITCH + lh * 16;
+  f32x16 acc[TM][TN];
+  for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) acc[i][j] = (f32x16){0};
+
+  auto rd = [&](bf16x8 (&af)[TM][3], bf16x8 (&bf)[TN][3], int ks) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const bf16x8*>(a_lane + (pl * BM + 32 * i) * PITCH + ks * 32);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8*>(b_lane + (pl * BN + 32 * j) * PITCH + ks * 32);
+  };
+  auto mm = [&](bf16x8 (&af)[TM][3], bf16x8 (&bf)[TN][3]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+      }
+  };
+
+  if constexpr (MODE == 0) {
+    for (int s = 0; s < slabs; ++s) {
+      if (BAR) __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 af[TM][3], bf[TN][3];
+        rd(af, bf, ks);
+        __builtin_amdgcn_sched_barrier(0);
+        mm(af, bf);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  } else {
+    bf16x8 af0[TM][3], bf0[TN][3], af1[TM][3], bf1[TN][3];
+    rd(af0, bf0, 0);
+    for (int s = 0; s < slabs; ++s) {
+      rd(af1, bf1, 1);
+      if (MODE == 1) __builtin_amdgcn_sched_barrier(0);
+      mm(af0, bf0);
+      if (MODE == 2) {
+        for (int q = 0; q < 3 * (TM + TN); ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);  // 1 DS read
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (BAR) __syncthreads();
+      rd(af0, bf0, 0);  // next slab's first k-step (the real kernel could only do this after its barrier)
+      if (MODE == 1) __builtin_amdgcn_sched_barrier(0);
+      mm(af1, bf1);
+      if (MODE == 2) {
+        for (int q = 0; q < 3 * (TM + TN); ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  float sum = 0.f;
+  for (int i = 0; i < TM; ++i) for (int j = 0; j < TN; ++j) for (int r = 0; r < 16; ++r) sum += acc[i][j][r];
+  if (sum == 1.2345f) out[0] = sum;
+}
+
+template <int WGM, int WGN, int MODE, int BAR>
+void run(const char* name, int wg_per_cu, float* dout) {
+  const int slabs = 4000;
+  const size_t lds = 3 * (BM + BN) * PITCH;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(loop_kernel<WGM, WGN, MODE, BAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  float ms = 0;
+  for (int rep = 0; rep < 2; ++rep) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((loop_kernel<WGM, WGN, MODE, BAR>), dim3(256 * wg_per_cu), dim3(64 * WGM * WGN), lds, 0, dout, slabs);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    CK(hipEventElapsedTime(&ms, e0, e1));
+  }
+  const double flop = 256.0 * wg_per_cu * slabs * 2.0 * 128 * 128 * 32 * 6;  // bf16 MFMA flops
+  printf("%-34s %d WG/CU  mode %d bar %d: %7.2f ms  bf16 %7.1f TFLOP/s  fp32-equivalent %6.1f TFLOP/s (%.0f %% of 416.7)\n", name, wg_per_cu, MODE, BAR, ms,
+         flop / ms / 1e9, flop / ms / 1e9 / 6, flop / ms / 1e9 / 6 / 416.7 * 100);
+}
+
+int main() {
+  float* dout; CK(hipMalloc(&dout, 64));
+  run<2, 4, 0, 0>("8 waves (64x32 per wave)", 1, dout);
+  run<2, 4, 0, 0>("8 waves (64x32 per wave)", 2, dout);
+  run<2, 4, 0, 1>("8 waves (64x32 per wave)", 2, dout);
+  run<2, 4, 1, 0>("8 waves (64x32 per wave)", 1, dout);
+  run<2, 4, 1, 0>("8 waves (64x32 per wave)", 2, dout);
+  run<2, 4, 1, 1>("8 waves (64x32 per wave)", 2, dout);
+  run<2, 4, 2, 0>("8 waves (64x32 per wave)", 2, dout);
+  run<2, 2, 0, 0>("4 waves (64x64 per wave)", 1, dout);
+  run<2, 2, 0, 0>("4 waves (64x64 per wave)", 2, dout);
+  run<2, 2, 0, 1>("4 waves (64x64 per wave)", 2, dout);
+  run<2, 2, 1, 0>("4 waves (64x64 per wave)", 1, dout);
+  run<2, 2, 1, 0>("4 waves (64x64 per wave)", 2, dout);
+  run<2, 2, 1, 1>("4 waves (64x64 per wave)", 2, dout);
+  run<2, 2, 2, 0>("4 waves (64x64 per wave)", 2, dout);
+  run<2, 2, 2, 1>("4 waves (64x64 per wave)", 2, dout);
+  return 0;
+}
