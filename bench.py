@@ -26,6 +26,8 @@ sys.path.insert(0, ROOT)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
+LABEL = {"v3plus": "DeepLabv3+ (v3plus.py)", "bam": "DeepLabv3+ BAM (bam.py)", "scse": "SCSE-UNet (scse.py)",
+         "res34": "Res34-UNet (res34.py)", "hrnet": "HRNet (hrnet.py)"}
 DILATED_GFLOP_PER_TILE = 97.84  # fwd + dgrad + wgrad of the 6 dilated convs, SURVEY.md §8d
 
 
@@ -156,12 +158,12 @@ def main():
             traffic_note = ("bytes per step of the kernel set, L2-miss side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits "
                             "included); algorithmic bytes of the set = %d" % int(tr["algorithmic_bytes_per_step"]))
         out = {
-            "metric": "512x512 tiles/sec fwd+bwd DeepLabv3+ (full train step: fwd+loss+bwd+Adam)",
+            "metric": f"{args.size}x{args.size} tiles/sec fwd+bwd {LABEL.get(args.model, args.model)} (full train step: fwd+loss+bwd+Adam)",
             "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "dtype_note": "fp32 tensors, fp32 accumulation; conv products as 6 bf16 MFMA passes over an exact 3-way split" if x6 else "fp32 MFMA",
-            "config": {"workload": f"DeepLabv3+ (v3plus.py) {args.size}x{args.size} bs={args.batch}/GPU fp32, "
+            "config": {"workload": f"{LABEL.get(args.model, args.model)} {args.size}x{args.size} bs={args.batch}/GPU fp32, "
                                    f"train step, {'dp%d' % world if world > 1 else 'single GPU'}",
                        "global_batch": world * args.batch, "model_flops_per_step_tflop": round(step_tflop, 3),
                        "step_achieved_tflops": round(step_tflop / (ms_per_step / 1e3), 2),

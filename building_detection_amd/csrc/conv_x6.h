@@ -447,9 +447,9 @@ inline bool x6_ok(const IgemmParams& p, bool vec) {
 // LDS read ds_read_b64_tr_b16: per 16-lane group a 4-pixel x 16-channel block, lane i receiving channel i of
 // the four pixels (mapping verified by scripts/exp_trread.hip).  Row pitch = channel bytes + 64 (an odd
 // multiple of 64 B modulo 256), which spreads the four pixel rows of a block over all 64 banks.
-// Loads follow the aligned-slab scheme of igemm_wgrad_kernel<FAST = 2>: constant per-thread voffsets, the slab's
-// position, image row and bounds on the scalar unit.  Requires OW % 32 == 0, stride 1, "same" geometry and the
-// tile's 128 r-rows inside one tap (1x1 kernel or Cin % 128 == 0).
+// Loads follow the aligned-slab scheme of igemm_wgrad_kernel<FAST = 2>: constant per-thread voffsets (which here
+// also carry the thread's tap shift, so a 128-row tile may span several taps: Cin = 32, 64), the slab's position
+// and image row on the scalar unit.  Requires OW % 32 == 0, stride 1 and "same" geometry.
 typedef short s16x4_t __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_ptr;
 
@@ -505,8 +505,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
   }
   const int rbase = tile_r * BM, n0 = tile_n * BN;
 
+  // This thread's four r-rows (one float4 of channels) lie in ONE tap (Cin % 4 == 0); the tile's 128 rows may
+  // span several taps (Cin < 128), so the tap offset (dh, dw) is per thread and rides in the voffset.
   const int rc = t & 31, pr0 = t >> 5;
-  const int tap = rbase / p.Cin;  // uniform: the whole tile lies in this tap
+  const int r_first = rbase + 4 * rc;
+  const bool rvalid = r_first < p.K;
+  const int tap = (rvalid ? r_first : rbase) / p.Cin;
   int s_dh, s_dw;
   {
     uint32_t kh, kw;
@@ -514,8 +518,6 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
     s_dh = (int)kh * p.dil - p.pad_t;
     s_dw = (int)kw * p.dil - p.pad_l;
   }
-  const int r_first = rbase + 4 * rc;
-  const bool rvalid = r_first < p.K;
   const int ci0 = r_first - tap * p.Cin;
 
   const int slab_begin = (int)split * p.slabs_per_split;
@@ -524,13 +526,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
   if (slab_end > nslab_total) slab_end = nslab_total;
 
   constexpr unsigned OOB = 0x80000000u;
-  constexpr int SH = 32;
+  // the descriptor's base sits SH pixels before x (SH = the most negative tap shift), so that voffset =
+  // (pixel-in-slab + tap shift + SH) * x_ld + channel is non-negative and the slab's position is the scalar offset
+  const int SH = p.pad_t * p.W + p.pad_l;
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(p.x) - (int64_t)SH * p.x_ld, 0, (int)(p.x_bytes + (uint32_t)(SH * p.x_ld * 4)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
   unsigned a_voffc[NA], b_voff[NB];
 #pragma unroll
-  for (int j = 0; j < NA; ++j) a_voffc[j] = rvalid ? (unsigned)((pr0 + PS * j) * p.x_ld + ci0) * 4u : OOB;
+  for (int j = 0; j < NA; ++j)
+    a_voffc[j] = rvalid ? (unsigned)((pr0 + PS * j + s_dh * p.W + s_dw + SH) * p.x_ld + ci0) * 4u : OOB;
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int idx = t + NT * i;
@@ -545,7 +550,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
     fd_divmod(q, p.fd_oh, n_, oh);
     const int ih = (int)oh + s_dh;
     const bool row_ok = (unsigned)ih < (unsigned)p.H;
-    const int soff_a = row_ok ? (p0 + s_dh * p.W + s_dw + SH) * p.x_ld * 4 : 0;
+    const int soff_a = p0 * p.x_ld * 4;
     const int col0 = (int)ow0 + s_dw + pr0;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
@@ -648,7 +653,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
       uint32_t q, tmp, n_, oh;
       fd_divmod((uint32_t)pa, p.fd_ow, q, tmp);
       fd_divmod(q, p.fd_oh, n_, oh);
-      const bool act = ((int)oh + s_dh >= 0) && ((int)oh + s_dh < p.H) && (s_dw > -p.W) && (s_dw < p.W);
+      const int tap_lo = rbase / p.Cin;
+      int tap_hi = (rbase + BM - 1 < p.K ? rbase + BM - 1 : p.K - 1) / p.Cin;
+      bool act = false;
+      for (int tp = tap_lo; tp <= tap_hi && !act; ++tp) {
+        uint32_t kh, kw;
+        fd_divmod((uint32_t)tp, p.fd_kw, kh, kw);
+        const int ddh = (int)kh * p.dil - p.pad_t, ddw = (int)kw * p.dil - p.pad_l;
+        act = ((int)oh + ddh >= 0) && ((int)oh + ddh < p.H) && (ddw > -p.W) && (ddw < p.W);
+      }
       flags[i] = act ? 1 : 0;
     }
     __syncthreads();
@@ -706,6 +719,6 @@ int launch_wgrad_x6(const WgradParams& p, int S, hipStream_t st) {
 
 inline bool wgrad_x6_ok(const WgradParams& p, bool vec) {
   const bool fast = p.stride == 1 && p.OH == p.H && p.OW == p.W && p.x_bytes != 0 && p.dy_bytes != 0;
-  return x6_enabled() && vec && fast && (p.OW % BK == 0) && (p.KH_KW == 1 || p.Cin % BM == 0) && p.Cout >= 16 &&
-         ((int64_t)p.x_bytes + 2 * 32 * (int64_t)p.x_ld * 4 < (1ll << 31));
+  const int64_t sh_bytes = ((int64_t)p.pad_t * p.W + p.pad_l + 64) * p.x_ld * 4;
+  return x6_enabled() && vec && fast && (p.OW % BK == 0) && p.Cout >= 16 && ((int64_t)p.x_bytes + 2 * sh_bytes < (1ll << 31));
 }

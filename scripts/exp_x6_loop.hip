@@ -23,7 +23,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void loop_kernel(flo
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Ap = smem;
   char* Bp = Ap + 3 * BM * PITCH;
-  for (int i = threadIdx.x; i < 3 * (BM + BN) * PITCH / 4; i += NT) reinterpret_cast<unsigned*>(smem)[i] = 0x3c003c00u + (i & 0xff);
+  // RANDOM operands (pseudo-random bf16 pairs of magnitude ~1): constant or zero operands toggle few bits, draw
+  // less power and read high (cdna_hip_programming.md rule 25); set X6_CONST=1 at build time for that variant
+  for (int i = threadIdx.x; i < 3 * (BM + BN) * PITCH / 4; i += NT) {
+#ifdef X6_CONST
+    reinterpret_cast<unsigned*>(smem)[i] = 0x3c003c00u + (i & 0xff);
+#else
+    unsigned h = (unsigned)i * 2654435761u + blockIdx.x * 40503u;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    reinterpret_cast<unsigned*>(smem)[i] = (h & 0x807f807fu) | 0x3f003f00u | ((h >> 3) & 0x00800080u);
+#endif
+  }
   __syncthreads();
   const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 31, lh = lane >> 5;
   const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;

@@ -54,6 +54,10 @@ CONV_CASES = [
     # aligned-slab wgrad path (W % 32 == 0): pointwise with ragged channel tile, 3x3 with Cin % 128 == 0
     (1, 32, 32, 200, 136, 1, 1, 1, "wgrad_aligned_pw_ragged"),
     (1, 32, 64, 128, 64, 3, 1, 2, "wgrad_aligned_3x3_d2"),
+    # x6 wgrad with a 128-row tile spanning several taps (Cin 32 / 64), ragged last tile (K = 9*48 = 432)
+    (1, 32, 32, 32, 32, 3, 1, 1, "x6_wgrad_c32"),
+    (2, 32, 64, 64, 48, 3, 1, 1, "x6_wgrad_c64_cout48"),
+    (1, 64, 32, 48, 80, 3, 1, 3, "x6_wgrad_c48_d3"),
 ]
 
 
