@@ -107,7 +107,8 @@ static inline SegPlan seg_plan(int num_cus, int nseg, int64_t rows, int C, bool 
   int64_t S = sg_cdiv((int64_t)4 * num_cus, (int64_t)pl.gx);
   const int64_t maxS = sg_cdiv(rows, (int64_t)pl.TY * 4);
   if (S > maxS) S = maxS;
-  if (S > 256) S = 256;
+  if (S > 1024) S = 1024;  // few-channel maps at full resolution (C = 32: one column block) need the row split
+                           // for occupancy: 1024 workgroups = 4 per CU
   if (S < 1) S = 1;
   pl.S = (int)S;
   pl.part_bytes = (size_t)nseg * pl.S * NOUT * C * sizeof(float);

@@ -101,7 +101,8 @@ class _ConvNode(Node):
             dz = dy
         d = self.desc(rt, x)
         with e.timed(self._tag):
-            e.conv2d_wgrad(x, dz, d, want_bias=self.b is not None, dw=rt.grad(self.w), db=rt.grad(self.b) if self.b else None)
+            want_b = self.b is not None and not getattr(self, "bias_grad_zero", False)
+            e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=rt.grad(self.w), db=rt.grad(self.b) if want_b else None)
             dx = e.conv2d_dgrad(dz, rt.param(self.w), d) if rt.needs_grad(self.inputs[0]) else None
         return [dx]
 
@@ -152,7 +153,8 @@ class _SepConvNode(Node):
         t = rt.saved(self)["t"]
         dz = e.act_bwd(y, dy, _lib.SG_ACT_RELU) if self.activation == "relu" else dy
         dpw = e.conv_desc(tuple(t.shape), self.filters, 1, 1)
-        e.conv2d_wgrad(t, dz, dpw, True, dw=rt.grad(self.pw), db=rt.grad(self.b))
+        want_b = not getattr(self, "bias_grad_zero", False)
+        e.conv2d_wgrad(t, dz, dpw, want_b, dw=rt.grad(self.pw), db=rt.grad(self.b) if want_b else None)
         dt = e.conv2d_dgrad(dz, rt.param(self.pw), dpw)
         ddw = e.conv_desc(tuple(x.shape), x.shape[-1], 3, 3, self.stride, 1, "same")
         e.dwconv_wgrad(x, dt, ddw, self.pre_relu, dw=rt.grad(self.dw))

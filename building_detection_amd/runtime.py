@@ -109,6 +109,15 @@ class Model:
         A ReLU is absorbed only if its output has exactly one consumer (or, for producers, it is the only
         consumer of the producer's output and is not a model output)."""
         outs = {id(t) for t in self.outputs}
+        # A bias added right before a training-mode BatchNormalization has an identically zero gradient (BN's input
+        # gradient sums to zero over the batch by construction): the column-sum launch is dropped and the slot in the
+        # gradient arena stays at its initial 0 (what the sum would return up to fp32 noise of ~1e-10).
+        for n in self.nodes:
+            if isinstance(n, (L._ConvNode, L._SepConvNode)) and getattr(n, "activation", None) in (None, "linear") \
+                    and id(n.output) not in outs:
+                cons = n.output.consumers
+                if len(cons) == 1 and isinstance(cons[0], L._BNNode) and len(n.output.shape) == 4:
+                    n.bias_grad_zero = True
         for n in self.nodes:
             if not isinstance(n, L._ActNode) or n.act != "relu" or n.fused_away:
                 continue
