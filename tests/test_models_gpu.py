@@ -212,3 +212,47 @@ def test_weights_roundtrip_and_errors(engine, tmp_path):
         zoo.ResNetFamily((64, 64, 3)).run_model("res50")
     with pytest.raises(ValueError):
         m2.predict(np.zeros((1, 32, 32, 3)))
+
+
+# ---- golden fixtures (tests/golden/, generated from the CPU oracle by make_golden.py) ---------------------------------
+GOLDEN = [("v3plus", "deeplab_v3plus", 64, {"aspp_pool": 4}), ("bam", "deeplab_v3plus_bam", 64, {"aspp_pool": 4}),
+          ("scse", "scse_unet", 32, {}), ("res34", "res34_unet", 32, {}), ("hrnet", "hrnet", 32, {})]
+
+
+@pytest.mark.parametrize("name,fn,size,kw", GOLDEN, ids=[g[0] for g in GOLDEN])
+def test_golden_fixture(engine, name, fn, size, kw):
+    """The HIP engine against the committed fixture: same seeded weights (re-created by the oracle's initialisers,
+    checked by checksum), predict() within 1e-4 of the stored probabilities (north_star: 1e-3) with bit-identical
+    argmax away from ties, training loss within 1e-4 relative, per-tensor gradient norms within 2 % overall."""
+    import os
+    from building_detection_amd import zoo
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", f"model_{name}.npz"))
+    x, y = synthetic_batch(2, size, size, seed=int(gold["seed"]))
+    assert abs(float(x.astype(np.float64).sum()) - float(gold["x_sum"])) < 1e-6
+    P = M.Params(seed=int(gold["seed"]))
+    with torch.no_grad():
+        getattr(M, fn)(P, torch.from_numpy(x[:1]), training=False, **kw)   # creates the seeded weights
+    ws = [t.detach().numpy() for t in P.tensors]
+    assert len(ws) == int(gold["n_tensors"])
+    assert abs(sum(float(np.abs(w).sum()) for w in ws) - float(gold["w_abs_sum"])) <= 1e-6 * float(gold["w_abs_sum"])
+    model = zoo.BUILDERS[name]((size, size, 3), 2, **kw) if kw else zoo.BUILDERS[name]((size, size, 3))
+    model.set_weights(ws)
+    p = model.predict(x)
+    err = float(np.abs(p - gold["probs"]).max())
+    print(f"golden {name}: max |p - p_gold| = {err:.2e}")
+    assert err <= 1e-4
+    margin = np.abs(gold["probs"][..., 1] - gold["probs"][..., 0])
+    same = (p.argmax(-1) == gold["probs"].argmax(-1)) | (margin < 1e-5)
+    assert same.all()
+    model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
+    logs = model.train_on_batch(x, y)
+    assert abs(logs["loss"] - float(gold["train_loss"])) <= 1e-4 * abs(float(gold["train_loss"]))
+    gn = np.array([float(np.sqrt(np.square(g.astype(np.float64)).sum())) for g in model.get_gradients()])
+    gg = gold["grad_norms"]
+    assert gn.shape == gg.shape
+    big = gg > 1e-6 * gg.max()   # biases in front of BatchNormalization have an identically zero gradient
+    rel = float(np.sqrt(np.square(gn[big] - gg[big]).sum() / np.square(gg[big]).sum()))
+    print(f"golden {name}: training loss {logs['loss']:.6f} (gold {float(gold['train_loss']):.6f}); gradient-norm vector off by {rel:.2e}")
+    assert rel <= 2e-2

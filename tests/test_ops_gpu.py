@@ -407,3 +407,51 @@ def test_inference_tail(engine):
     out = engine.vote_ge([m.cuda() for m in masks], 3).cpu()
     exp = ((sum((m // 255).int() for m in masks) >= 3).to(torch.uint8) * 255)
     assert torch.equal(out, exp)
+
+
+def test_golden_ops(engine):
+    """The HIP ops against the committed op-level fixture tests/golden/ops.npz (made by tests/golden/make_golden.py
+    from the CPU oracle): the TF-semantics corner cases of SURVEY App. B, each through the C ABI."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ops.npz"))
+    c = lambda k: torch.from_numpy(np.ascontiguousarray(g[k])).cuda()  # noqa: E731
+    x, w, b = c("conv_x"), c("conv_w"), c("conv_b")
+    close(engine.conv2d_fwd(x, w, b, 2, 1, "same"), torch.from_numpy(g["conv_s2_even"]), what="3x3 s2 even size: pad (0,1)")
+    close(engine.conv2d_fwd(x, w, b, 1, 2, "same"), torch.from_numpy(g["conv_d2"]), what="3x3 dilation 2")
+    close(engine.conv2d_fwd(x, w[1:2, 1:2].contiguous(), None, 2, 1, "same"), torch.from_numpy(g["conv_1x1_s2"]), what="1x1 s2")
+    dw, pw = c("sep_dw"), c("sep_pw")
+    for stride, key in ((1, "sep_y"), (2, "sep_y_s2")):
+        t = engine.dwconv_fwd(x, dw, stride)
+        close(engine.conv2d_fwd(t, pw, b[:5].contiguous(), 1, 1, "same"), torch.from_numpy(g[key]), what=f"SeparableConv2D s{stride}")
+    n, h, wd, cin = x.shape
+    for k, wk, yk, bias in ((3, "convT_w3", "convT_k3", b[:5].contiguous()), (2, "convT_w2", "convT_k2", None)):
+        d = engine.conv_desc((n, 2 * h, 2 * wd, 5), cin, k, k, 2, 1, "same")
+        close(engine.conv2d_dgrad(x, c(wk), d, bias=bias), torch.from_numpy(g[yk]), what=f"Conv2DTranspose k{k} s2")
+    gam, bet = c("bn_gamma"), c("bn_beta")
+    mm, mv = torch.zeros(4).cuda(), torch.ones(4).cuda()
+    y, _, _ = engine.bn_train_fwd(x, gam, bet, mm, mv)
+    close(y, torch.from_numpy(g["bn_train_y"]), what="BN train y")
+    close(mm, torch.from_numpy(g["bn_new_mean"]), what="BN moving mean")
+    close(mv, torch.from_numpy(g["bn_new_var"]), what="BN moving var (4-D: unbiased)")
+    mm2, mv2 = torch.zeros(4).cuda(), torch.ones(4).cuda()
+    y2, _, _ = engine.bn_train_fwd(c("bn2_x"), gam, bet, mm2, mv2)
+    close(y2, torch.from_numpy(g["bn2_train_y"]), what="BN 2-D train y")
+    close(mv2, torch.from_numpy(g["bn2_new_var"]), what="BN moving var (2-D: biased)")
+    close(engine.bn_infer(x, gam, bet, c("bn_imean"), c("bn_ivar")), torch.from_numpy(g["bn_infer_y"]), what="BN inference")
+    close(engine.maxpool_fwd(x, 3, 2, "same")[0], torch.from_numpy(g["maxpool_3s2_same"]), what="maxpool 3x3 s2 same")
+    close(engine.maxpool_fwd(x, 2, 4, "valid")[0], torch.from_numpy(g["maxpool_2s4"]), what="maxpool 2x2 s4")
+    close(engine.maxpool_fwd(x, 2, 2, "valid")[0], torch.from_numpy(g["maxpool_2s2"]), what="maxpool 2x2 s2")
+    close(engine.avgpool_fwd(x, 4, 4), torch.from_numpy(g["avgpool_4"]), what="avgpool 4")
+    close(engine.upsample_fwd(x, 2), torch.from_numpy(g["up_2"]), what="upsample x2")
+    yt, yp = c("loss_y_true").float(), c("loss_y_pred")
+    for kind in range(3):
+        got = float(engine.loss_fwd(kind, yp, yt).item())
+        assert abs(got - float(g["loss_values"][kind])) <= 2e-6 * abs(float(g["loss_values"][kind])), (kind, got)
+    assert engine.confusion_counts(yp, yt).cpu().tolist() == g["confusion"].tolist()
+    p, m, v = c("adam_p0").clone(), torch.zeros(16).cuda(), torch.zeros(16).cuda()
+    for step in (1, 2, 3):
+        lr_t = 1e-3 * np.sqrt(1 - 0.999 ** step) / (1 - 0.9 ** step)
+        engine.adam_step(p, m, v, c("adam_g0") * step, lr_t)
+    close(p, torch.from_numpy(g["adam_p3"]), what="Adam params after 3 steps")
+    close(m, torch.from_numpy(g["adam_m3"]), what="Adam m")
+    close(v, torch.from_numpy(g["adam_v3"]), what="Adam v")

@@ -181,3 +181,41 @@ def test_res34_backbone_reference_known_answer():
     with torch.no_grad():
         M.res34_unet(P, torch.zeros(1, 32, 32, 3), backbone_only=True)
     assert P.count(True) == 22910272  # train_model/res34.py:305 "Trainable params: 22,910,272"
+
+
+# ---- golden fixtures (tests/golden/, generated by make_golden.py from this oracle; see its docstring) -------------
+def _load_generator():
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(__file__), "golden", "make_golden.py")
+    spec = importlib.util.spec_from_file_location("make_golden", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, os.path.dirname(path)
+
+
+def test_golden_ops_reproduced():
+    """The committed op-level vectors (TF 'same' asymmetry at stride 2, Conv2DTranspose, fused/non-fused BN moving
+    variance, pools, losses, confusion counts, Keras Adam, the LR schedule) are reproduced by the oracle exactly."""
+    gen, here = _load_generator()
+    stored = np.load(f"{here}/ops.npz")
+    fresh = gen.ops_fixture()
+    assert set(stored.files) == set(fresh.keys())
+    for k in stored.files:
+        np.testing.assert_allclose(np.asarray(fresh[k], dtype=np.float64), stored[k].astype(np.float64), rtol=1e-6, atol=1e-7,
+                                   err_msg=k)
+
+
+@pytest.mark.parametrize("name,fn,size,kw", [("scse", "scse_unet", 32, {}), ("hrnet", "hrnet", 32, {})],
+                         ids=["scse", "hrnet"])
+def test_golden_models_reproduced(name, fn, size, kw):
+    """Two of the five model fixtures are re-derived on CPU here (all five on the GPU box against the engine):
+    seeded weights, predict() probabilities, training loss and per-tensor gradient norms."""
+    gen, here = _load_generator()
+    stored = np.load(f"{here}/model_{name}.npz")
+    fresh = gen.model_fixture(name, fn, size, kw)
+    assert int(stored["n_tensors"]) == int(fresh["n_tensors"])
+    np.testing.assert_allclose(fresh["w_abs_sum"], stored["w_abs_sum"], rtol=1e-9)
+    np.testing.assert_allclose(fresh["probs"], stored["probs"], atol=2e-6)
+    np.testing.assert_allclose(fresh["train_loss"], stored["train_loss"], rtol=1e-9)
+    np.testing.assert_allclose(fresh["grad_norms"], stored["grad_norms"], rtol=1e-7, atol=1e-12)
