@@ -1025,7 +1025,12 @@ void plan_common(IgemmParams& p, bool vec, int bn) {
 
 int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
   IgemmParams p = p_in;
-  const int bn = pick_bn(p.M, p.Nout, num_cus);
+  int bn = pick_bn(p.M, p.Nout, num_cus);
+  {
+    // experiment switch: 128-wide tiles that give at most one tile per CU are halved (two workgroups per CU)
+    static const bool bn64 = getenv("SG_X6_BN64") != nullptr;
+    if (bn64 && bn == 128 && sg_cdiv(p.M, BM) * sg_cdiv(p.Nout, 128) <= (int64_t)num_cus) bn = 64;
+  }
   plan_common(p, true, bn);
   p.stagger = 0;
   {
