@@ -43,6 +43,7 @@ for s in $STAGES; do
     infer) run_stage infer 600 python scripts/bench_infer.py ;;
     census) run_stage census 600 python scripts/conv_census.py ;;
     nodes) run_stage nodes 600 python scripts/node_census.py ;;
+    bw) run_stage bw 600 python scripts/bw_census.py ;;
     *) echo "unknown stage $s" ;;
   esac
 done
