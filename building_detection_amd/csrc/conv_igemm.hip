@@ -1032,7 +1032,11 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
     if (bn64 && bn == 128 && sg_cdiv(p.M, BM) * sg_cdiv(p.Nout, 128) <= (int64_t)num_cus) bn = 64;
   }
   plan_common(p, true, bn);
-  p.stagger = 0;
+  {
+    static int il = -1;  // SG_X6_INTERLEAVE=0: staggered halves instead of the hand-interleaved step (A/B switch)
+    if (il < 0) il = getenv("SG_X6_INTERLEAVE") ? atoi(getenv("SG_X6_INTERLEAVE")) : 1;
+    p.stagger = il ? 2 : 0;
+  }
   {
     static int abl = -1;
     if (abl < 0) {
@@ -1041,13 +1045,13 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
     }
     p.ablate = abl;
   }
-  // Structure by tile count (measured, profiles/r01_ab_x6.txt): with at most one or two tiles per CU there is no
-  // second workgroup to overlap with, and the double-buffered one-workgroup-per-CU form wins (ASPP / SK forward:
-  // 1.00 -> 0.93 ms, 0.148 -> 0.138 ms); with many tiles the two-workgroups-per-CU single-buffer form does
-  // (ASPP dgrad 0.87 vs 0.97 ms).  SG_X6_VARIANT overrides.
+  // Structure by tile count (measured, profiles/r01_ab_x6.txt, r01_ab_x6_interleave.txt): up to ~4 tiles per CU
+  // the double-buffered one-workgroup-per-CU form with the hand-interleaved step wins (ASPP forward 1.02 -> 0.89
+  // ms, pointwise 728 forward 0.150 -> 0.137 ms); with many tiles the two-workgroups-per-CU single-buffer form
+  // does (ASPP dgrad 0.83 vs 0.94 ms, decoder 128->64 dgrad 0.92 vs 1.03 ms).  SG_X6_VARIANT overrides.
   const int64_t tiles = sg_cdiv(p.M, BM) * sg_cdiv(p.Nout, bn);
   int var = x6_variant();
-  if (var < 0) var = (tiles <= 2 * (int64_t)num_cus) ? 1 : 0;
+  if (var < 0) var = (tiles <= 4 * (int64_t)num_cus) ? 1 : 0;
   if (bn == 128) {
     switch (var) {
       case 0: return launch_x6<128, 2, 4, 1>(p, st);

@@ -276,6 +276,89 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     }
   };
 
+  // ---- hand-interleaved step (p.stagger == 2): the MFMAs of slab s with, woven into their gaps in a fixed order,
+  // the split + LDS store of slab s+1 (other buffer) and the loads of slab s+3 (same register set).  Every
+  // piece is fenced with sched_barrier, so the instruction stream is exactly: fragment reads, then per MFMA one
+  // small piece of staging.  An MFMA blocks the vector issue for 8 of its 32 cycles; the rest takes the piece.
+  auto prep_load = [&](int k0) {
+    const int tap = (int)fd_div((uint32_t)k0, p.fd_c);
+    if (tap != cur_tap) {  // uniform
+      cur_tap = tap;
+      uint32_t kh, kw;
+      fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+      const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
+#pragma unroll
+      for (int j = 0; j < NA; ++j) {
+        int64_t off;
+        const bool ok = gather_elem_addr(j, dh, dw, off) && tap < ntaps;
+        tap_voff[j] = ok ? (unsigned)off * 4u + 16u * kc : OOB;
+      }
+    }
+  };
+  auto fused_step = [&](int k0, auto SET, int sbuf, int cbuf) {
+    constexpr int S = decltype(SET)::value;
+    constexpr int NM = 12 * TM * TN;
+    const char* a_lane_b = a_lane + cbuf * BUFSZ;
+    const char* b_lane_b = b_lane + cbuf * BUFSZ;
+    bf16x8_t af[2][TM][3], bf[2][TN][3];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          af[ks][i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (pl * BM + 32 * i) * XPITCH + ks * 32);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bf[ks][j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (pl * BN + 32 * j) * XPITCH + ks * 32);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int soff_a = (k0 - cur_tap * p.C) * 4, soff_b = k0 * 2;
+    const bool kvalid = !ktail || (k0 + 4 * kc < p.K);
+    unsigned hs[NA][2], ms[NA][2], ls[NA][2];
+    constexpr int P_SPLIT = 2 * NA;            // pieces: 2*NA splits, NA A-writes, NB B-writes, NA + NB loads
+    constexpr int P_AW = P_SPLIT + NA, P_BW = P_AW + NB, P_LA = P_BW + NA, P_LB = P_LA + NB;
+    auto piece = [&](int w) {
+      if (w < P_SPLIT) {
+        const int j = w >> 1, hf = w & 1;
+        split3_pair(ra[S][j][2 * hf], ra[S][j][2 * hf + 1], hs[j][hf], ms[j][hf], ls[j][hf]);
+      } else if (w < P_AW) {
+        const int j = w - P_SPLIT;
+        char* dst = Ap + sbuf * BUFSZ + (r0 + RS * j) * XPITCH + kc * 8;
+        *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){hs[j][0], hs[j][1]};
+        *reinterpret_cast<u32x2_t*>(dst + BM * XPITCH) = (u32x2_t){ms[j][0], ms[j][1]};
+        *reinterpret_cast<u32x2_t*>(dst + 2 * BM * XPITCH) = (u32x2_t){ls[j][0], ls[j][1]};
+      } else if (w < P_BW) {
+        const int i = w - P_AW, idx = t + NT * i;
+        if ((NBC % NT == 0) || idx < NBC) {
+          const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
+          const int row = rem >> 2, c = rem & 3;
+          *reinterpret_cast<u32x4_t*>(Bp + sbuf * BUFSZ + (pl * BN + row) * XPITCH + c * 16) = rb[S][i];
+        }
+      } else if (w < P_LA) {
+        const int j = w - P_BW;
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
+        ra[S][j] = __builtin_bit_cast(f32x4, v);
+      } else if (w < P_LB) {
+        const int i = w - P_LA;
+        rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < NM; ++q) {
+      const int ks = q / (6 * TM * TN), r = q % (6 * TM * TN), tile = r / 6, term = r % 6;
+      const int i = tile / TN, j = tile % TN;
+      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PA_[term]], bf[ks][j][PB_[term]], acc[i][j], 0, 0, 0);
+      piece(q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int w = NM; w < P_LB; ++w) piece(w);  // narrow tiles have more pieces than MFMAs
+  };
+
   // ---- slab stream (padding-tap elimination and channel-block order as in igemm_conv_kernel) ---------------
   const int spt = p.C / BK;
   int nslab = (p.K + BK - 1) / BK;
@@ -351,6 +434,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
       store_AB(IC<0>{}, 0);
       load_AB(next_k0(), IC<0>{});  // slab 2 (the iterator repeats the last slab past the end: stored, never read)
       __syncthreads();
+      if (p.stagger == 2) {
+        for (int s = 0; s < nslab; s += 2) {
+          const int ka = next_k0();
+          prep_load(ka);
+          fused_step(ka, IC<1>{}, 1, 0);
+          __syncthreads();
+          if (s + 1 >= nslab) break;
+          const int kb = next_k0();
+          prep_load(kb);
+          fused_step(kb, IC<0>{}, 0, 1);
+          __syncthreads();
+        }
+      } else
       for (int s = 0; s < nslab; s += 2) {
         // slab s from buffer 0; slab s+1 (set 1) goes to buffer 1, set 1 then fetches slab s+3
         const int ka = next_k0();
