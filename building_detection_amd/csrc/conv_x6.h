@@ -300,20 +300,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     constexpr int NM = 12 * TM * TN;
     const char* a_lane_b = a_lane + cbuf * BUFSZ;
     const char* b_lane_b = b_lane + cbuf * BUFSZ;
+    // fragment reads in the order the MFMAs consume them (a3,b1 | a1,b3 | a2,b2 of the first tile, ...): LDS
+    // returns in order, so the first MFMA waits for two reads, not for all eighteen
     bf16x8_t af[2][TM][3], bf[2][TN][3];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          af[ks][i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (pl * BM + 32 * i) * XPITCH + ks * 32);
+        for (int u = 0; u < 3; ++u) {
+          constexpr int APL[3] = {2, 0, 1}, BPL[3] = {0, 2, 1};
+          af[ks][i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (APL[u] * BM + 32 * i) * XPITCH + ks * 32);
+          if (i == 0) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          bf[ks][j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (pl * BN + 32 * j) * XPITCH + ks * 32);
-    }
+            for (int j = 0; j < TN; ++j)
+              bf[ks][j][BPL[u]] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (BPL[u] * BN + 32 * j) * XPITCH + ks * 32);
+          }
+          if (ks == 0 && i == 0) __builtin_amdgcn_sched_barrier(0);  // keep the first tile's operands first in the queue
+        }
     __builtin_amdgcn_sched_barrier(0);
     const int soff_a = (k0 - cur_tap * p.C) * 4, soff_b = k0 * 2;
     const bool kvalid = !ktail || (k0 + 4 * kc < p.K);
