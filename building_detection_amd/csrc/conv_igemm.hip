@@ -1170,6 +1170,14 @@ int dispatch_wgrad(const WgradParams& p_in, int S, bool vec, hipStream_t st) {
   const int var = conv_variant() & 3;
   p.stagger = (conv_variant() >> 2) & 1;
   if (wgrad_x6_ok(p, vec)) {
+    {
+      static int abl = -1;
+      if (abl < 0) {
+        const char* e = getenv("SG_X6_ABLATE");
+        abl = e ? atoi(e) & 7 : 0;
+      }
+      p.stagger = abl;  // the x6 wgrad kernel has no stagger; the field carries the ablation mask
+    }
     if (bn == 128) return launch_wgrad_x6<128, 2, 4>(p, S, st);
     if (bn == 64) return launch_wgrad_x6<64, 4, 2>(p, S, st);
     return launch_wgrad_x6<32, 4, 1>(p, S, st);

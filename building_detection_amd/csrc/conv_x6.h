@@ -777,13 +777,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
   auto slab_of = [&](int i) -> int { return use_list ? slist[1 + i] : slab_begin + i; };
   const int lasti = nslab - 1;
   if (nslab > 0) {
+    // p.stagger carries SG_X6_ABLATE here (timing-only diagnostics, results wrong): 1 = no global loads in the loop,
+    // 2 = no split + LDS store + barriers, 4 = no fragment reads + MFMAs
+    const bool do_ld = !(p.stagger & 1), do_st = !(p.stagger & 2), do_mm = !(p.stagger & 4);
     load_AB(slab_of(0) * BK);
     for (int s = 0; s < nslab; ++s) {
-      __syncthreads();
-      store_AB();
-      __syncthreads();
-      load_AB(slab_of(s < lasti ? s + 1 : lasti) * BK);
-      compute();
+      if (do_st) {
+        __syncthreads();
+        store_AB();
+        __syncthreads();
+      }
+      const int pn = slab_of(s < lasti ? s + 1 : lasti) * BK;
+      if (do_ld) load_AB(pn);
+      if (do_mm) compute();
     }
   }
 
