@@ -1178,9 +1178,15 @@ int dispatch_wgrad(const WgradParams& p_in, int S, bool vec, hipStream_t st) {
       }
       p.stagger = abl;  // the x6 wgrad kernel has no stagger; the field carries the ablation mask
     }
-    if (bn == 128) return launch_wgrad_x6<128, 2, 4>(p, S, st);
-    if (bn == 64) return launch_wgrad_x6<64, 4, 2>(p, S, st);
-    return launch_wgrad_x6<32, 4, 1>(p, S, st);
+    static const int wpf2 = getenv("SG_X6_WGRAD_PF2") ? atoi(getenv("SG_X6_WGRAD_PF2")) : 0;  // A/B switch
+    if (wpf2) {
+      if (bn == 128) return launch_wgrad_x6<128, 2, 4, 2>(p, S, st);
+      if (bn == 64) return launch_wgrad_x6<64, 4, 2, 2>(p, S, st);
+      return launch_wgrad_x6<32, 4, 1, 2>(p, S, st);
+    }
+    if (bn == 128) return launch_wgrad_x6<128, 2, 4, 1>(p, S, st);
+    if (bn == 64) return launch_wgrad_x6<64, 4, 2, 1>(p, S, st);
+    return launch_wgrad_x6<32, 4, 1, 1>(p, S, st);
   }
   if (!vec) {
     if (bn == 128) return launch_wgrad<128, 2, 4, 1, false>(p, S, st);

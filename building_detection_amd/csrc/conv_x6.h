@@ -567,8 +567,11 @@ struct X6WPitch {
   static constexpr int B = (BN == 128) ? 2 * BN + 64 : 192;   // 320 / 192 / 192
 };
 
-template <int BN, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel(const WgradParams p) {
+// PF == 1: single LDS buffer, two barriers per slab, two workgroups per CU.  PF == 2: one workgroup per CU, LDS
+// double-buffered, two register sets and the hand-interleaved step of conv_x6_kernel (the staging of slab s+1
+// and the loads of slab s+3 woven into the MFMA gaps of slab s).
+template <int BN, int WGM, int WGN, int PF>
+__global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM * WGN / 2) void wgrad_x6_kernel(const WgradParams p) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -580,9 +583,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
   static_assert(NA >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ap = smem;                     // [3][BK][PA]
-  char* Bp = Ap + 3 * BK * PA;         // [3][BK][PB]
-  int* slist = reinterpret_cast<int*>(Bp + 3 * BK * PB);  // [1 + 1024] + flags[1024]
+  constexpr int BUFSZ = 3 * BK * (PA + PB);  // one LDS buffer: A' planes then B planes
+  char* Ap = smem;                     // [PF buffers] x { A' [3][BK][PA], B [3][BK][PB] }
+  char* Bp = Ap + 3 * BK * PA;
+  int* slist = reinterpret_cast<int*>(smem + PF * BUFSZ);  // [1 + 1024] + flags[1024]
 
   const int t = threadIdx.x;
   const uint32_t ntn = (p.Cout + BN - 1) / BN;
@@ -643,8 +647,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
     b_voff[i] = (idx < NBC && (n0 + 4 * c4) < p.Cout) ? (unsigned)(kr * p.y_ld + n0 + 4 * c4) * 4u : OOB;
   }
 
-  f32x4 ra[NA], rb[NB];
-  auto load_AB = [&](int p0) {
+  f32x4 ra[PF][NA], rb[PF][NB];
+  auto load_AB = [&](int p0, auto SET) {
+    constexpr int S = decltype(SET)::value;
     uint32_t q, ow0, n_, oh;
     fd_divmod((uint32_t)p0, p.fd_ow, q, ow0);
     fd_divmod(q, p.fd_oh, n_, oh);
@@ -656,23 +661,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
     for (int j = 0; j < NA; ++j) {
       const bool v = row_ok && ((unsigned)(col0 + PS * j) < (unsigned)p.W);
       const u32x4_t val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a, 0);
-      ra[j] = __builtin_bit_cast(f32x4, val);
+      ra[S][j] = __builtin_bit_cast(f32x4, val);
     }
     const int soff_b = p0 * p.y_ld * 4;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const u32x4_t val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b, 0);
-      rb[i] = __builtin_bit_cast(f32x4, val);
+      rb[S][i] = __builtin_bit_cast(f32x4, val);
     }
   };
 
-  auto store_AB = [&]() {
+  auto store_AB = [&](auto SET, int buf) {
+    constexpr int S = decltype(SET)::value;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       unsigned h0, m0_, l0, h1, m1, l1;
-      split3_pair(ra[j][0], ra[j][1], h0, m0_, l0);
-      split3_pair(ra[j][2], ra[j][3], h1, m1, l1);
-      char* dst = Ap + (pr0 + PS * j) * PA + rc * 8;
+      split3_pair(ra[S][j][0], ra[S][j][1], h0, m0_, l0);
+      split3_pair(ra[S][j][2], ra[S][j][3], h1, m1, l1);
+      char* dst = Ap + buf * BUFSZ + (pr0 + PS * j) * PA + rc * 8;
       *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
       *reinterpret_cast<u32x2_t*>(dst + BK * PA) = (u32x2_t){m0_, m1};
       *reinterpret_cast<u32x2_t*>(dst + 2 * BK * PA) = (u32x2_t){l0, l1};
@@ -683,9 +689,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
       if (idx < NBC) {
         const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
         unsigned h0, m0_, l0, h1, m1, l1;
-        split3_pair(rb[i][0], rb[i][1], h0, m0_, l0);
-        split3_pair(rb[i][2], rb[i][3], h1, m1, l1);
-        char* dst = Bp + kr * PB + c4 * 8;
+        split3_pair(rb[S][i][0], rb[S][i][1], h0, m0_, l0);
+        split3_pair(rb[S][i][2], rb[S][i][3], h1, m1, l1);
+        char* dst = Bp + buf * BUFSZ + kr * PB + c4 * 8;
         *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
         *reinterpret_cast<u32x2_t*>(dst + BK * PB) = (u32x2_t){m0_, m1};
         *reinterpret_cast<u32x2_t*>(dst + 2 * BK * PB) = (u32x2_t){l0, l1};
@@ -710,7 +716,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
   const char* a_lane = Ap + tr_row * PA + (wm + tr_col) * 2;
   const char* b_lane = Bp + tr_row * PB + (wn + tr_col) * 2;
 
-  auto compute = [&]() {
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t af[TM][3], bf[TN][3];
@@ -718,14 +724,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-          const char* a = a_lane + (pl * BK + 16 * ks) * PA + 64 * i;
+          const char* a = a_lane + buf * BUFSZ + (pl * BK + 16 * ks) * PA + 64 * i;
           af[i][pl] = tr_frag(a, a + 4 * PA);
         }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl) {
-          const char* b = b_lane + (pl * BK + 16 * ks) * PB + 64 * j;
+          const char* b = b_lane + buf * BUFSZ + (pl * BK + 16 * ks) * PB + 64 * j;
           bf[j][pl] = tr_frag(b, b + 4 * PB);
         }
 #pragma unroll
@@ -779,17 +785,111 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
   if (nslab > 0) {
     // p.stagger carries SG_X6_ABLATE here (timing-only diagnostics, results wrong): 1 = no global loads in the loop,
     // 2 = no split + LDS store + barriers, 4 = no fragment reads + MFMAs
-    const bool do_ld = !(p.stagger & 1), do_st = !(p.stagger & 2), do_mm = !(p.stagger & 4);
-    load_AB(slab_of(0) * BK);
-    for (int s = 0; s < nslab; ++s) {
-      if (do_st) {
+    if constexpr (PF == 1) {
+      const bool do_ld = !(p.stagger & 1), do_st = !(p.stagger & 2), do_mm = !(p.stagger & 4);
+      load_AB(slab_of(0) * BK, IC<0>{});
+      for (int s = 0; s < nslab; ++s) {
+        if (do_st) {
+          __syncthreads();
+          store_AB(IC<0>{}, 0);
+          __syncthreads();
+        }
+        const int pn = slab_of(s < lasti ? s + 1 : lasti) * BK;
+        if (do_ld) load_AB(pn, IC<0>{});
+        if (do_mm) compute(0);
+      }
+    } else {
+      // fused step: MFMAs of the slab in buffer cbuf with, one piece per MFMA, the split + store of register set S
+      // into buffer sbuf and the loads of slab p0 into the same set
+      auto fused_step = [&](int p0, auto SET, int sbuf, int cbuf) {
+        constexpr int S = decltype(SET)::value;
+        constexpr int NM = 12 * TM * TN;
+        bf16x8_t af[2][TM][3], bf[2][TN][3];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+              constexpr int APL[3] = {2, 0, 1}, BPL[3] = {0, 2, 1};
+              const char* a = a_lane + cbuf * BUFSZ + (APL[u] * BK + 16 * ks) * PA + 64 * i;
+              af[ks][i][APL[u]] = tr_frag(a, a + 4 * PA);
+              if (i == 0) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                  const char* b = b_lane + cbuf * BUFSZ + (BPL[u] * BK + 16 * ks) * PB + 64 * j;
+                  bf[ks][j][BPL[u]] = tr_frag(b, b + 4 * PB);
+                }
+              }
+              if (ks == 0 && i == 0) __builtin_amdgcn_sched_barrier(0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        uint32_t q_, ow0, n_, oh;
+        fd_divmod((uint32_t)p0, p.fd_ow, q_, ow0);
+        fd_divmod(q_, p.fd_oh, n_, oh);
+        const bool row_ok = (unsigned)((int)oh + s_dh) < (unsigned)p.H;
+        const int soff_a = p0 * p.x_ld * 4, soff_b = p0 * p.y_ld * 4;
+        const int col0 = (int)ow0 + s_dw + pr0;
+        unsigned ha[NA][2], ma[NA][2], la[NA][2], hb[NB][2], mb[NB][2], lb[NB][2];
+        constexpr int P_SA = 2 * NA, P_WA = P_SA + NA, P_SB = P_WA + 2 * NB, P_WB = P_SB + NB, P_LA = P_WB + NA, P_LB = P_LA + NB;
+        auto piece = [&](int w) {
+          if (w < P_SA) {
+            const int j = w >> 1, hf = w & 1;
+            split3_pair(ra[S][j][2 * hf], ra[S][j][2 * hf + 1], ha[j][hf], ma[j][hf], la[j][hf]);
+          } else if (w < P_WA) {
+            const int j = w - P_SA;
+            char* dst = Ap + sbuf * BUFSZ + (pr0 + PS * j) * PA + rc * 8;
+            *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){ha[j][0], ha[j][1]};
+            *reinterpret_cast<u32x2_t*>(dst + BK * PA) = (u32x2_t){ma[j][0], ma[j][1]};
+            *reinterpret_cast<u32x2_t*>(dst + 2 * BK * PA) = (u32x2_t){la[j][0], la[j][1]};
+          } else if (w < P_SB) {
+            const int i = (w - P_WA) >> 1, hf = (w - P_WA) & 1;
+            split3_pair(rb[S][i][2 * hf], rb[S][i][2 * hf + 1], hb[i][hf], mb[i][hf], lb[i][hf]);
+          } else if (w < P_WB) {
+            const int i = w - P_SB, idx = t + NT * i;
+            if ((NBC % NT == 0) || idx < NBC) {
+              const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
+              char* dst = Bp + sbuf * BUFSZ + kr * PB + c4 * 8;
+              *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){hb[i][0], hb[i][1]};
+              *reinterpret_cast<u32x2_t*>(dst + BK * PB) = (u32x2_t){mb[i][0], mb[i][1]};
+              *reinterpret_cast<u32x2_t*>(dst + 2 * BK * PB) = (u32x2_t){lb[i][0], lb[i][1]};
+            }
+          } else if (w < P_LA) {
+            const int j = w - P_WB;
+            const bool v = row_ok && ((unsigned)(col0 + PS * j) < (unsigned)p.W);
+            const u32x4_t val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a, 0);
+            ra[S][j] = __builtin_bit_cast(f32x4, val);
+          } else if (w < P_LB) {
+            const int i = w - P_LA;
+            const u32x4_t val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b, 0);
+            rb[S][i] = __builtin_bit_cast(f32x4, val);
+          }
+        };
+#pragma unroll
+        for (int q = 0; q < NM; ++q) {
+          const int ks = q / (6 * TM * TN), r = q % (6 * TM * TN), tile = r / 6, term = r % 6;
+          const int i = tile / TN, j = tile % TN;
+          constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PA_[term]], bf[ks][j][PB_[term]], acc[i][j], 0, 0, 0);
+          piece(q);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int w = NM; w < P_LB; ++w) piece(w);
+      };
+      auto slab_at = [&](int i) -> int { return slab_of(i < lasti ? i : lasti) * BK; };
+      load_AB(slab_at(0), IC<0>{});
+      load_AB(slab_at(1), IC<1>{});
+      store_AB(IC<0>{}, 0);
+      load_AB(slab_at(2), IC<0>{});
+      __syncthreads();
+      for (int s = 0; s < nslab; s += 2) {
+        fused_step(slab_at(s + 3), IC<1>{}, 1, 0);
         __syncthreads();
-        store_AB();
+        if (s + 1 >= nslab) break;
+        fused_step(slab_at(s + 4), IC<0>{}, 0, 1);
         __syncthreads();
       }
-      const int pn = slab_of(s < lasti ? s + 1 : lasti) * BK;
-      if (do_ld) load_AB(pn);
-      if (do_mm) compute();
     }
   }
 
@@ -808,17 +908,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void wgrad_x6_kernel
   }
 }
 
-template <int BN, int WGM, int WGN>
+template <int BN, int WGM, int WGN, int PF>
 int launch_wgrad_x6(const WgradParams& p, int S, hipStream_t st) {
-  constexpr size_t lds = (size_t)3 * BK * (X6WPitch<BN>::A + X6WPitch<BN>::B) + (2 * 1024 + 4) * sizeof(int);
+  constexpr size_t lds = (size_t)PF * 3 * BK * (X6WPitch<BN>::A + X6WPitch<BN>::B) + (2 * 1024 + 4) * sizeof(int);
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(wgrad_x6_kernel<BN, WGM, WGN>, lds);
+    int rc = set_dyn_lds(wgrad_x6_kernel<BN, WGM, WGN, PF>, lds);
     if (rc) return rc;
     attr_done = true;
   }
   const int64_t tiles = sg_cdiv(p.K, BM) * sg_cdiv(p.Cout, BN);
-  hipLaunchKernelGGL((wgrad_x6_kernel<BN, WGM, WGN>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((wgrad_x6_kernel<BN, WGM, WGN, PF>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("wgrad_x6_kernel");
   return 0;
 }
