@@ -38,6 +38,7 @@ _pp = C.POINTER(C.c_void_p)
 _SIGNATURES = {
     "sg_abi_version": (_i, []),
     "sg_last_error": (C.c_char_p, []),
+    "sg_set_conv_x6": (_i, [_i]),
     "sg_create": (_i, [_i, _pp]),
     "sg_destroy": (_i, [_vp]),
     "sg_num_cus": (_i, [_vp]),

@@ -1461,6 +1461,12 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
 
 extern "C" {
 
+int sg_set_conv_x6(int on) {
+  const int prev = x6_enabled() ? 1 : 0;
+  g_x6_enabled = on ? 1 : 0;
+  return prev;
+}
+
 size_t sg_conv2d_fwd_ws_bytes(const sg_conv_desc* d) {
   if (!d) return 0;
   return x6_planes_bytes(d->KH * d->KW * d->Cin, d->Cout) + 256;

@@ -525,13 +525,13 @@ inline int x6_variant() {
 }
 
 // A/B switch: SG_CONV_X6=0 keeps every convolution on the native fp32 MFMA kernel.
+int g_x6_enabled = -1;  // -1: not yet read from the environment; set by sg_set_conv_x6()
 inline bool x6_enabled() {
-  static int v = -1;
-  if (v < 0) {
+  if (g_x6_enabled < 0) {
     const char* e = getenv("SG_CONV_X6");
-    v = e ? (atoi(e) != 0) : 1;
+    g_x6_enabled = e ? (atoi(e) != 0) : 1;
   }
-  return v != 0;
+  return g_x6_enabled != 0;
 }
 
 // Can this launch take the x6 kernel?  (UT gather: every 32-deep slab inside one tap; 16-byte channel runs.)

@@ -118,6 +118,10 @@ class Engine:
         return torch.zeros(*shape, dtype=torch.float32, device=self.device)
 
     # ---------------------------------------------------------------------------------------------- conv
+    def set_conv_x6(self, on: bool) -> bool:
+        """Process-wide: run qualifying convolutions as six bf16 MFMA passes (True, default) or on the native fp32 MFMA."""
+        return bool(self.lib.sg_set_conv_x6(int(bool(on))))
+
     @staticmethod
     def conv_desc(xshape, cout, kh, kw, stride=1, dilation=1, padding="same", x_ld=0, y_ld=0) -> ConvDesc:
         n, h, w, cin = xshape

@@ -55,6 +55,10 @@ int sg_create(int device, sg_ctx** out);
 int sg_destroy(sg_ctx* ctx);
 /* number of compute units of the ctx's device (for host-side split heuristics) */
 int sg_num_cus(const sg_ctx* ctx);
+/* Process-wide switch of the "x6" convolution path (fp32 products as six bf16 MFMA passes, csrc/conv_x6.h):
+ * on = 1 (default, or SG_CONV_X6 in the environment), 0 = every convolution on the native fp32 MFMA kernels.
+ * Returns the previous value.  Lets a caller (and the parity tests) run both paths on the same inputs. */
+int sg_set_conv_x6(int on);
 
 /* ------------------------------------------------------------------------------------------------ conv
  * Geometry of a forward convolution  y[N,Ho,Wo,Cout] = conv(x[N,H,W,Cin], w[KH,KW,Cin,Cout]).

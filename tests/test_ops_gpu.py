@@ -455,3 +455,46 @@ def test_golden_ops(engine):
     close(p, torch.from_numpy(g["adam_p3"]), what="Adam params after 3 steps")
     close(m, torch.from_numpy(g["adam_m3"]), what="Adam m")
     close(v, torch.from_numpy(g["adam_v3"]), what="Adam v")
+
+
+X6_CASES = [
+    # n, h, w, cin, cout, k, dil
+    (2, 32, 32, 1024, 256, 3, 6),    # ASPP-like: K = 9216
+    (4, 32, 32, 728, 728, 1, 1),     # middle-flow pointwise, ragged K and N
+    (1, 64, 64, 64, 32, 3, 1),       # entry-flow: tile spanning two taps in wgrad
+]
+
+
+@pytest.mark.parametrize("case", X6_CASES, ids=["aspp", "pw728", "c64"])
+def test_x6_at_least_as_accurate_as_native_fp32_mfma(engine, case):
+    """Both convolution paths on the same inputs against an fp64 reference: the six-pass bf16 split ("x6") must be
+    no less accurate than the native fp32 MFMA kernels it replaces (and both within the 2e-5 of the op tests)."""
+    n, h, w, cin, cout, k, dil = case
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = rnd(g, n, h, w, cin)
+    x = x * torch.exp(2 * rnd(g, n, h, w, cin))              # activations with a few orders of magnitude of range
+    wt = rnd(g, k, k, cin, cout) * (1.0 / np.sqrt(k * k * cin))
+    xr, wr = x.double().requires_grad_(), wt.double().requires_grad_()
+    yr = T.conv2d(xr, wr, None, 1, dil, "same")
+    dy = rnd(g, *yr.shape)
+    yr.backward(dy.double())
+    refs = {"fwd": yr.detach(), "dgrad": xr.grad, "wgrad": wr.grad}
+    xd, wd, dyd = x.cuda(), wt.cuda(), dy.cuda()
+    d = engine.conv_desc(x.shape, cout, k, k, 1, dil, "same")
+    errs = {}
+    prev = engine.set_conv_x6(True)
+    try:
+        for on in (True, False):
+            engine.set_conv_x6(on)
+            got = {"fwd": engine.conv2d_fwd(xd, wd, None, 1, dil, "same"), "dgrad": engine.conv2d_dgrad(dyd, wd, d),
+                   "wgrad": engine.conv2d_wgrad(xd, dyd, d, want_bias=False)[0]}
+            for key, val in got.items():
+                ref = refs[key]
+                errs[(on, key)] = float((val.cpu().double() - ref).abs().max() / ref.abs().max())
+    finally:
+        engine.set_conv_x6(prev)
+    for key in ("fwd", "dgrad", "wgrad"):
+        ex, en = errs[(True, key)], errs[(False, key)]
+        print(f"{key}: max rel err x6 {ex:.2e}  native fp32 MFMA {en:.2e}")
+        assert ex <= 2e-5 and en <= 2e-5
+        assert ex <= 1.5 * en + 2e-8, (key, ex, en)
