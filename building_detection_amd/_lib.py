@@ -58,7 +58,7 @@ _SIGNATURES = {
     "sg_dense_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _i]),
     "sg_bn_ws_bytes": (_sz, [_vp, _i64, _i]),
     "sg_bn_train_fwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _sz]),
-    "sg_bn_train_bwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "sg_bn_train_bwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "sg_bn_infer": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i]),
     "sg_act_fwd": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),
     "sg_act_bwd": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _i]),

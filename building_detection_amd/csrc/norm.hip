@@ -51,6 +51,8 @@ struct BnBwdOp {
   const float* __restrict__ dy;
   const float* __restrict__ mean;
   const float* __restrict__ invstd;
+  const float* __restrict__ gamma;  // with beta: the ReLU mask is recomputed from x instead of read from y
+  const float* __restrict__ beta;
   float* dgamma;
   float* dbeta;
   int C;
@@ -64,10 +66,18 @@ struct BnBwdOp {
     ldv<V>(mean + c, mv);
     ldv<V>(invstd + c, iv);
     if (relu) {
-      float yv[V];
-      ldv<V>(y + r * C + c, yv);
+      if (beta) {
+        float gm[V], bt[V];
+        ldv<V>(gamma + c, gm);
+        ldv<V>(beta + c, bt);
 #pragma unroll
-      for (int i = 0; i < V; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+        for (int i = 0; i < V; ++i) gv[i] = fmaf((xv[i] - mv[i]) * iv[i], gm[i], bt[i]) > 0.f ? gv[i] : 0.f;
+      } else {
+        float yv[V];
+        ldv<V>(y + r * C + c, yv);
+#pragma unroll
+        for (int i = 0; i < V; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
+      }
     }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -101,7 +111,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
 #pragma unroll
     for (int k = 0; k < V; ++k) {
       const float is = infer ? rsqrtf(iv[k] + eps) : iv[k];
-      float t = (xv[k] - mv[k]) * is * gv[k] + bv[k];
+      float t = fmaf((xv[k] - mv[k]) * is, gv[k], bv[k]);  // the backward re-evaluates exactly this for the ReLU mask
       if (relu) t = fmaxf(t, 0.f);
       o[k] = t;
     }
@@ -113,8 +123,9 @@ template <int V>
 __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
                                     const float* __restrict__ dy, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                    const float* __restrict__ dgamma, const float* __restrict__ dbeta,
-                                    float* __restrict__ dx, int64_t rows, int C, int relu, FastDiv fd_cv) {
+                                    const float* __restrict__ beta, const float* __restrict__ dgamma,
+                                    const float* __restrict__ dbeta, float* __restrict__ dx, int64_t rows, int C, int relu,
+                                    FastDiv fd_cv) {
   const uint32_t cv = C / V;
   const uint32_t total = (uint32_t)(rows * cv);
   const uint32_t stride = gridDim.x * blockDim.x;
@@ -131,10 +142,17 @@ __global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __
     ldv<V>(dgamma + c, dg);
     ldv<V>(dbeta + c, db);
     if (relu) {
-      float yv[V];
-      ldv<V>(y + r * C + c, yv);
+      if (beta) {
+        float bt[V];
+        ldv<V>(beta + c, bt);
 #pragma unroll
-      for (int k = 0; k < V; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+        for (int k = 0; k < V; ++k) gv[k] = fmaf((xv[k] - mv[k]) * iv[k], gam[k], bt[k]) > 0.f ? gv[k] : 0.f;
+      } else {
+        float yv[V];
+        ldv<V>(y + r * C + c, yv);
+#pragma unroll
+        for (int k = 0; k < V; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+      }
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -199,12 +217,12 @@ int sg_bn_train_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
 }
 
 int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* y,
-                    const void* dy, const void* gamma, const void* save_mean, const void* save_invstd, void* dx,
-                    void* dgamma, void* dbeta, int relu, void* ws, size_t ws_bytes) {
+                    const void* dy, const void* gamma, const void* beta, const void* save_mean, const void* save_invstd,
+                    void* dx, void* dgamma, void* dbeta, int relu, void* ws, size_t ws_bytes) {
   SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_train_bwd: bad ctx/dtype");
   SG_CHECK_ARG(rows > 0 && C > 0 && x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta,
                "sg_bn_train_bwd: bad argument");
-  SG_CHECK_ARG(!relu || y, "sg_bn_train_bwd: relu set but y is null");
+  SG_CHECK_ARG(!relu || y || beta, "sg_bn_train_bwd: relu set but neither y nor beta given");
   SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_train_bwd: tensor exceeds 2^31 elements");
   const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy) && sg_aligned16(dx) && (!relu || sg_aligned16(y));
   const SegPlan pl = seg_plan<2>(ctx->num_cus, 1, rows, C, vec);
@@ -216,6 +234,7 @@ int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
   BnBwdOp op;
   op.x = (const float*)x; op.y = (const float*)y; op.dy = (const float*)dy;
   op.mean = (const float*)save_mean; op.invstd = (const float*)save_invstd;
+  op.gamma = (const float*)gamma; op.beta = (const float*)beta;
   op.dgamma = (float*)dgamma; op.dbeta = (float*)dbeta; op.C = C; op.relu = relu;
   int rc = seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_bwd_reduce");
   if (rc) return rc;
@@ -224,11 +243,13 @@ int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
   if (vec)
     hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)y,
                        (const float*)dy, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
-                       (const float*)dgamma, (const float*)dbeta, (float*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));
+                       (const float*)beta, (const float*)dgamma, (const float*)dbeta, (float*)dx, rows, C, relu,
+                       make_fastdiv((uint32_t)(C / V)));
   else
     hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)y,
                        (const float*)dy, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
-                       (const float*)dgamma, (const float*)dbeta, (float*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));
+                       (const float*)beta, (const float*)dgamma, (const float*)dbeta, (float*)dx, rows, C, relu,
+                       make_fastdiv((uint32_t)(C / V)));
   SG_LAUNCH_CHECK("bn_bwd_apply_kernel");
   return 0;
 }

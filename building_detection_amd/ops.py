@@ -210,7 +210,7 @@ class Engine:
                                        int(x.dim() == 4), wsp, wsn), "sg_bn_train_fwd")
         return y, mean, invstd
 
-    def bn_train_bwd(self, x, y, dy, gamma, mean, invstd, relu=False, out=None, dgamma=None, dbeta=None):
+    def bn_train_bwd(self, x, y, dy, gamma, mean, invstd, relu=False, out=None, dgamma=None, dbeta=None, beta=None):
         c = x.shape[-1]
         rows = x.numel() // c
         dx = out if out is not None else torch.empty_like(x)
@@ -218,7 +218,8 @@ class Engine:
         dbeta = dbeta if dbeta is not None else self.empty(c)
         wsp, wsn = self.ws(self.lib.sg_bn_ws_bytes(self.h, rows, c))
         check(self.lib.sg_bn_train_bwd(self.h, self.stream, SG_F32, rows, c, _ptr(x), _ptr(y), _ptr(dy), _ptr(gamma),
-                                       _ptr(mean), _ptr(invstd), _ptr(dx), _ptr(dgamma), _ptr(dbeta), int(relu), wsp, wsn),
+                                       _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(dx), _ptr(dgamma), _ptr(dbeta), int(relu),
+                                       wsp, wsn),
               "sg_bn_train_bwd")
         return dx, dgamma, dbeta
 

@@ -92,13 +92,16 @@ int sg_conv2d_fwd_ws(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d
 /* Conv2D input gradient dx[N,H,W,Cin] (pixel stride d->x_ld) from dy[N,Ho,Wo,Cout] (pixel stride d->y_ld).
  * The same routine is Conv2DTranspose *forward* (y_T = dgrad of the SAME conv that maps the upsampled grid
  * back): v3plus.py:328,335, scse.py:71-89, res34.py:144 — hence the optional epilogue
- * (bias has d->Cin entries here).  ws: sg_conv2d_dgrad_ws_bytes(d) bytes (transposed kernel). */
+ * (bias has d->Cin entries here).  ws: sg_conv2d_dgrad_ws_bytes(d) bytes (the per-tap transposed kernel of the
+ * fp32 path, or its three bf16 planes for the x6 path, whichever is larger). */
 size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d);
 int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
                     const void* w, const void* bias, void* dx, int flags, void* ws, size_t ws_bytes);
 
 /* Conv2D kernel gradient dw[KH,KW,Cin,Cout] (and dbias[Cout] if non-null) = sum over N*Ho*Wo.
- * Deterministic split-K: partial slabs in ws, then a fixed-order reduce.  ws: sg_conv2d_wgrad_ws_bytes. */
+ * Deterministic split-K: partial slabs in ws, then a fixed-order reduce (no float atomics: bit-reproducible run
+ * to run).  Runs as six bf16 MFMA passes (x6) when the geometry is stride 1 / "same" / W % 32 == 0, else on the
+ * fp32 MFMA; 1x1 kernels with Cout <= 4 take a streaming reduction.  ws: sg_conv2d_wgrad_ws_bytes. */
 size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d);
 int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
                     const void* dy, void* dw, void* dbias, void* ws, size_t ws_bytes);
@@ -138,8 +141,11 @@ int sg_bn_train_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
                     const void* gamma, const void* beta, void* moving_mean, void* moving_var, void* y,
                     void* save_mean, void* save_invstd, float momentum, float eps, int relu,
                     int unbiased_update, void* ws, size_t ws_bytes);
+/* With a fused ReLU the backward needs the mask [y > 0].  Given beta it is recomputed from x (the same
+ * fmaf((x-mean)*invstd, gamma, beta) the forward evaluated), which saves reading y in both passes; with
+ * beta == NULL the mask is read from y. */
 int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x,
-                    const void* y, const void* dy, const void* gamma, const void* save_mean,
+                    const void* y, const void* dy, const void* gamma, const void* beta, const void* save_mean,
                     const void* save_invstd, void* dx, void* dgamma, void* dbeta, int relu, void* ws,
                     size_t ws_bytes);
 int sg_bn_infer(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x,

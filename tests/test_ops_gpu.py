@@ -186,6 +186,10 @@ def test_batchnorm(engine, shape, relu):
     close(dx, xr.grad, rtol=1e-4, what="bn dx")
     close(dg, gr.grad, rtol=1e-4, what="bn dgamma")
     close(db, br.grad, rtol=1e-4, what="bn dbeta")
+    # the same backward with the ReLU mask recomputed from x (beta given) must be bit-identical to the y-mask form
+    dx2, dg2, db2 = engine.bn_train_bwd(x.cuda(), None if relu else y, dy.cuda(), gamma.cuda(), mean, invstd, relu=relu,
+                                        beta=beta.cuda())
+    assert torch.equal(dx, dx2) and torch.equal(dg, dg2) and torch.equal(db, db2)
     yi, _, _ = T.batch_norm(x, gamma, beta, mm, mv, training=False)
     yg = engine.bn_infer(x.cuda(), gamma.cuda(), beta.cuda(), mm.cuda(), mv.cuda(), relu=relu)
     close(yg, torch.relu(yi) if relu else yi, what="bn infer")
