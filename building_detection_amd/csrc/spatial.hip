@@ -144,6 +144,9 @@ struct DwRunParams {
   FastDiv fd_rpr, fd_h;
 };
 
+// RR output rows per run: the (RR + 2) x 6 input window is loaded once for RR x 4 outputs - 4.5 loads per output
+// at RR = 1, 2.25 at RR = 4 (fd_h divides by H / RR then)
+template <int RR>
 __global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams p) {
   const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
   if (c >= p.C) return;
@@ -152,16 +155,18 @@ __global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams p) {
   for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (p.flip ? 8 - t : t) * p.C + c);
   const int64_t stride = (int64_t)gridDim.y * 4;
   for (int64_t run = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); run < p.nruns; run += stride) {
-    uint32_t rowi, q, n, oh;
+    uint32_t rowi, q, n, ohb;
     fd_divmod((uint32_t)run, p.fd_rpr, rowi, q);
-    fd_divmod(rowi, p.fd_h, n, oh);
-    const int ow0 = (int)q * 4;
-    f32x4 acc[4];
+    fd_divmod(rowi, p.fd_h, n, ohb);
+    const int ow0 = (int)q * 4, oh0 = (int)ohb * RR;
+    f32x4 acc[RR][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int rr = 0; rr < RR; ++rr)
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int ih = (int)oh - 1 + a;
+      for (int k = 0; k < 4; ++k) acc[rr][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < RR + 2; ++a) {
+      const int ih = oh0 - 1 + a;
       if ((unsigned)ih >= (unsigned)p.H) continue;
       const float* rowp = p.in + ((int64_t)(n * p.H + ih) * p.W) * p.in_ld + c;
       f32x4 v[6];
@@ -176,26 +181,36 @@ __global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams p) {
           for (int e = 0; e < 4; ++e) v[b][e] = fmaxf(v[b][e], 0.f);
         }
       }
+      // input row a feeds output row rr = a - ta through kernel row ta (0..2)
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int ta = 0; ta < 3; ++ta) {
+        const int rr = a - ta;
+        if (rr < 0 || rr >= RR) continue;
 #pragma unroll
-        for (int b = 0; b < 3; ++b) acc[k] += v[k + b] * wt[a * 3 + b];
-    }
-    const int64_t opix = ((int64_t)(n * p.H + oh) * p.W + ow0);
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      f32x4 o = acc[k];
-      if (p.mask) {
-        const f32x4 m = *reinterpret_cast<const f32x4*>(p.mask + (opix + k) * p.mask_ld + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = m[e] > 0.f ? o[e] : 0.f;
+          for (int b = 0; b < 3; ++b) acc[rr][k] += v[k + b] * wt[ta * 3 + b];
       }
-      *reinterpret_cast<f32x4*>(p.out + (opix + k) * p.out_ld + c) = o;
+    }
+#pragma unroll
+    for (int rr = 0; rr < RR; ++rr) {
+      const int64_t opix = ((int64_t)(n * p.H + oh0 + rr) * p.W + ow0);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        f32x4 o = acc[rr][k];
+        if (p.mask) {
+          const f32x4 m = *reinterpret_cast<const f32x4*>(p.mask + (opix + k) * p.mask_ld + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = m[e] > 0.f ? o[e] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(p.out + (opix + k) * p.out_ld + c) = o;
+      }
     }
   }
 }
 
-// wgrad, same window: a "row" of the segmented reducer is a run of 4 output pixels
+// wgrad, same window: a "row" of the segmented reducer is a run of RR rows x 4 output pixels
+template <int RR>
 struct DwWgradRunOp {
   static constexpr int NOUT = 9;
   const float* __restrict__ x;
@@ -208,17 +223,20 @@ struct DwWgradRunOp {
     if constexpr (V != 4) {
       return;  // the run path is only planned with 16-byte chunks (seg_plan vec_ok = true, C % 4 == 0)
     } else {
-    uint32_t rowi, q, n, oh;
+    uint32_t rowi, q, n, ohb;
     fd_divmod((uint32_t)r, fd_rpr, rowi, q);
-    fd_divmod(rowi, fd_h, n, oh);
-    const int ow0 = (int)q * 4;
-    f32x4 g[4];
-    const float* gp = dy + ((int64_t)(n * H + oh) * W + ow0) * y_ld + c;
+    fd_divmod(rowi, fd_h, n, ohb);
+    const int ow0 = (int)q * 4, oh0 = (int)ohb * RR;
+    f32x4 g[RR][4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) g[k] = *reinterpret_cast<const f32x4*>(gp + (int64_t)k * y_ld);
+    for (int rr = 0; rr < RR; ++rr) {
+      const float* gp = dy + ((int64_t)(n * H + oh0 + rr) * W + ow0) * y_ld + c;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) {
-      const int ih = (int)oh - 1 + a;
+      for (int k = 0; k < 4; ++k) g[rr][k] = *reinterpret_cast<const f32x4*>(gp + (int64_t)k * y_ld);
+    }
+#pragma unroll
+    for (int a = 0; a < RR + 2; ++a) {
+      const int ih = oh0 - 1 + a;
       if ((unsigned)ih >= (unsigned)H) continue;
       const float* rowp = x + ((int64_t)(n * H + ih) * W) * x_ld + c;
       f32x4 v[6];
@@ -234,11 +252,16 @@ struct DwWgradRunOp {
         }
       }
 #pragma unroll
-      for (int b = 0; b < 3; ++b)
+      for (int ta = 0; ta < 3; ++ta) {
+        const int rr = a - ta;  // input row a meets output row rr under kernel row ta
+        if (rr < 0 || rr >= RR) continue;
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int b = 0; b < 3; ++b)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[a * 3 + b][e] = fmaf(v[k + b][e], g[k][e], acc[a * 3 + b][e]);
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[ta * 3 + b][e] = fmaf(v[k + b][e], g[rr][k][e], acc[ta * 3 + b][e]);
+      }
     }
     }
   }
@@ -253,13 +276,30 @@ inline bool dw_run_ok(const sg_conv_desc* d) {
          d->Ho == d->H && d->Wo == d->W && (d->W % 4 == 0) && (d->Cin % 4 == 0);
 }
 
-int launch_dw_run(const DwRunParams& p, hipStream_t st) {
+// Rows per run, measured (profiles/r01_bw_census.txt, SG_DW_RR = 1 / 2 / 4): the stencil kernels want tall strips on
+// small maps (32x32x728 bs16: 35 -> 24 us at 4 rows) and 2 rows on large ones; the kernel-gradient reduction loses
+// more from the shrinking number of runs than it gains on small maps (51 -> 65 us at 4 rows) and takes 2 rows
+// only from 64x64 up (64x64x728: 248 -> 157 us).
+inline int dw_rows_per_run(int H, int64_t pixels, bool wgrad) {
+  static const int force = getenv("SG_DW_RR") ? atoi(getenv("SG_DW_RR")) : 0;  // A/B switch: 1, 2 or 4
+  const bool small = pixels <= 32768;
+  const int want = force ? force : (wgrad ? (small ? 1 : 2) : (small ? 4 : 2));
+  return (want >= 4 && H % 4 == 0) ? 4 : ((want >= 2 && H % 2 == 0) ? 2 : 1);
+}
+
+int launch_dw_run(const DwRunParams& p_in, hipStream_t st) {
+  DwRunParams p = p_in;
+  const int rr = dw_rows_per_run(p.H, (int64_t)p.N * p.H * p.W, false);
+  p.nruns = (int64_t)p.N * (p.H / rr) * p.runs_per_row;
+  p.fd_h = make_fastdiv((uint32_t)(p.H / rr));
   const unsigned gx = (unsigned)sg_cdiv(p.C / 4, 64);
   int64_t gy = sg_cdiv(p.nruns, 4);
   const int64_t cap = sg_cdiv(16384, gx);
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
-  hipLaunchKernelGGL(dw_s1_run_kernel, dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
+  if (rr == 4) hipLaunchKernelGGL(dw_s1_run_kernel<4>, dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
+  else if (rr == 2) hipLaunchKernelGGL(dw_s1_run_kernel<2>, dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(dw_s1_run_kernel<1>, dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
   SG_LAUNCH_CHECK("dw_s1_run_kernel");
   return 0;
 }
@@ -569,17 +609,22 @@ int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
   const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
   const bool vec = (op.C % 4 == 0) && (op.x_ld % 4 == 0) && (op.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy);
   if (vec && dw_run_ok(d)) {
-    DwWgradRunOp ro;
-    ro.x = (const float*)x; ro.dy = (const float*)dy; ro.dw = (float*)dw; ro.H = d->H; ro.W = d->W; ro.C = op.C;
-    ro.x_ld = op.x_ld; ro.y_ld = op.y_ld; ro.pre_relu = pre_relu;
-    ro.fd_rpr = make_fastdiv((uint32_t)(d->W / 4)); ro.fd_h = make_fastdiv((uint32_t)d->H);
-    const int64_t nruns = rows / 4;
+    const int rr = dw_rows_per_run(d->H, rows, true);
+    const int64_t nruns = rows / (4 * rr);
     const SegPlan rp = seg_plan<9>(ctx->num_cus, 1, nruns, op.C, true);
     if (!ws || ws_bytes < rp.part_bytes) {
       sg_set_error("sg_dwconv2d_wgrad: workspace %zu < %zu", ws_bytes, rp.part_bytes);
       return SG_EWORKSPACE;
     }
-    return seg_reduce_launch(ro, rp, 1, nruns, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad_run");
+    auto run = [&](auto ro) -> int {
+      ro.x = (const float*)x; ro.dy = (const float*)dy; ro.dw = (float*)dw; ro.H = d->H; ro.W = d->W; ro.C = op.C;
+      ro.x_ld = op.x_ld; ro.y_ld = op.y_ld; ro.pre_relu = pre_relu;
+      ro.fd_rpr = make_fastdiv((uint32_t)(d->W / 4)); ro.fd_h = make_fastdiv((uint32_t)(d->H / rr));
+      return seg_reduce_launch(ro, rp, 1, nruns, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad_run");
+    };
+    if (rr == 4) return run(DwWgradRunOp<4>{});
+    if (rr == 2) return run(DwWgradRunOp<2>{});
+    return run(DwWgradRunOp<1>{});
   }
   const SegPlan pl = seg_plan<9>(ctx->num_cus, 1, rows, op.C, vec);
   if (!ws || ws_bytes < pl.part_bytes) {
