@@ -139,6 +139,7 @@ struct DwRunParams {
   const float* __restrict__ mask;  // dgrad with pre_relu: forward input, else null
   float* __restrict__ out;
   int N, H, W, C, in_ld, out_ld, mask_ld, relu_in, flip;
+  int lc;                          // lanes per run along the channels (set by launch_dw_run)
   int runs_per_row;                // W / 4
   int64_t nruns;                   // N * H * runs_per_row
   FastDiv fd_rpr, fd_h;
@@ -148,13 +149,16 @@ struct DwRunParams {
 // at RR = 1, 2.25 at RR = 4 (fd_h divides by H / RR then)
 template <int RR>
 __global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams p) {
-  const int c = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4;
+  // p.lc lanes (a power of two <= 64) cover the channel chunks of one run; with few channels (C = 64: 16 chunks)
+  // a wave takes several runs instead of idling three quarters of its lanes
+  const int lc = p.lc, rpb = 256 / lc;
+  const int c = (blockIdx.x * lc + (threadIdx.x & (lc - 1))) * 4;
   if (c >= p.C) return;
   f32x4 wt[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (p.flip ? 8 - t : t) * p.C + c);
-  const int64_t stride = (int64_t)gridDim.y * 4;
-  for (int64_t run = (int64_t)blockIdx.y * 4 + (threadIdx.x >> 6); run < p.nruns; run += stride) {
+  const int64_t stride = (int64_t)gridDim.y * rpb;
+  for (int64_t run = (int64_t)blockIdx.y * rpb + threadIdx.x / lc; run < p.nruns; run += stride) {
     uint32_t rowi, q, n, ohb;
     fd_divmod((uint32_t)run, p.fd_rpr, rowi, q);
     fd_divmod(rowi, p.fd_h, n, ohb);
@@ -292,8 +296,11 @@ int launch_dw_run(const DwRunParams& p_in, hipStream_t st) {
   const int rr = dw_rows_per_run(p.H, (int64_t)p.N * p.H * p.W, false);
   p.nruns = (int64_t)p.N * (p.H / rr) * p.runs_per_row;
   p.fd_h = make_fastdiv((uint32_t)(p.H / rr));
-  const unsigned gx = (unsigned)sg_cdiv(p.C / 4, 64);
-  int64_t gy = sg_cdiv(p.nruns, 4);
+  int lc = 1;
+  while (lc < p.C / 4 && lc < 64) lc <<= 1;
+  p.lc = lc;
+  const unsigned gx = (unsigned)sg_cdiv(p.C / 4, lc);
+  int64_t gy = sg_cdiv(p.nruns, 256 / lc);
   const int64_t cap = sg_cdiv(16384, gx);
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
