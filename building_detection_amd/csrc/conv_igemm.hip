@@ -938,8 +938,16 @@ int conv_variant() {
   return v;
 }
 
-int conv_l2() {
-  static int v = -1;
+// x6 == true: the switches as the x6 kernels use them.  Re-measured with those kernels (profiles/r01_ab_l2_orders.txt,
+// second part): the grouped order takes the ASPP dgrad fetch from 1998 to 485 MiB and the tap-inner wgrad order from
+// 795 to 279 MiB at 0-3 % of kernel time (the fp32 kernels paid 6-13 %), so both are on there: default 7.
+int conv_l2(bool x6 = false) {
+  static int v = -1, vx = -1;
+  if (vx < 0) {
+    const char* e = getenv("SG_CONV_L2");
+    vx = e ? atoi(e) & 7 : 7;
+  }
+  if (x6) return vx;
   if (v < 0) {
     const char* e = getenv("SG_CONV_L2");
     // default 2: measured on the ASPP convs (scripts/ab_l2.sh, 30 iterations, two interleaved rounds):
@@ -1004,7 +1012,7 @@ int pick_bn(int64_t M, int N, int num_cus) {
 }
 
 // fields shared by the fp32 and the x6 kernel: padding-tap elimination, tile order, K order
-void plan_common(IgemmParams& p, bool vec, int bn) {
+void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false) {
   static int noskip = -1;
   if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;  // A/B switch for the padding-tap elimination
   const int ntaps = p.K / p.C, spt = p.C / BK;
@@ -1013,12 +1021,12 @@ void plan_common(IgemmParams& p, bool vec, int bn) {
   // An XCD owns 1/8 of the tiles and with them about 1/8 of the A operand's pixels.
   const int64_t ntn = sg_cdiv(p.Nout, bn);
   const int64_t a_per_xcd = p.x_bytes ? (int64_t)p.x_bytes / 8 : (1ll << 40);
-  p.group_m = ((conv_l2() & 1) && ntn >= 4) ? (a_per_xcd <= (2ll << 20) ? 16 : 8) : 1;
+  p.group_m = ((conv_l2(x6) & 1) && ntn >= 4) ? (a_per_xcd <= (2ll << 20) ? 16 : 8) : 1;
   const bool ut = vec && (p.C % BK == 0) && p.x_bytes != 0 && p.w_bytes != 0;
   // decided from ONE image's footprint, never from the batch: the K order fixes the rounding order, and
   // inference must not depend on how many tiles travel together (tests/test_fullsize_gpu.py)
   const int64_t img_bytes = (int64_t)p.H * p.W * p.x_ld * 4;
-  p.cb = ((conv_l2() & 2) && ut && ntaps > 1 && spt > 4 && spt % 4 == 0 && img_bytes > (2ll << 20)) ? 4 : 0;
+  p.cb = ((conv_l2(x6) & 2) && ut && ntaps > 1 && spt > 4 && spt % 4 == 0 && img_bytes > (2ll << 20)) ? 4 : 0;
 }
 
 #include "conv_x6.h"
@@ -1031,7 +1039,7 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
     static const bool bn64 = getenv("SG_X6_BN64") != nullptr;
     if (bn64 && bn == 128 && sg_cdiv(p.M, BM) * sg_cdiv(p.Nout, 128) <= (int64_t)num_cus) bn = 64;
   }
-  plan_common(p, true, bn);
+  plan_common(p, true, bn, true);
   {
     static int il = -1;  // SG_X6_INTERLEAVE=0: staggered halves instead of the hand-interleaved step (A/B switch)
     if (il < 0) il = getenv("SG_X6_INTERLEAVE") ? atoi(getenv("SG_X6_INTERLEAVE")) : 1;
@@ -1170,6 +1178,7 @@ int dispatch_wgrad(const WgradParams& p_in, int S, bool vec, hipStream_t st) {
   const int var = conv_variant() & 3;
   p.stagger = (conv_variant() >> 2) & 1;
   if (wgrad_x6_ok(p, vec)) {
+    p.tap_inner = ((conv_l2(true) & 4) && p.KH_KW > 1 && p.Cin % BM == 0) ? 1 : 0;
     {
       static int abl = -1;
       if (abl < 0) {
@@ -1437,6 +1446,10 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
   const int64_t nslab = sg_cdiv(P, BK);
   const int64_t slots = 2 * (int64_t)num_cus;
   const double flops = 2.0 * (double)tiles * BM * bn * (double)P;  // padded tile work
+  // sustained rate of the kernel that will run: the x6 wgrad (geometry test as in wgrad_x6_ok) or the fp32 MFMA one
+  static const double rate_x6 = getenv("SG_WGRAD_PLAN_RATE") ? atof(getenv("SG_WGRAD_PLAN_RATE")) * 1e12 : 110e12;
+  const bool x6_geom = d->stride == 1 && d->Ho == d->H && d->Wo == d->W && d->W % 32 == 0 && d->Cout >= 16 && d->Cin % 4 == 0;
+  const double rate = x6_geom ? rate_x6 : 110e12;
   int64_t maxS = nslab / 8;  // at least 8 slabs per split
   if (maxS < 1) maxS = 1;
   if (maxS > 512) maxS = 512;
@@ -1447,7 +1460,7 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
     const double eff = (double)wgs / (double)(sg_cdiv(wgs, slots) * slots);
     const double part_bytes = S > 1 ? (double)S * (double)K * d->Cout * 4.0 : 0.0;
     if (part_bytes > (double)(384ll << 20)) break;
-    const double t = flops / (eff * 110e12) + 2.0 * part_bytes / 3.0e12 + (S > 1 ? 3e-6 : 0.0);
+    const double t = flops / (eff * rate) + 2.0 * part_bytes / 3.0e12 + (S > 1 ? 3e-6 : 0.0);
     if (t < best_t * 0.999) { best_t = t; best_S = S; }
   }
   pl.slabs_per_split = (int)sg_cdiv(nslab, best_S);

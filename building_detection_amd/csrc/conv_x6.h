@@ -107,7 +107,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   const int t = threadIdx.x;
   const uint32_t ntn = (p.Nout + BN - 1) / BN;
   const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-  const uint32_t tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+  uint32_t tile_m, tile_n;
+  if (p.group_m > 1) {  // grouped order (see igemm_conv_kernel): row tile fastest inside groups of group_m row tiles
+    const uint32_t ntm = gridDim.x / ntn, gm = (uint32_t)p.group_m;
+    const uint32_t per = gm * ntn, g = bid / per, r = bid - g * per;
+    const uint32_t left = ntm - g * gm, gsz = left < gm ? left : gm;
+    tile_n = r / gsz;
+    tile_m = g * gm + (r - tile_n * gsz);
+  } else {
+    tile_m = bid / ntn;
+    tile_n = bid - tile_m * ntn;
+  }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- A rows (same gather as igemm_conv_kernel's UT path) ----------------------------------------------
