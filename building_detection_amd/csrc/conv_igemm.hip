@@ -59,6 +59,7 @@ struct IgemmParams {
   // x6 path (conv_x6.h): the weights as three bf16 planes [3][Npad][Kpad]; w_bytes then is their extent
   const unsigned short* __restrict__ wq;
   int Kpad, Npad;
+  float* __restrict__ stats;  // SG_EPI_BN_STATS: [tiles_m][2][Nout] per-tile (sum, centred sum of squares), else null
 };
 
 __device__ __forceinline__ int spt_of(const IgemmParams& p) { return p.C / BK; }  // slabs per tap (UT)
@@ -1492,6 +1493,17 @@ int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, c
 
 int sg_conv2d_fwd_ws(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
                      const void* bias, void* y, int flags, void* ws, size_t ws_bytes) {
+  return sg_conv2d_fwd_stats(ctx, stream, dtype, d, x, w, bias, y, flags, ws, ws_bytes, nullptr, nullptr);
+}
+
+size_t sg_conv2d_fwd_stats_bytes(const sg_conv_desc* d) {
+  if (!d) return 0;
+  return (size_t)sg_cdiv((int64_t)d->N * d->Ho * d->Wo, BM) * 2 * d->Cout * sizeof(float);
+}
+
+int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
+                        const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out) {
+  if (tiles_out) *tiles_out = 0;
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_fwd: null ctx");
   SG_CHECK_ARG(dtype == SG_F32, "sg_conv2d_fwd: only SG_F32 is implemented");
   int rc = check_desc(d, "sg_conv2d_fwd");
@@ -1510,7 +1522,7 @@ int sg_conv2d_fwd_ws(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d
         sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
         const float* xs = (const float*)x + (int64_t)n0 * d->H * d->W * xl;
         float* ys = (float*)y + (int64_t)n0 * d->Ho * d->Wo * yl;
-        int rcs = sg_conv2d_fwd_ws(ctx, stream, dtype, &sub, xs, w, bias, ys, flags, ws, ws_bytes);
+        int rcs = sg_conv2d_fwd_ws(ctx, stream, dtype, &sub, xs, w, bias, ys, flags, ws, ws_bytes);  // (no statistics)
         if (rcs) return rcs;
       }
       return 0;
@@ -1543,9 +1555,28 @@ int sg_conv2d_fwd_ws(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d
     p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
   }
   const bool vec = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
-  if (ws && aligned16(ws) && ws_bytes >= x6_planes_bytes(p.K, p.Nout) && x6_ok(p, vec))
+  p.stats = nullptr;
+  if (ws && aligned16(ws) && ws_bytes >= x6_planes_bytes(p.K, p.Nout) && x6_ok(p, vec)) {
+    if (stats && tiles_out && !(flags & SG_EPI_RELU)) {  // the statistics ride in the x6 kernel's epilogue only
+      p.stats = (float*)stats;
+      *tiles_out = (int)sg_cdiv(p.M, BM);
+    }
     return run_x6(p, (const float*)w, false, d->Cin, d->Cout, ws, ctx->num_cus, (hipStream_t)stream);
+  }
   return dispatch_igemm(p, vec, ctx->num_cus, (hipStream_t)stream);
+}
+
+int sg_bn_train_fwd_tiles(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* stats, int tiles,
+                          void* moving_mean, void* moving_var, void* save_mean, void* save_invstd, float momentum,
+                          float eps, int unbiased_update) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_train_fwd_tiles: bad ctx/dtype");
+  SG_CHECK_ARG(rows > 0 && C > 0 && stats && tiles == (int)sg_cdiv(rows, BM) && moving_mean && moving_var && save_mean && save_invstd,
+               "sg_bn_train_fwd_tiles: bad argument");
+  hipLaunchKernelGGL(bn_tiles_finalize_kernel, dim3((unsigned)sg_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream,
+                     (const float*)stats, tiles, C, rows, (float*)moving_mean, (float*)moving_var, (float*)save_mean,
+                     (float*)save_invstd, momentum, eps, unbiased_update);
+  SG_LAUNCH_CHECK("bn_tiles_finalize_kernel");
+  return 0;
 }
 
 size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d) {
@@ -1616,6 +1647,7 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
     p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
   }
+  p.stats = nullptr;
   const bool vec = (d->Cout % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy);
   if (x6_ok(p, vec)) return run_x6(p, (const float*)w, true, d->Cin, d->Cout, ws, ctx->num_cus, st);
   {

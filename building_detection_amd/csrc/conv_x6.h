@@ -500,6 +500,83 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
       }
     }
   }
+
+  // ---- BatchNormalization statistics of this tile (SG_EPI_BN_STATS): per output channel the sum and the centred sum of
+  // squares over the tile's valid rows, taken from the accumulators before they leave the registers; two-pass within
+  // the tile (mean first, then sum (v - mean)^2), combined over the tiles in fp64 by bn_tiles_finalize_kernel.
+  // Layout: stats[tile_m][2][Nout].  Saves BatchNormalization its own statistics pass over y.
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem);  // [WGM][BN] partials, then [BN] tile means
+    float* tmean = red + WGM * BN;
+    const int wrow = wave / WGN;
+    const int nvalid = (p.M - m0) < BM ? (p.M - m0) : BM;
+    float vals[TN][TM][16];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn + 32 * j + lr;
+      const float bv = (has_bias && col < p.Nout) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) vals[j][i][r] = acc[i][j][r] + bv;
+    }
+    __syncthreads();  // every wave is done with the slab buffers
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cl = wn + 32 * j + lr;
+        const float mu = pass ? tmean[cl] : 0.f;
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float dlt = vals[j][i][r] - mu;
+            if (row < p.M) sacc += pass ? dlt * dlt : dlt;
+          }
+        sacc += __shfl_xor(sacc, 32, 64);  // lanes l and l+32 hold the same column
+        if (lh == 0) red[wrow * BN + cl] = sacc;
+      }
+      __syncthreads();
+      for (int cl = t; cl < BN; cl += NT) {
+        float tot = 0.f;
+#pragma unroll
+        for (int wq = 0; wq < WGM; ++wq) tot += red[wq * BN + cl];
+        const int col = n0 + cl;
+        if (pass == 0) tmean[cl] = tot / (float)nvalid;
+        if (col < p.Nout) p.stats[((int64_t)tile_m * 2 + pass) * p.Nout + col] = tot;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// mean / variance over all rows from the per-tile (sum, centred sum of squares) pairs, in fp64 (Chan's combination), then
+// the BatchNormalization bookkeeping of BnStatsOp::finalize.  One thread per channel; T = ceil(rows / 128) tiles.
+__global__ void bn_tiles_finalize_kernel(const float* __restrict__ stats, int T, int C, int64_t rows, float* moving_mean,
+                                         float* moving_var, float* save_mean, float* save_invstd, float momentum, float eps,
+                                         int unbiased) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0;
+  for (int tI = 0; tI < T; ++tI) s1 += (double)stats[((int64_t)tI * 2) * C + c];
+  const double n = (double)rows, mean = s1 / n;
+  double m2 = 0.0;
+  for (int tI = 0; tI < T; ++tI) {
+    const int64_t left = rows - (int64_t)tI * BM;
+    const double nt = (double)(left < BM ? left : BM);
+    const double mt = (double)stats[((int64_t)tI * 2) * C + c] / nt;
+    m2 += (double)stats[((int64_t)tI * 2 + 1) * C + c] + nt * (mt - mean) * (mt - mean);
+  }
+  double var = m2 / n;
+  if (var < 0.0) var = 0.0;
+  save_mean[c] = (float)mean;
+  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  const double var_u = (unbiased && rows > 1) ? var * (n / (n - 1.0)) : var;
+  moving_mean[c] = (float)((double)moving_mean[c] * momentum + mean * (1.0 - (double)momentum));
+  moving_var[c] = (float)((double)moving_var[c] * momentum + var_u * (1.0 - (double)momentum));
 }
 
 template <int BN, int WGM, int WGN, int PF>

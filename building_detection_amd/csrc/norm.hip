@@ -254,6 +254,27 @@ int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
   return 0;
 }
 
+int sg_bn_apply(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* gamma,
+                const void* beta, const void* mean, const void* invstd, void* y, int relu) {
+  SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_apply: bad ctx/dtype");
+  SG_CHECK_ARG(rows > 0 && C > 0 && x && gamma && beta && mean && invstd && y, "sg_bn_apply: bad argument");
+  SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_apply: tensor exceeds 2^31 elements");
+  const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
+  const int V = vec ? 4 : 1;
+  const unsigned blocks = ew_blocks(rows * (C / V));
+  hipStream_t st = (hipStream_t)stream;
+  if (vec)
+    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)mean,
+                       (const float*)invstd, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, 0.f, 0,
+                       make_fastdiv((uint32_t)(C / V)));
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)mean,
+                       (const float*)invstd, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, 0.f, 0,
+                       make_fastdiv((uint32_t)(C / V)));
+  SG_LAUNCH_CHECK("bn_apply_kernel");
+  return 0;
+}
+
 int sg_bn_infer(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* gamma,
                 const void* beta, const void* moving_mean, const void* moving_var, void* y, float eps, int relu) {
   SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_infer: bad ctx/dtype");

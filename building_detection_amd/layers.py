@@ -81,6 +81,12 @@ class _ConvNode(Node):
         (x,) = xs
         b = rt.param(self.b) if self.b else None
         with rt.eng.timed(self._tag):
+            if training and getattr(self, "emit_bn_stats", False):
+                # the following BatchNormalization takes its statistics from this conv's epilogue
+                y, st = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=self.desc(rt, x), want_stats=True)
+                if st is not None:
+                    rt.bn_stats[id(y)] = st
+                return y
             y = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=self.desc(rt, x), relu=self.activation == "relu")
         if self.activation == "sigmoid":
             y = rt.eng.act_fwd(y, _lib.SG_ACT_SIGMOID, out=y)
@@ -145,6 +151,11 @@ class _SepConvNode(Node):
         t = e.dwconv_fwd(x, rt.param(self.dw), self.stride, self.pre_relu)
         if training:
             rt.save(self, t=t)
+            if getattr(self, "emit_bn_stats", False):
+                y, st = e.conv2d_fwd(t, rt.param(self.pw), rt.param(self.b), want_stats=True)
+                if st is not None:
+                    rt.bn_stats[id(y)] = st
+                return y
         return e.conv2d_fwd(t, rt.param(self.pw), rt.param(self.b), relu=self.activation == "relu")
 
     def backward(self, rt, xs, y, dy):
@@ -304,8 +315,14 @@ class _BNNode(Node):
         (x,) = xs
         e = rt.eng
         if training:
-            y, mean, invstd = e.bn_train_fwd(x, rt.param(self.gamma), rt.param(self.beta), rt.param(self.mm),
-                                             rt.param(self.mv), relu=self.relu, momentum=self.momentum, eps=self.epsilon)
+            st = rt.bn_stats.pop(id(x), None)
+            if st is not None:  # statistics already produced by the conv that wrote x
+                y, mean, invstd = e.bn_train_fwd_from_tiles(x, st[0], st[1], rt.param(self.gamma), rt.param(self.beta),
+                                                            rt.param(self.mm), rt.param(self.mv), relu=self.relu,
+                                                            momentum=self.momentum, eps=self.epsilon)
+            else:
+                y, mean, invstd = e.bn_train_fwd(x, rt.param(self.gamma), rt.param(self.beta), rt.param(self.mm),
+                                                 rt.param(self.mv), relu=self.relu, momentum=self.momentum, eps=self.epsilon)
             rt.save(self, mean=mean, invstd=invstd)
             return y
         return e.bn_infer(x, rt.param(self.gamma), rt.param(self.beta), rt.param(self.mm), rt.param(self.mv),

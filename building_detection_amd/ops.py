@@ -128,7 +128,10 @@ class Engine:
         ho, wo, pt, pl = conv_out_geometry(h, w, kh, kw, stride, dilation, padding)
         return ConvDesc(n, h, w, cin, cout, kh, kw, stride, dilation, pt, pl, ho, wo, x_ld, y_ld)
 
-    def conv2d_fwd(self, x, w, b=None, stride=1, dilation=1, padding="same", relu=False, out=None, desc=None):
+    def conv2d_fwd(self, x, w, b=None, stride=1, dilation=1, padding="same", relu=False, out=None, desc=None,
+                   want_stats=False):
+        """want_stats: also return the BatchNormalization statistics of y as (stats tensor [tiles,2,Cout], tiles), or
+        None when this launch could not produce them (then BN computes its own)."""
         _chk(x, "x"); _chk(w, "w")
         kh, kw, cin, cout = w.shape
         d = desc or self.conv_desc(x.shape, cout, kh, kw, stride, dilation, padding)
@@ -137,6 +140,12 @@ class Engine:
         flags = (_lib.SG_EPI_BIAS if b is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
         need = self.lib.sg_conv2d_fwd_ws_bytes(C.byref(d))
         wsp, wsn = self.ws(need)
+        if want_stats:
+            st = self.empty(self.lib.sg_conv2d_fwd_stats_bytes(C.byref(d)) // 4)
+            tiles = C.c_int(0)
+            check(self.lib.sg_conv2d_fwd_stats(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y),
+                                               flags, wsp, wsn, _ptr(st), C.byref(tiles)), "sg_conv2d_fwd_stats")
+            return y, ((st, tiles.value) if tiles.value > 0 else None)
         check(self.lib.sg_conv2d_fwd_ws(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags,
                                         wsp, wsn), "sg_conv2d_fwd_ws")
         return y
@@ -208,6 +217,18 @@ class Engine:
         check(self.lib.sg_bn_train_fwd(self.h, self.stream, SG_F32, rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mm),
                                        _ptr(mv), _ptr(y), _ptr(mean), _ptr(invstd), momentum, eps, int(relu),
                                        int(x.dim() == 4), wsp, wsn), "sg_bn_train_fwd")
+        return y, mean, invstd
+
+    def bn_train_fwd_from_tiles(self, x, stats, tiles, gamma, beta, mm, mv, relu=False, momentum=0.99, eps=1e-3, out=None):
+        """Training forward with the statistics the producing conv left in `stats` (conv2d_fwd(want_stats=True))."""
+        c = x.shape[-1]
+        rows = x.numel() // c
+        y = out if out is not None else torch.empty_like(x)
+        mean, invstd = self.empty(c), self.empty(c)
+        check(self.lib.sg_bn_train_fwd_tiles(self.h, self.stream, SG_F32, rows, c, _ptr(stats), int(tiles), _ptr(mm), _ptr(mv),
+                                             _ptr(mean), _ptr(invstd), momentum, eps, int(x.dim() == 4)), "sg_bn_train_fwd_tiles")
+        check(self.lib.sg_bn_apply(self.h, self.stream, SG_F32, rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean),
+                                   _ptr(invstd), _ptr(y), int(relu)), "sg_bn_apply")
         return y, mean, invstd
 
     def bn_train_bwd(self, x, y, dy, gamma, mean, invstd, relu=False, out=None, dgamma=None, dbeta=None, beta=None):

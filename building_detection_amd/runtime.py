@@ -118,6 +118,7 @@ class Model:
                 cons = n.output.consumers
                 if len(cons) == 1 and isinstance(cons[0], L._BNNode) and len(n.output.shape) == 4:
                     n.bias_grad_zero = True
+                    n.emit_bn_stats = True  # the conv epilogue hands BN its statistics (sg_conv2d_fwd_stats)
         for n in self.nodes:
             if not isinstance(n, L._ActNode) or n.act != "relu" or n.fused_away:
                 continue
@@ -419,6 +420,7 @@ class _Runtime:
         self._gviews: Dict[int, object] = {}
         self.values: Dict[int, object] = {}
         self._saved: Dict[int, dict] = {}
+        self.bn_stats: Dict[int, tuple] = {}  # id(conv output tensor) -> (per-tile statistics, tiles)
         self.on_node_done = None
 
     # -- parameters ---------------------------------------------------------------------------------------
@@ -459,6 +461,7 @@ class _Runtime:
     def release(self):
         self.values.clear()
         self._saved.clear()
+        self.bn_stats.clear()
 
     def forward(self, x, training: bool):
         m = self.model

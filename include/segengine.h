@@ -89,6 +89,25 @@ size_t sg_conv2d_fwd_ws_bytes(const sg_conv_desc* d);
 int sg_conv2d_fwd_ws(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
                      const void* w, const void* bias, void* y, int flags, void* ws, size_t ws_bytes);
 
+/* The forward that also hands the following BatchNormalization its statistics (epilogue flag
+ * bn_stats): per 128-pixel tile and output channel the sum and the centred sum of squares of y, written to
+ * stats[tiles][2][Cout] (sg_conv2d_fwd_stats_bytes) from the accumulators.  *tiles_out = number of tiles written,
+ * or 0 when this launch could not produce them (shape not on the x6 path): the caller then lets
+ * sg_bn_train_fwd compute its own.  sg_bn_train_fwd_tiles turns them into mean / inv-std / moving statistics
+ * (fp64 combination); the apply pass is sg_bn_apply.  Replaces Conv2D -> BatchNormalization (training) at
+ * predict_model/v3plus.py:173-179 and every SeparableConv2D -> BatchNormalization pair (v3plus.py:187-278). */
+size_t sg_conv2d_fwd_stats_bytes(const sg_conv_desc* d);
+int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
+                        const void* w, const void* bias, void* y, int flags, void* ws, size_t ws_bytes,
+                        void* stats, int* tiles_out);
+int sg_bn_train_fwd_tiles(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* stats,
+                          int tiles, void* moving_mean, void* moving_var, void* save_mean, void* save_invstd,
+                          float momentum, float eps, int unbiased_update);
+/* y = gamma * (x - mean) * invstd + beta (ReLU optional) with given statistics: the apply pass of the training
+ * forward on its own. */
+int sg_bn_apply(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* gamma,
+                const void* beta, const void* mean, const void* invstd, void* y, int relu);
+
 /* Conv2D input gradient dx[N,H,W,Cin] (pixel stride d->x_ld) from dy[N,Ho,Wo,Cout] (pixel stride d->y_ld).
  * The same routine is Conv2DTranspose *forward* (y_T = dgrad of the SAME conv that maps the upsampled grid
  * back): v3plus.py:328,335, scse.py:71-89, res34.py:144 — hence the optional epilogue

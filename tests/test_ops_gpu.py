@@ -502,3 +502,31 @@ def test_x6_at_least_as_accurate_as_native_fp32_mfma(engine, case):
         print(f"{key}: max rel err x6 {ex:.2e}  native fp32 MFMA {en:.2e}")
         assert ex <= 2e-5 and en <= 2e-5
         assert ex <= 1.5 * en + 2e-8, (key, ex, en)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 32, 256, 728, 1), (3, 20, 32, 64, 96, 3), (1, 32, 32, 128, 40, 3)],
+                         ids=["pw_728", "ragged_rows", "cout40"])
+def test_conv_epilogue_bn_statistics(engine, shape):
+    """SG_EPI bn_stats: the per-tile (sum, centred sum of squares) a convolution leaves for the following
+    BatchNormalization give the same normalised output, saved statistics and moving statistics as BN's own pass."""
+    n, h, w, cin, cout, k = shape
+    g = torch.Generator().manual_seed(cout)
+    x = rnd(g, n, h, w, cin).cuda()
+    wt = (rnd(g, k, k, cin, cout) * (1.0 / np.sqrt(k * k * cin))).cuda()
+    b = (rnd(g, cout) * 3).cuda()                      # a bias that shifts the channel means away from zero
+    gam, bet = (rnd(g, cout) + 1.5).cuda(), rnd(g, cout).cuda()
+    y, st = engine.conv2d_fwd(x, wt, b, 1, 1, "same", want_stats=True)
+    assert st is not None, "this shape is on the x6 path and must produce statistics"
+    mm1, mv1 = torch.zeros(cout).cuda(), torch.ones(cout).cuda()
+    mm2, mv2 = torch.zeros(cout).cuda(), torch.ones(cout).cuda()
+    z1, mean1, inv1 = engine.bn_train_fwd(y, gam, bet, mm1, mv1, relu=True)
+    z2, mean2, inv2 = engine.bn_train_fwd_from_tiles(y, st[0], st[1], gam, bet, mm2, mv2, relu=True)
+    close(mean2, mean1, rtol=2e-6, what="mean")
+    close(inv2, inv1, rtol=2e-6, what="inv-std")
+    close(mm2, mm1, rtol=2e-6, what="moving mean")
+    close(mv2, mv1, rtol=2e-6, what="moving variance")
+    close(z2, z1, rtol=5e-6, what="normalised output")
+    # and against the oracle in float64
+    yr = T.conv2d(x.cpu().double(), wt.cpu().double(), b.cpu().double(), 1, 1, "same")
+    zr, _, _ = T.batch_norm(yr, gam.cpu().double(), bet.cpu().double(), torch.zeros(cout).double(), torch.ones(cout).double(), True)
+    close(z2, torch.relu(zr), rtol=2e-5, what="conv -> BN -> ReLU vs fp64 oracle")
