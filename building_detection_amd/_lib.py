@@ -47,7 +47,8 @@ _SIGNATURES = {
     "sg_conv2d_fwd_ws": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "sg_conv2d_fwd_stats_bytes": (_sz, [_dp]),
     "sg_conv2d_fwd_stats": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, C.POINTER(C.c_int)]),
-    "sg_bn_train_fwd_tiles": (_i, [_vp, _vp, _i, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i]),
+    "sg_bn_tiles_ws_bytes": (_sz, [_vp, _i, _i]),
+    "sg_bn_train_fwd_tiles": (_i, [_vp, _vp, _i, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _sz]),
     "sg_bn_apply": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "sg_conv2d_dgrad_ws_bytes": (_sz, [_dp]),
     "sg_conv2d_dgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),

@@ -1566,17 +1566,29 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
   return dispatch_igemm(p, vec, ctx->num_cus, (hipStream_t)stream);
 }
 
+size_t sg_bn_tiles_ws_bytes(const sg_ctx* ctx, int tiles, int C) {
+  if (!ctx) return 0;
+  return seg_plan<2>(ctx->num_cus, 1, tiles, C, true).part_bytes + seg_plan<2>(ctx->num_cus, 1, tiles, C, false).part_bytes;
+}
+
 int sg_bn_train_fwd_tiles(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* stats, int tiles,
                           void* moving_mean, void* moving_var, void* save_mean, void* save_invstd, float momentum,
-                          float eps, int unbiased_update) {
+                          float eps, int unbiased_update, void* ws, size_t ws_bytes) {
   SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_train_fwd_tiles: bad ctx/dtype");
   SG_CHECK_ARG(rows > 0 && C > 0 && stats && tiles == (int)sg_cdiv(rows, BM) && moving_mean && moving_var && save_mean && save_invstd,
                "sg_bn_train_fwd_tiles: bad argument");
-  hipLaunchKernelGGL(bn_tiles_finalize_kernel, dim3((unsigned)sg_cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream,
-                     (const float*)stats, tiles, C, rows, (float*)moving_mean, (float*)moving_var, (float*)save_mean,
-                     (float*)save_invstd, momentum, eps, unbiased_update);
-  SG_LAUNCH_CHECK("bn_tiles_finalize_kernel");
-  return 0;
+  const bool vec = (C % 4 == 0) && sg_aligned16(stats);
+  const SegPlan pl = seg_plan<2>(ctx->num_cus, 1, tiles, C, vec);
+  if (!ws || ws_bytes < pl.part_bytes) {
+    sg_set_error("sg_bn_train_fwd_tiles: workspace %zu < %zu", ws_bytes, pl.part_bytes);
+    return SG_EWORKSPACE;
+  }
+  BnTilesOp op;
+  op.stats = (const float*)stats; op.C = C; op.rows = rows;
+  op.moving_mean = (float*)moving_mean; op.moving_var = (float*)moving_var;
+  op.save_mean = (float*)save_mean; op.save_invstd = (float*)save_invstd;
+  op.momentum = momentum; op.eps = eps; op.unbiased = unbiased_update;
+  return seg_reduce_launch(op, pl, 1, tiles, C, (float*)ws, (hipStream_t)stream, "bn_tiles");
 }
 
 size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d) {

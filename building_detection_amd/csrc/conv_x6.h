@@ -553,31 +553,49 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   }
 }
 
-// mean / variance over all rows from the per-tile (sum, centred sum of squares) pairs, in fp64 (Chan's combination), then
-// the BatchNormalization bookkeeping of BnStatsOp::finalize.  One thread per channel; T = ceil(rows / 128) tiles.
-__global__ void bn_tiles_finalize_kernel(const float* __restrict__ stats, int T, int C, int64_t rows, float* moving_mean,
-                                         float* moving_var, float* save_mean, float* save_invstd, float momentum, float eps,
-                                         int unbiased) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0;
-  for (int tI = 0; tI < T; ++tI) s1 += (double)stats[((int64_t)tI * 2) * C + c];
-  const double n = (double)rows, mean = s1 / n;
-  double m2 = 0.0;
-  for (int tI = 0; tI < T; ++tI) {
-    const int64_t left = rows - (int64_t)tI * BM;
-    const double nt = (double)(left < BM ? left : BM);
-    const double mt = (double)stats[((int64_t)tI * 2) * C + c] / nt;
-    m2 += (double)stats[((int64_t)tI * 2 + 1) * C + c] + nt * (mt - mean) * (mt - mean);
+// mean / variance over all rows from the per-tile (sum, centred sum of squares) pairs: a segmented column reduction
+// over the T tiles (rows of the reducer = tiles), pivoted on tile 0's mean so nothing cancels, combined in fp64, then
+// the BatchNormalization bookkeeping of BnStatsOp::finalize.
+struct BnTilesOp {
+  static constexpr int NOUT = 2;
+  const float* __restrict__ stats;  // [T][2][C]
+  int C;
+  int64_t rows;                     // pixels (not tiles)
+  float* moving_mean;
+  float* moving_var;
+  float* save_mean;
+  float* save_invstd;
+  float momentum, eps;
+  int unbiased;
+
+  template <int V>
+  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[2][V]) const {
+    float s1[V], m2[V], s0[V];
+    ldv<V>(stats + (2 * r) * C + c, s1);
+    ldv<V>(stats + (2 * r + 1) * C + c, m2);
+    ldv<V>(stats + c, s0);
+    const int64_t left = rows - r * BM;
+    const float nt = (float)(left < BM ? left : BM), n0 = (float)(rows < BM ? rows : BM);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float d = s1[i] / nt - s0[i] / n0;  // tile mean minus the pivot (tile 0's mean)
+      acc[0][i] = fmaf(nt, d, acc[0][i]);
+      acc[1][i] += fmaf(nt * d, d, m2[i]);
+    }
   }
-  double var = m2 / n;
-  if (var < 0.0) var = 0.0;
-  save_mean[c] = (float)mean;
-  save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  const double var_u = (unbiased && rows > 1) ? var * (n / (n - 1.0)) : var;
-  moving_mean[c] = (float)((double)moving_mean[c] * momentum + mean * (1.0 - (double)momentum));
-  moving_var[c] = (float)((double)moving_var[c] * momentum + var_u * (1.0 - (double)momentum));
-}
+  __device__ __forceinline__ void finalize(int, int c, const double (&s)[2]) const {
+    const double n = (double)rows, n0 = (double)(rows < BM ? rows : BM);
+    const double m1 = s[0] / n;
+    const double mean = (double)stats[c] / n0 + m1;
+    double var = s[1] / n - m1 * m1;
+    if (var < 0.0) var = 0.0;
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    const double var_u = (unbiased && rows > 1) ? var * (n / (n - 1.0)) : var;
+    moving_mean[c] = (float)((double)moving_mean[c] * momentum + mean * (1.0 - (double)momentum));
+    moving_var[c] = (float)((double)moving_var[c] * momentum + var_u * (1.0 - (double)momentum));
+  }
+};
 
 template <int BN, int WGM, int WGN, int PF>
 int launch_x6(const IgemmParams& p, hipStream_t st) {

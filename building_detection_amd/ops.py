@@ -225,8 +225,10 @@ class Engine:
         rows = x.numel() // c
         y = out if out is not None else torch.empty_like(x)
         mean, invstd = self.empty(c), self.empty(c)
+        wsp, wsn = self.ws(self.lib.sg_bn_tiles_ws_bytes(self.h, int(tiles), c))
         check(self.lib.sg_bn_train_fwd_tiles(self.h, self.stream, SG_F32, rows, c, _ptr(stats), int(tiles), _ptr(mm), _ptr(mv),
-                                             _ptr(mean), _ptr(invstd), momentum, eps, int(x.dim() == 4)), "sg_bn_train_fwd_tiles")
+                                             _ptr(mean), _ptr(invstd), momentum, eps, int(x.dim() == 4), wsp, wsn),
+              "sg_bn_train_fwd_tiles")
         check(self.lib.sg_bn_apply(self.h, self.stream, SG_F32, rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean),
                                    _ptr(invstd), _ptr(y), int(relu)), "sg_bn_apply")
         return y, mean, invstd

@@ -100,9 +100,10 @@ size_t sg_conv2d_fwd_stats_bytes(const sg_conv_desc* d);
 int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
                         const void* w, const void* bias, void* y, int flags, void* ws, size_t ws_bytes,
                         void* stats, int* tiles_out);
+size_t sg_bn_tiles_ws_bytes(const sg_ctx* ctx, int tiles, int C);
 int sg_bn_train_fwd_tiles(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* stats,
                           int tiles, void* moving_mean, void* moving_var, void* save_mean, void* save_invstd,
-                          float momentum, float eps, int unbiased_update);
+                          float momentum, float eps, int unbiased_update, void* ws, size_t ws_bytes);
 /* y = gamma * (x - mean) * invstd + beta (ReLU optional) with given statistics: the apply pass of the training
  * forward on its own. */
 int sg_bn_apply(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* gamma,

@@ -130,7 +130,8 @@ def test_train_step_parity(engine, name, size, kw):
     g_rel, c_rel = (num / den) ** 0.5, (num_c / den) ** 0.5
     print(f"{name}: global rel-L2 grad error gpu {g_rel:.2e} (cpu-fp32 oracle {c_rel:.2e}); worst tensor {worst[1]}: "
           f"gpu {worst[2]:.2e}, cpu-fp32 oracle {worst[3]:.2e}, share of gradient energy {worst[4]:.1e}")
-    assert g_rel <= 2e-2, f"{name}: global gradient error {g_rel:.3e}"
+    # ... and the whole gradient against the fp32 CPU oracle's own distance from fp64 (Res34: 1.6e-2 by itself)
+    assert g_rel <= max(2e-2, 2.5 * c_rel), f"{name}: global gradient error {g_rel:.3e} (fp32 oracle {c_rel:.3e})"
     assert worst[0] <= 1.0, f"{name}: gradient of {worst[1]} off by {worst[2]:.3e} (relative L2; fp32 oracle {worst[3]:.3e})"
 
     # BN moving statistics after the training forward
