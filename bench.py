@@ -31,8 +31,10 @@ LABEL = {"v3plus": "DeepLabv3+ (v3plus.py)", "bam": "DeepLabv3+ BAM (bam.py)", "
 DILATED_GFLOP_PER_TILE = 97.84  # fwd + dgrad + wgrad of the 6 dilated convs, SURVEY.md §8d
 
 
-def cpu_baseline(threads, batch, size, steps):
-    """One oracle training step (fwd + loss + bwd + Adam) per iteration on the host cores."""
+def cpu_baseline(threads, batch, size, steps, model=None):
+    """One oracle training step (fwd + loss + bwd + Adam) per iteration on the host cores.  With `model` (the engine's
+    DeepLabv3+, after its timed steps) the same weights and tiles are also run through both in inference mode: the
+    metric's "mIoU vs TF2 CPU" leg, with the CPU oracle standing in for TF2 (absent here)."""
     import torch
     from oracle import models as M
     from building_detection_amd.data import synthetic_batch
@@ -57,9 +59,24 @@ def cpu_baseline(threads, batch, size, steps):
         if it > 0:  # first iteration creates the parameters
             times.append(time.time() - t0)
     best = min(times)
-    return {"value": round(batch / best, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
-            "sample": f"CPU oracle (restated TF2 semantics, torch CPU ops) DeepLabv3+ {size}x{size} bs={batch}, "
-                      f"min of {steps} full steps (fwd+loss+bwd+Adam), {best:.2f} s/step"}
+    out = {"value": round(batch / best, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
+           "sample": f"CPU oracle (restated TF2 semantics, torch CPU ops) DeepLabv3+ {size}x{size} bs={batch}, "
+                     f"min of {steps} full steps (fwd+loss+bwd+Adam), {best:.2f} s/step"}
+    if model is not None:
+        import numpy as np
+        with torch.no_grad():
+            p_cpu = M.deeplab_v3plus(P, xt, training=False)
+        model.set_weights([t.detach().numpy() for t in P.tensors])
+        p_gpu = model.predict(x)
+        cm_c = M.metrics_from_counts(*M.confusion(yt, p_cpu))
+        cm_g = M.metrics_from_counts(*M.confusion(yt, torch.from_numpy(p_gpu)))
+        pc = p_cpu.numpy()
+        out["parity"] = {"what": "predict() of the engine vs the CPU oracle, same weights (after the oracle's training steps) "
+                                 f"and the same {batch} tiles",
+                         "max_abs_prob_diff": float(np.abs(p_gpu - pc).max()),
+                         "argmax_mismatch_pixels": int((p_gpu.argmax(-1) != pc.argmax(-1)).sum()),
+                         "MIoU_gpu": round(cm_g["MIoU"], 6), "MIoU_cpu_oracle": round(cm_c["MIoU"], 6)}
+    return out
 
 
 def main():
@@ -180,7 +197,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             try:
-                out["cpu_baseline"] = cpu_baseline(threads, 2, args.size, 2)
+                out["cpu_baseline"] = cpu_baseline(threads, 2, args.size, 2, model if args.model == "v3plus" else None)
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)
