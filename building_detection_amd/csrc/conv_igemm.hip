@@ -1426,6 +1426,8 @@ struct WgradPlan {
   int slabs_per_split;
   size_t dw_part_bytes;
   size_t bias_part_bytes;
+  int chunks = 1;  // > 1: activations beyond 2 GiB are reduced as sub-batches of nb whole images, each with S splits
+  int nb = 0;
 };
 
 // Split of the pixel reduction over S workgroups per tile.  Modelled time = MFMA work / (fraction of the
@@ -1435,6 +1437,19 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
   WgradPlan pl;
   const int64_t K = (int64_t)d->KH * d->KW * d->Cin;
   const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+  {
+    const int nb = images_per_2gib(d);
+    if (nb >= 1 && nb < d->N && !thin_ok(d)) {
+      sg_conv_desc sub = *d;
+      sub.N = nb;
+      pl = plan_wgrad(num_cus, &sub);
+      pl.nb = nb;
+      pl.chunks = (int)sg_cdiv(d->N, nb);
+      pl.dw_part_bytes = (size_t)pl.chunks * pl.S * K * d->Cout * 4;  // every chunk writes partial slabs
+      pl.bias_part_bytes = colsum_ws_bytes(num_cus, P, d->Cout);
+      return pl;
+    }
+  }
   if (thin_ok(d)) {
     pl.S = 1;
     pl.slabs_per_split = 0;
@@ -1706,42 +1721,63 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     }
     return 0;
   }
-  WgradParams p;
-  p.x = (const float*)x;
-  p.dy = (const float*)dy;
-  p.out = pl.S > 1 ? (float*)ws : (float*)dw;
-  p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_ld = d->x_ld ? d->x_ld : d->Cin;
-  p.OH = d->Ho; p.OW = d->Wo; p.Cout = d->Cout; p.y_ld = d->y_ld ? d->y_ld : d->Cout;
-  p.stride = d->stride; p.dil = d->dilation; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
-  p.K = d->KH * d->KW * d->Cin;
-  p.P = d->N * d->Ho * d->Wo;
-  p.slabs_per_split = pl.slabs_per_split;
-  p.fd_ohow = make_fastdiv((uint32_t)(d->Ho * d->Wo));
-  p.fd_ow = make_fastdiv((uint32_t)d->Wo);
-  p.fd_c = make_fastdiv((uint32_t)d->Cin);
-  p.fd_kw = make_fastdiv((uint32_t)d->KW);
-  p.fd_oh = make_fastdiv((uint32_t)d->Ho);
-  {
-    const int64_t xb = (((int64_t)d->N * d->H * d->W - 1) * p.x_ld + d->Cin) * 4;
-    const int64_t yb = (((int64_t)p.P - 1) * p.y_ld + d->Cout) * 4;
-    p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
-    p.dy_bytes = yb < (1ll << 31) ? (uint32_t)yb : 0;
+  const int K_all = d->KH * d->KW * d->Cin;
+  auto launch_part = [&](const sg_conv_desc& dd, const float* xs, const float* dys, float* out, int S, int sps) -> int {
+    WgradParams p;
+    p.x = xs;
+    p.dy = dys;
+    p.out = out;
+    p.H = dd.H; p.W = dd.W; p.Cin = dd.Cin; p.x_ld = dd.x_ld ? dd.x_ld : dd.Cin;
+    p.OH = dd.Ho; p.OW = dd.Wo; p.Cout = dd.Cout; p.y_ld = dd.y_ld ? dd.y_ld : dd.Cout;
+    p.stride = dd.stride; p.dil = dd.dilation; p.pad_t = dd.pad_t; p.pad_l = dd.pad_l;
+    p.K = K_all;
+    p.P = dd.N * dd.Ho * dd.Wo;
+    p.slabs_per_split = sps;
+    p.fd_ohow = make_fastdiv((uint32_t)(dd.Ho * dd.Wo));
+    p.fd_ow = make_fastdiv((uint32_t)dd.Wo);
+    p.fd_c = make_fastdiv((uint32_t)dd.Cin);
+    p.fd_kw = make_fastdiv((uint32_t)dd.KW);
+    p.fd_oh = make_fastdiv((uint32_t)dd.Ho);
+    {
+      const int64_t xb = (((int64_t)dd.N * dd.H * dd.W - 1) * p.x_ld + dd.Cin) * 4;
+      const int64_t yb = (((int64_t)p.P - 1) * p.y_ld + dd.Cout) * 4;
+      p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
+      p.dy_bytes = yb < (1ll << 31) ? (uint32_t)yb : 0;
+    }
+    const bool vec = (dd.Cin % 4 == 0) && (p.x_ld % 4 == 0) && (dd.Cout % 4 == 0) && (p.y_ld % 4 == 0) &&
+                     aligned16(xs) && aligned16(dys);
+    return dispatch_wgrad(p, S, vec, st);
+  };
+  int total_parts = pl.S;
+  if (pl.chunks > 1) {
+    // sub-batches of whole images, each writing its S partial slabs one after the other; one reduce over all of them
+    const int64_t xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+    const int64_t slab = (int64_t)K_all * d->Cout;
+    for (int c = 0; c < pl.chunks; ++c) {
+      sg_conv_desc sub = *d;
+      const int n0 = c * pl.nb;
+      sub.N = (d->N - n0 < pl.nb) ? d->N - n0 : pl.nb;
+      rc = launch_part(sub, (const float*)x + (int64_t)n0 * d->H * d->W * xl, (const float*)dy + (int64_t)n0 * d->Ho * d->Wo * yl,
+                       (float*)ws + (int64_t)c * pl.S * slab, pl.S, pl.slabs_per_split);
+      if (rc) return rc;
+    }
+    total_parts = pl.chunks * pl.S;
+  } else {
+    rc = launch_part(*d, (const float*)x, (const float*)dy, pl.S > 1 ? (float*)ws : (float*)dw, pl.S, pl.slabs_per_split);
+    if (rc) return rc;
   }
-  const bool vec = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cout % 4 == 0) && (p.y_ld % 4 == 0) &&
-                   aligned16(x) && aligned16(dy);
-  rc = dispatch_wgrad(p, pl.S, vec, st);
-  if (rc) return rc;
-  if (pl.S > 1) {
-    const int64_t n = (int64_t)p.K * p.Cout;
+  if (total_parts > 1) {
+    const int64_t n = (int64_t)K_all * d->Cout;
     int64_t blocks = sg_cdiv(n, 256);
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, (float*)dw, n, pl.S);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, (float*)dw, n, total_parts);
     SG_LAUNCH_CHECK("reduce_splits_kernel");
   }
   if (dbias) {
     // 256-byte aligned region after the dw partials
     float* part = (float*)((char*)ws + ((pl.dw_part_bytes + 255) & ~(size_t)255));
-    rc = launch_colsum(ctx->num_cus, (const float*)dy, (int64_t)p.P, d->Cout, p.y_ld, (float*)dbias, part, st);
+    rc = launch_colsum(ctx->num_cus, (const float*)dy, (int64_t)d->N * d->Ho * d->Wo, d->Cout, d->y_ld ? d->y_ld : d->Cout,
+                       (float*)dbias, part, st);
     if (rc) return rc;
   }
   return 0;
