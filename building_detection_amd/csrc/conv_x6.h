@@ -26,7 +26,12 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 
-constexpr int XPITCH = 80;  // bytes per LDS row of a plane slab
+// LDS rows of a plane slab are the bare 64 bytes (32 k as bf16); the four 16-byte chunks of row r are stored at
+// slot (chunk ^ xswz(r)).  Reads: the 16 lanes of a ds_read_b128 group (rows {0-3,12-15,20-27} or {4-11,16-19,28-31})
+// then hit 16 distinct 16-byte bank groups; writes: two consecutive rows fill the 32 write banks exactly once
+// (the padded 80-byte rows this replaces cost 28 % of the LDS-active cycles in bank conflicts, SQ_LDS_BANK_CONFLICT).
+constexpr int XPITCH = 64;
+__device__ __forceinline__ int xswz(int row) { return (row >> 2) & 3; }
 
 // (x0, x1) -> three packed bf16 pairs (element 0 in the low half), x = h + m + l up to 2^-25 |x|
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
@@ -210,7 +215,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
       unsigned h0, m0_, l0, h1, m1, l1;
       split3_pair(ra[S][j][0], ra[S][j][1], h0, m0_, l0);
       split3_pair(ra[S][j][2], ra[S][j][3], h1, m1, l1);
-      char* dst = Ap + buf * BUFSZ + (r0 + RS * j) * XPITCH + kc * 8;
+      const int arow = r0 + RS * j;
+      char* dst = Ap + buf * BUFSZ + arow * XPITCH + (((kc >> 1) ^ xswz(arow)) << 4) + (kc & 1) * 8;
       *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
       *reinterpret_cast<u32x2_t*>(dst + BM * XPITCH) = (u32x2_t){m0_, m1};
       *reinterpret_cast<u32x2_t*>(dst + 2 * BM * XPITCH) = (u32x2_t){l0, l1};
@@ -221,7 +227,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
       if (idx < NBC) {
         const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
         const int row = rem >> 2, c = rem & 3;
-        *reinterpret_cast<u32x4_t*>(Bp + buf * BUFSZ + (pl * BN + row) * XPITCH + c * 16) = rb[S][i];
+        *reinterpret_cast<u32x4_t*>(Bp + buf * BUFSZ + (pl * BN + row) * XPITCH + ((c ^ xswz(row)) << 4)) = rb[S][i];
       }
     }
   };
@@ -237,8 +243,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const char* a_lane = Ap + (wm + lr) * XPITCH + lh * 16;
-  const char* b_lane = Bp + (wn + lr) * XPITCH + lh * 16;
+  const char* a_lane = Ap + (wm + lr) * XPITCH;
+  const char* b_lane = Bp + (wn + lr) * XPITCH;
+  // byte offset of this lane's 16-byte chunk (k = 16 ks + 8 lh ..) inside its row, after the swizzle; wm, wn and the
+  // 32-row sub-tile offsets are multiples of 32, so the swizzle depends on lr only
+  const int koff[2] = {((0 + lh) ^ xswz(lr)) << 4, ((2 + lh) ^ xswz(lr)) << 4};
 
   // All 18 (TM = 2, TN = 1) fragment reads of the slab's two k-steps are issued back to back, then the 24 MFMAs:
   // the MFMAs of k-step 0 start when its nine fragments have landed and cover the flight of k-step 1's.  (Left to
@@ -259,12 +268,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            af[kq][i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (pl * BM + 32 * i) * XPITCH + ks * 32);
+            af[kq][i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (pl * BM + 32 * i) * XPITCH + koff[ks]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            bf[kq][j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (pl * BN + 32 * j) * XPITCH + ks * 32);
+            bf[kq][j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (pl * BN + 32 * j) * XPITCH + koff[ks]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -320,11 +329,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           constexpr int APL[3] = {2, 0, 1}, BPL[3] = {0, 2, 1};
-          af[ks][i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (APL[u] * BM + 32 * i) * XPITCH + ks * 32);
+          af[ks][i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (APL[u] * BM + 32 * i) * XPITCH + koff[ks]);
           if (i == 0) {
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              bf[ks][j][BPL[u]] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (BPL[u] * BN + 32 * j) * XPITCH + ks * 32);
+              bf[ks][j][BPL[u]] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (BPL[u] * BN + 32 * j) * XPITCH + koff[ks]);
           }
           if (ks == 0 && i == 0) __builtin_amdgcn_sched_barrier(0);  // keep the first tile's operands first in the queue
         }
@@ -340,7 +349,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         split3_pair(ra[S][j][2 * hf], ra[S][j][2 * hf + 1], hs[j][hf], ms[j][hf], ls[j][hf]);
       } else if (w < P_AW) {
         const int j = w - P_SPLIT;
-        char* dst = Ap + sbuf * BUFSZ + (r0 + RS * j) * XPITCH + kc * 8;
+        const int arow = r0 + RS * j;
+        char* dst = Ap + sbuf * BUFSZ + arow * XPITCH + (((kc >> 1) ^ xswz(arow)) << 4) + (kc & 1) * 8;
         *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){hs[j][0], hs[j][1]};
         *reinterpret_cast<u32x2_t*>(dst + BM * XPITCH) = (u32x2_t){ms[j][0], ms[j][1]};
         *reinterpret_cast<u32x2_t*>(dst + 2 * BM * XPITCH) = (u32x2_t){ls[j][0], ls[j][1]};
@@ -349,7 +359,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         if ((NBC % NT == 0) || idx < NBC) {
           const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
           const int row = rem >> 2, c = rem & 3;
-          *reinterpret_cast<u32x4_t*>(Bp + sbuf * BUFSZ + (pl * BN + row) * XPITCH + c * 16) = rb[S][i];
+          *reinterpret_cast<u32x4_t*>(Bp + sbuf * BUFSZ + (pl * BN + row) * XPITCH + ((c ^ xswz(row)) << 4)) = rb[S][i];
         }
       } else if (w < P_LA) {
         const int j = w - P_BW;
