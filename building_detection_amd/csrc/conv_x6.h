@@ -14,8 +14,9 @@
 //      thread prefetched into registers one slab ahead; split into the three planes when written to LDS.
 //   B: the weights are split ONCE per launch by split3_weights_kernel into three bf16 planes [n][k] (k
 //      contiguous, zero-padded to whole tiles), so a thread stages one 16-byte chunk per plane, no arithmetic.
-//   LDS: per plane [row][80 bytes] (32 k = 64 B + 16 B pad: ds_read_b128 of 16 rows hits 16 distinct 16-byte
-//      bank groups); fragments are plain row reads for A and B alike (lane (r, h) takes k = 8h..8h+7 of row r).
+//   LDS: per plane [row][64 bytes], the 16-byte chunks of a row XOR-swizzled by the row (XPITCH / xswz below:
+//      conflict-free reads and writes); fragments are plain row reads for A and B alike (lane (r, h) takes
+//      k = 8h..8h+7 of row r).
 //   Per 16-deep k-step a wave (64 x 32 sub-tile) reads 9 fragments and issues 12 MFMAs (0.75 ds_read_b128 per
 //   MFMA; the LDS array saturates at 2).
 #pragma once
