@@ -1031,6 +1031,7 @@ void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false) {
 }
 
 #include "conv_x6.h"
+#include "conv_x6p.h"
 
 int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
   IgemmParams p = p_in;
@@ -1081,7 +1082,9 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
 }
 
 // split the weights into the x6 planes (in `ws`) and run the x6 kernel
-int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void* ws, int num_cus, hipStream_t st) {
+int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH, int KW, void* ws, int num_cus,
+           hipStream_t st) {
+  if (x6p_ok(p, KH, KW)) return run_x6p(p, w, dgrad, Cin, Cout, ws, st);
   const int K = p.K, N = p.Nout;
   p.Kpad = x6_kpad(K);
   p.Npad = x6_npad(N);
@@ -1576,7 +1579,7 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
       p.stats = (float*)stats;
       *tiles_out = (int)sg_cdiv(p.M, BM);
     }
-    return run_x6(p, (const float*)w, false, d->Cin, d->Cout, ws, ctx->num_cus, (hipStream_t)stream);
+    return run_x6(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, (hipStream_t)stream);
   }
   return dispatch_igemm(p, vec, ctx->num_cus, (hipStream_t)stream);
 }
@@ -1676,7 +1679,7 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   }
   p.stats = nullptr;
   const bool vec = (d->Cout % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy);
-  if (x6_ok(p, vec)) return run_x6(p, (const float*)w, true, d->Cin, d->Cout, ws, ctx->num_cus, st);
+  if (x6_ok(p, vec)) return run_x6(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
   {
     dim3 grid((unsigned)sg_cdiv(d->Cout, 32), (unsigned)sg_cdiv(d->Cin, 32), (unsigned)(d->KH * d->KW));
     hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, st, (const float*)w, wt, d->Cin, d->Cout);

@@ -1,0 +1,304 @@
+// "Patch" form of the x6 convolution (conv_x6.h) for 3x3, stride 1, dilation 1, "same" convolutions with 32 or 64
+// reduction channels per tap: the full-resolution entry / decoder / U-Net convolutions.  Included by
+// conv_igemm.hip inside its anonymous namespace, after conv_x6.h.
+//
+// With N = 32..64 output columns the im2col tile of conv_x6_kernel stages - and splits into the three bf16 planes -
+// every input element nine times (once per tap) for 32..64 columns of MFMA work: the VALU split and the LDS
+// traffic, not the matrix pipe, set its rate (65-125 TFLOP/s).  Here a workgroup owns an 8 x 16
+// pixel tile of one image (128 GEMM rows):
+//   * its 10 x 18 x C input patch is loaded and split ONCE into LDS (three planes, [patch row][pixel][C] bf16,
+//     the 16-byte chunks of a pixel XOR-swizzled by the pixel so that the 16 lanes of a ds_read_b128 group - 16
+//     consecutive pixels - hit 16 distinct bank groups; patch rows are padded to a multiple of 256 bytes);
+//   * the nine taps' A fragments are plain reads of that patch at a pixel offset: no staging in the K loop;
+//   * the weights are split once per launch into FRAGMENT-major planes (split3_weights_frag_kernel: for every
+//     16-deep k-step, 32-column block and plane the 64 lanes' 16-byte operands lie contiguous, 1 KB), and each
+//     wave loads its B fragments straight from global memory / L2 into registers, one k-step ahead;
+//   * so the K loop has NO barrier: four waves drift freely, each holding all 128 rows (4 x 32) of one
+//     32-column block.  With BN = 32 / 64 the four waves split K four / two ways (k-step s belongs to wave class
+//     s mod KS) and the partial accumulators are summed through LDS in a fixed order at the end (deterministic);
+//   * per k-step a wave issues 12 ds_read_b128 + 3 global loads for 24 MFMAs, the reads of the next half k-step
+//     in flight under the MFMAs of the current one.
+// Serves forward and dgrad alike (IgemmParams: off = -1, k_mul = +1 / off = +1, k_mul = -1).
+#pragma once
+
+template <int C>
+struct X6P {
+  static constexpr int PB = 2 * C;                        // bytes of one pixel in one plane
+  static constexpr int NCH = PB / 16;                     // 16-byte chunks per pixel (4 / 8)
+  static constexpr int SH = (C == 32) ? 2 : 1;            // log2(pixels per 256 bytes)
+  static constexpr int ROWP = (C == 32) ? 1280 : 2304;    // bytes per patch row: 18 pixels, padded to k * 256
+  static constexpr int PLANE = 10 * ROWP;
+  static constexpr int PATCH = 3 * PLANE;                 // 38,400 / 69,120 bytes
+  __device__ static __forceinline__ int chunk_slot(int chunk, int pc) { return (chunk ^ ((pc >> SH) & (NCH - 1))) << 4; }
+};
+
+// B[k][n] (k = tap*Ck + kk, see split3_weights_kernel) -> fragment-major planes:
+//   out[((ks * NB32 + nb) * 3 + plane) * 512 + lane * 8 + e] = plane of B[ks*16 + (lane>>5)*8 + e][nb*32 + (lane&31)]
+__global__ __launch_bounds__(256) void split3_weights_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int K,
+                                                                  int N, int Ck, int s_tap, int s_k, int s_n) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = (int)(gid & 63);
+  const int64_t f = gid >> 6;
+  const int NB32 = N / 32;
+  if (f >= (int64_t)(K / 16) * NB32) return;
+  const int ks = (int)(f / NB32), nb = (int)(f - (int64_t)ks * NB32);
+  const int n = nb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = k0 + 2 * e + u;
+      const int tap = k / Ck, kk = k - tap * Ck;
+      v[u] = w[(int64_t)tap * s_tap + (int64_t)kk * s_k + (int64_t)n * s_n];
+    }
+    split3_pair(v[0], v[1], h[e], m[e], l[e]);
+  }
+  u32x4_t* o = reinterpret_cast<u32x4_t*>(out + (f * 3) * 512 + lane * 8);
+  o[0] = (u32x4_t){h[0], h[1], h[2], h[3]};
+  o[64] = (u32x4_t){m[0], m[1], m[2], m[3]};   // + 512 ushorts = 64 u32x4
+  o[128] = (u32x4_t){l[0], l[1], l[2], l[3]};
+}
+
+template <int C, int BN>
+__global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, int tiles_x, int tiles_y) {
+  using L = X6P<C>;
+  constexpr int NBLK = BN / 32;     // 32-column blocks of the tile: 1, 2, 4
+  constexpr int KS = 4 / NBLK;      // K classes: 4, 2, 1
+  constexpr int CS = C / 16;        // k-steps per tap
+  constexpr int NKS = 9 * CS;
+  constexpr int NF4 = 180 * C / 4;  // float4 of the patch
+  constexpr int NIT = (NF4 + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 31, lh = lane >> 5;
+  const uint32_t ntn = (uint32_t)p.Nout / BN;
+  const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+  const uint32_t bx = tile_m % (uint32_t)tiles_x, tq = tile_m / (uint32_t)tiles_x;
+  const uint32_t by = tq % (uint32_t)tiles_y, img = tq / (uint32_t)tiles_y;
+
+  // ---- the patch: rows by*8-1 .. by*8+8, columns bx*16-1 .. bx*16+16 of image img, zero outside the image ----
+  {
+    const int y0 = (int)by * 8 - 1, x0 = (int)bx * 16 - 1;
+    const float* xi = p.x + (int64_t)img * p.H * p.W * p.x_ld;
+    f32x4 v[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t + 256 * it;
+      const int pix = idx / (C / 4), c4 = idx - pix * (C / 4);
+      const int pr = pix / 18, pc = pix - pr * 18;
+      const int gy = y0 + pr, gx = x0 + pc;
+      const bool ok = (NF4 % 256 == 0 || idx < NF4) && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (ok) v[it] = *reinterpret_cast<const f32x4*>(xi + ((int64_t)gy * p.W + gx) * p.x_ld + c4 * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = t + 256 * it;
+      if (NF4 % 256 == 0 || idx < NF4) {
+        const int pix = idx / (C / 4), c4 = idx - pix * (C / 4);
+        const int pr = pix / 18, pc = pix - pr * 18;
+        unsigned h0, m0, l0, h1, m1, l1;
+        split3_pair(v[it][0], v[it][1], h0, m0, l0);
+        split3_pair(v[it][2], v[it][3], h1, m1, l1);
+        char* dst = smem + pr * L::ROWP + pc * L::PB + L::chunk_slot(c4 >> 1, pc) + (c4 & 1) * 8;
+        *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
+        *reinterpret_cast<u32x2_t*>(dst + L::PLANE) = (u32x2_t){m0, m1};
+        *reinterpret_cast<u32x2_t*>(dst + 2 * L::PLANE) = (u32x2_t){l0, l1};
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- K loop: no barrier ---------------------------------------------------------------------------------
+  const int nblk = wave % NBLK, kc = wave / NBLK;
+  const int px = lr & 15, pyl = lr >> 4;
+  const int NB32 = p.Nout / 32;
+  const unsigned short* bq = p.wq + ((int64_t)(tile_n * NBLK + nblk) * 3) * 512 + lane * 8;
+  const int64_t bstep = (int64_t)NB32 * 3 * 512;  // ushorts per k-step
+  f32x16 acc[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  auto load_b = [&](int ks, bf16x8_t (&b)[3]) {
+    const unsigned short* q = bq + ks * bstep;
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8_t*>(q + pl * 512);
+  };
+  // byte offset (inside plane 0, row block 0) of this lane's A operand of k-step ks
+  auto a_offset = [&](int ks) -> int {
+    const int tap = ks / CS, cs = ks - tap * CS;
+    const int kh = tap / 3, kw = tap - kh * 3;
+    const int dyr = 1 + p.off_h + kh * p.k_mul, dxr = 1 + p.off_w + kw * p.k_mul;
+    const int q = px + dxr;
+    return (pyl + dyr) * L::ROWP + q * L::PB + L::chunk_slot(cs * 2 + lh, q);
+  };
+  auto read_a = [&](int off, int half, bf16x8_t (&a)[2][3]) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      constexpr int APL[3] = {2, 0, 1};  // consumption order of the planes (a3, a1, a2)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        a[i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(smem + APL[u] * L::PLANE + (2 * half + i) * 2 * L::ROWP + off);
+    }
+  };
+  auto mma_half = [&](int half, bf16x8_t (&a)[2][3], bf16x8_t (&b)[3]) {
+    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+        acc[2 * half + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA_[term]], b[PB_[term]], acc[2 * half + i], 0, 0, 0);
+  };
+
+  {
+    bf16x8_t a0[2][3], a1[2][3], bcur[3], bnxt[3];
+    int ks = kc;
+    int off = a_offset(ks < NKS ? ks : 0);
+    load_b(ks < NKS ? ks : 0, bcur);
+    read_a(off, 0, a0);
+    for (; ks < NKS; ks += KS) {
+      const int kn = (ks + KS < NKS) ? ks + KS : ks;  // the tail re-reads the last step (unused)
+      load_b(kn, bnxt);
+      read_a(off, 1, a1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(0, a0, bcur);
+      __builtin_amdgcn_sched_barrier(0);
+      off = a_offset(kn);
+      read_a(off, 0, a0);
+      __builtin_amdgcn_sched_barrier(0);
+      mma_half(1, a1, bcur);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bcur[pl] = bnxt[pl];
+    }
+  }
+
+  // ---- K classes summed in the fixed order 0 + 1 (+ 2 + 3) through LDS (the patch is dead) ------------------
+  if constexpr (KS > 1) {
+    float* red = reinterpret_cast<float*>(smem);  // [(KS-1) * NBLK][64][64 lanes]
+    __syncthreads();
+    if (kc > 0) {
+      float* dst = red + ((kc - 1) * NBLK + nblk) * 4096 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(i * 16 + r) * 64] = acc[i][r];
+    }
+    __syncthreads();
+    if (kc > 0) return;
+#pragma unroll 1
+    for (int k = 1; k < KS; ++k) {  // (not unrolled: three rounds of 64 reads in flight at once would spill)
+      const float* src = red + ((k - 1) * NBLK + nblk) * 4096 + lane;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] += src[(i * 16 + r) * 64];
+    }
+  }
+
+  // ---- epilogue: this wave holds the tile's 128 rows of its 32 columns -------------------------------------------
+  const int col = (int)tile_n * BN + nblk * 32 + lr;
+  const float bv = (p.flags & SG_EPI_BIAS) ? p.bias[col] : 0.f;
+  const bool do_relu = (p.flags & SG_EPI_RELU) != 0;
+  float* yo = p.y + ((int64_t)img * p.OH * p.OW + (int64_t)by * 8 * p.OW + bx * 16) * p.y_ld + col;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int rb = (r & 3) + 8 * (r >> 2) + 4 * lh;  // row of the 32-row block = pixel (2i + rb/16, rb%16)
+      float v = acc[i][r] + bv;
+      acc[i][r] = v;
+      if (do_relu) v = fmaxf(v, 0.f);
+      yo[((int64_t)(2 * i + (rb >> 4)) * p.OW + (rb & 15)) * p.y_ld] = v;
+    }
+  // BatchNormalization statistics of the tile (see conv_x6_kernel): sum, then centred sum of squares, over its 128 rows
+  if (p.stats) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += acc[i][r];
+    s += __shfl_xor(s, 32, 64);
+    const float mu = s * (1.f / 128.f);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float d = acc[i][r] - mu;
+        q = fmaf(d, d, q);
+      }
+    q += __shfl_xor(q, 32, 64);
+    if (lh == 0) {
+      p.stats[((int64_t)tile_m * 2) * p.Nout + col] = s;
+      p.stats[((int64_t)tile_m * 2 + 1) * p.Nout + col] = q;
+    }
+  }
+}
+
+inline bool x6p_enabled() {
+  static const bool on = getenv("SG_X6_NOPATCH") == nullptr;
+  return on;
+}
+
+// geometry the patch form covers; KH, KW are the filter's (IgemmParams carries only K)
+inline bool x6p_ok(const IgemmParams& p, int KH, int KW) {
+  if (!x6p_enabled() || KH != 3 || KW != 3) return false;
+  if (!(p.C == 32 || p.C == 64) || p.K != 9 * p.C) return false;
+  if (p.a_mul != 1 || p.div != 1) return false;
+  const bool fwd = p.k_mul == 1 && p.off_h == -1 && p.off_w == -1, bwd = p.k_mul == -1 && p.off_h == 1 && p.off_w == 1;
+  if (!fwd && !bwd) return false;
+  if (p.OH != p.H || p.OW != p.W || (p.H % 8) || (p.W % 16)) return false;
+  if (!(p.Nout == 32 || p.Nout == 64 || p.Nout % 128 == 0)) return false;
+  if ((p.x_ld % 4) || (((uintptr_t)p.x) & 15)) return false;
+  return true;
+}
+
+template <int C, int BN>
+int launch_x6p(const IgemmParams& p, hipStream_t st) {
+  constexpr int KS = 4 / (BN / 32), NBLK = BN / 32;
+  constexpr size_t red = (size_t)(KS - 1) * NBLK * 4096 * sizeof(float);
+  constexpr size_t lds = X6P<C>::PATCH > red ? (size_t)X6P<C>::PATCH : red;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = set_dyn_lds(conv_x6p_kernel<C, BN>, lds);
+    if (rc) return rc;
+    attr_done = true;
+  }
+  const int tiles_x = p.OW / 16, tiles_y = p.OH / 8;
+  const int64_t tiles = (int64_t)(p.M / 128) * (p.Nout / BN);
+  if (tiles <= 0 || tiles > 0x7fffffff || (int64_t)(p.M / 128) % ((int64_t)tiles_x * tiles_y) != 0) {
+    sg_set_error("conv_x6p: bad tile count %lld", (long long)tiles);
+    return SG_EINVAL;
+  }
+  hipLaunchKernelGGL((conv_x6p_kernel<C, BN>), dim3((unsigned)tiles), dim3(256), lds, st, p, tiles_x, tiles_y);
+  SG_LAUNCH_CHECK("conv_x6p_kernel");
+  return 0;
+}
+
+// split the weights fragment-major (in `ws`, x6_planes_bytes() is enough) and run the patch kernel
+int run_x6p(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void* ws, hipStream_t st) {
+  const int K = p.K, N = p.Nout;
+  p.wq = (const unsigned short*)ws;
+  const int64_t threads = (int64_t)(K / 16) * (N / 32) * 64;
+  const dim3 grid((unsigned)sg_cdiv(threads, 256));
+  if (!dgrad)
+    hipLaunchKernelGGL(split3_weights_frag_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, Cin, Cin * Cout, Cout, 1);
+  else
+    hipLaunchKernelGGL(split3_weights_frag_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, Cout, Cin * Cout, 1, Cout);
+  SG_LAUNCH_CHECK("split3_weights_frag_kernel");
+  const int bn = N >= 128 ? 128 : N;
+  if (p.C == 32) {
+    if (bn == 32) return launch_x6p<32, 32>(p, st);
+    if (bn == 64) return launch_x6p<32, 64>(p, st);
+    return launch_x6p<32, 128>(p, st);
+  }
+  if (bn == 32) return launch_x6p<64, 32>(p, st);
+  if (bn == 64) return launch_x6p<64, 64>(p, st);
+  return launch_x6p<64, 128>(p, st);
+}

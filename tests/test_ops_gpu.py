@@ -58,6 +58,14 @@ CONV_CASES = [
     (1, 32, 32, 32, 32, 3, 1, 1, "x6_wgrad_c32"),
     (2, 32, 64, 64, 48, 3, 1, 1, "x6_wgrad_c64_cout48"),
     (1, 64, 32, 48, 80, 3, 1, 3, "x6_wgrad_c48_d3"),
+    # LDS-patch x6 kernel (3x3 s1 d1, 32 / 64 reduction channels, H % 8 == 0, W % 16 == 0): every (C, BN) form forward
+    # and dgrad, K split 4 / 2 / 1 ways, image borders on all sides, several column tiles
+    (2, 16, 32, 32, 32, 3, 1, 1, "patch_c32_n32"),
+    (2, 24, 48, 64, 64, 3, 1, 1, "patch_c64_n64"),
+    (1, 16, 16, 64, 32, 3, 1, 1, "patch_c64_n32"),
+    (3, 8, 16, 32, 64, 3, 1, 1, "patch_c32_n64_one_tile"),
+    (1, 8, 32, 64, 128, 3, 1, 1, "patch_c64_n128"),
+    (2, 16, 16, 32, 256, 3, 1, 1, "patch_c32_n256"),
 ]
 
 
@@ -86,20 +94,31 @@ def test_conv2d_fwd_dgrad_wgrad(engine, case):
     close(db, br.grad, what=f"{tag} bias grad")
 
 
-def test_conv2d_into_concat_slice(engine):
+@pytest.mark.parametrize("hw", [(12, 12), (16, 32)], ids=["im2col", "patch"])
+def test_conv2d_into_concat_slice(engine, hw):
     """y_ld / x_ld: a conv writing into (and reading from) a channel slice of a wider buffer."""
     g = torch.Generator().manual_seed(7)
-    x = rnd(g, 2, 12, 12, 64)
+    h, w = hw
+    x = rnd(g, 2, h, w, 64)
     wt = rnd(g, 3, 3, 32, 64) * 0.1
     # input = channels [16,48) of x ; output = channels [64,128) of a 160-wide buffer
     xs = x[..., 16:48].contiguous()
     yr = T.conv2d(xs, wt, None, 1, 1, "same")
     xd = x.cuda()
-    buf = torch.zeros(2, 12, 12, 160, device="cuda")
-    d = engine.conv_desc((2, 12, 12, 32), 64, 3, 3, 1, 1, "same", x_ld=64, y_ld=160)
+    buf = torch.zeros(2, h, w, 160, device="cuda")
+    d = engine.conv_desc((2, h, w, 32), 64, 3, 3, 1, 1, "same", x_ld=64, y_ld=160)
     engine.conv2d_fwd(xd.view(-1)[16:], wt.cuda(), None, out=buf.view(-1)[64:], desc=d)
     close(buf[..., 64:128], yr, what="slice conv")
     assert buf[..., :64].abs().max().item() == 0 and buf[..., 128:].abs().max().item() == 0
+    # dgrad through the same slices: dy = channels [64,128) of the wide buffer, dx into channels [16,48) of a 64-wide one
+    dy = rnd(g, 2, h, w, 64)
+    xr = xs.clone().requires_grad_()
+    T.conv2d(xr, wt, None, 1, 1, "same").backward(dy)
+    buf[..., 64:128] = dy.cuda()
+    dxb = torch.zeros(2, h, w, 64, device="cuda")
+    engine.conv2d_dgrad(buf.view(-1)[64:], wt.cuda(), d, out=dxb.view(-1)[16:])
+    close(dxb[..., 16:48], xr.grad, what="slice dgrad")
+    assert dxb[..., :16].abs().max().item() == 0 and dxb[..., 48:].abs().max().item() == 0
 
 
 @pytest.mark.parametrize("k,tag", [(3, "convT3"), (2, "convT2")])
@@ -504,8 +523,9 @@ def test_x6_at_least_as_accurate_as_native_fp32_mfma(engine, case):
         assert ex <= 1.5 * en + 2e-8, (key, ex, en)
 
 
-@pytest.mark.parametrize("shape", [(2, 32, 32, 256, 728, 1), (3, 20, 32, 64, 96, 3), (1, 32, 32, 128, 40, 3)],
-                         ids=["pw_728", "ragged_rows", "cout40"])
+@pytest.mark.parametrize("shape", [(2, 32, 32, 256, 728, 1), (3, 20, 32, 64, 96, 3), (1, 32, 32, 128, 40, 3),
+                                   (2, 24, 32, 64, 32, 3), (1, 16, 48, 32, 64, 3)],
+                         ids=["pw_728", "ragged_rows", "cout40", "patch_c64_n32", "patch_c32_n64"])
 def test_conv_epilogue_bn_statistics(engine, shape):
     """SG_EPI bn_stats: the per-tile (sum, centred sum of squares) a convolution leaves for the following
     BatchNormalization give the same normalised output, saved statistics and moving statistics as BN's own pass."""
