@@ -1084,7 +1084,7 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
 // split the weights into the x6 planes (in `ws`) and run the x6 kernel
 int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH, int KW, void* ws, int num_cus,
            hipStream_t st) {
-  if (x6p_ok(p, KH, KW)) return run_x6p(p, w, dgrad, Cin, Cout, ws, st);
+  if (x6p_ok(p, KH, KW)) return run_x6p(p, w, dgrad, Cin, Cout, ws, num_cus, st);
   const int K = p.K, N = p.Nout;
   p.Kpad = x6_kpad(K);
   p.Npad = x6_npad(N);

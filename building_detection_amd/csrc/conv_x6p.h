@@ -61,8 +61,17 @@ __global__ __launch_bounds__(256) void split3_weights_frag_kernel(const float* _
   o[128] = (u32x4_t){l[0], l[1], l[2], l[3]};
 }
 
+// Persistent: gridDim.x = (workgroups that fit one CU) x CUs; workgroup g walks tiles g, g + gridDim.x, ...  All
+// tiles cost the same, so workgroups that start together stay in lockstep - every CU's workgroups load their patches
+// together, run their K loops together, store together, and the memory phase and the MFMA phase simply add up
+// (measured: 0.46 ms + 1.42 ms = 1.87 ms on 512x512 64->64).  `delay` (100 MHz ticks) therefore holds back the
+// second (third) workgroup of each CU by one (two) K-loop times at the start; the offset then persists and one
+// workgroup's patch load / epilogue runs under the other's MFMAs.
+__device__ unsigned g_x6p_arrivals[2048];  // per CU: workgroups that have started there (never reset; used modulo)
+
 template <int C, int BN>
-__global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, int tiles_x, int tiles_y, int ntiles, int delay,
+                                                          int wg_per_cu) {
   using L = X6P<C>;
   constexpr int NBLK = BN / 32;     // 32-column blocks of the tile: 1, 2, 4
   constexpr int KS = 4 / NBLK;      // K classes: 4, 2, 1
@@ -70,173 +79,267 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
   constexpr int NKS = 9 * CS;
   constexpr int NF4 = 180 * C / 4;  // float4 of the patch
   constexpr int NIT = (NF4 + 255) / 256;
+  constexpr int RED = (KS > 1) ? 4 * NBLK * (KS - 1) * 4096 : 0;          // bytes of the K-class exchange
+  constexpr int STAT_OFF = (L::PATCH > RED) ? L::PATCH : RED;             // [2][4 waves][32] floats behind it
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int t = threadIdx.x, wave = t >> 6, lane = t & 63, lr = lane & 31, lh = lane >> 5;
+  const int t = threadIdx.x, wave = t >> 6;
+  const int nblk = wave % NBLK, kc = wave / NBLK;
   const uint32_t ntn = (uint32_t)p.Nout / BN;
-  const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-  const uint32_t tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
-  const uint32_t bx = tile_m % (uint32_t)tiles_x, tq = tile_m / (uint32_t)tiles_x;
-  const uint32_t by = tq % (uint32_t)tiles_y, img = tq / (uint32_t)tiles_y;
+  const int NB32 = p.Nout / 32;
+  const int64_t bstep = (int64_t)NB32 * 3 * 512;  // ushorts per k-step of the fragment-major weights
+  const bool do_relu = (p.flags & SG_EPI_RELU) != 0;
 
-  // ---- the patch: rows by*8-1 .. by*8+8, columns bx*16-1 .. bx*16+16 of image img, zero outside the image ----
-  {
-    const int y0 = (int)by * 8 - 1, x0 = (int)bx * 16 - 1;
-    const float* xi = p.x + (int64_t)img * p.H * p.W * p.x_ld;
-    f32x4 v[NIT];
-#pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = t + 256 * it;
-      const int pix = idx / (C / 4), c4 = idx - pix * (C / 4);
-      const int pr = pix / 18, pc = pix - pr * 18;
-      const int gy = y0 + pr, gx = x0 + pc;
-      const bool ok = (NF4 % 256 == 0 || idx < NF4) && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (ok) v[it] = *reinterpret_cast<const f32x4*>(xi + ((int64_t)gy * p.W + gx) * p.x_ld + c4 * 4);
+  if (delay > 0) {  // see above; the phase is the order of arrival on this very CU (HW_ID: CU / SH / SE, XCC_ID)
+    __shared__ int s_phase;
+    if (t == 0) {
+      const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+      s_phase = (int)(atomicAdd(&g_x6p_arrivals[((xcc & 7u) << 8) | ((hw >> 8) & 0xffu)], 1u) % (unsigned)wg_per_cu);
     }
+    __syncthreads();
+    const int phase = s_phase;
+    if (phase > 0) {
+      const uint64_t t0 = __builtin_amdgcn_s_memrealtime(), wait = (uint64_t)phase * (uint64_t)delay;
+      while (__builtin_amdgcn_s_memrealtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+    }
+  }
+
+  for (uint32_t tile = xcd_remap(blockIdx.x, gridDim.x); tile < (uint32_t)ntiles; tile += gridDim.x) {
+    const uint32_t tile_m = tile / ntn, tile_n = tile - tile_m * ntn;
+    const uint32_t bx = tile_m % (uint32_t)tiles_x, tq = tile_m / (uint32_t)tiles_x;
+    const uint32_t by = tq % (uint32_t)tiles_y, img = tq / (uint32_t)tiles_y;
+    // The thread index is laundered once per tile: everything derived from it (the patch chunk arithmetic, the 64
+    // output offsets of the epilogue) is otherwise hoisted out of the tile loop and lives - 150+ registers, spills -
+    // through the K loop.
+    int tl = t;
+    asm volatile("" : "+v"(tl));
+    const int lane = tl & 63, lr = lane & 31, lh = lane >> 5;
+    const int px = lr & 15, pyl = lr >> 4;
+
+    const bool dbg = (p.ablate & 4) != 0;  // timing diagnostics: phase durations into y instead of the result
+    uint64_t ts[6];
+    if (dbg) ts[0] = __builtin_amdgcn_s_memtime();
+    // ---- the patch: rows by*8-1 .. by*8+8, columns bx*16-1 .. bx*16+16 of image img, zero outside the image ----
+    {
+      const int y0 = (int)by * 8 - 1, x0 = (int)bx * 16 - 1;
+      const float* xi = p.x + (int64_t)img * p.H * p.W * p.x_ld;
+      f32x4 v[NIT];
 #pragma unroll
-    for (int it = 0; it < NIT; ++it) {
-      const int idx = t + 256 * it;
-      if (NF4 % 256 == 0 || idx < NF4) {
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tl + 256 * it;
         const int pix = idx / (C / 4), c4 = idx - pix * (C / 4);
         const int pr = pix / 18, pc = pix - pr * 18;
-        unsigned h0, m0, l0, h1, m1, l1;
-        split3_pair(v[it][0], v[it][1], h0, m0, l0);
-        split3_pair(v[it][2], v[it][3], h1, m1, l1);
-        char* dst = smem + pr * L::ROWP + pc * L::PB + L::chunk_slot(c4 >> 1, pc) + (c4 & 1) * 8;
-        *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
-        *reinterpret_cast<u32x2_t*>(dst + L::PLANE) = (u32x2_t){m0, m1};
-        *reinterpret_cast<u32x2_t*>(dst + 2 * L::PLANE) = (u32x2_t){l0, l1};
+        const int gy = y0 + pr, gx = x0 + pc;
+        const bool ok = (NF4 % 256 == 0 || idx < NF4) && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok && !(p.ablate & 2)) v[it] = *reinterpret_cast<const f32x4*>(xi + ((int64_t)gy * p.W + gx) * p.x_ld + c4 * 4);
+      }
+      __syncthreads();  // the previous tile's LDS reads (K loop, K-class exchange, statistics) are done
+      if (dbg) {
+        ts[1] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        ts[2] = __builtin_amdgcn_s_memtime();
+      }
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        const int idx = tl + 256 * it;
+        if (NF4 % 256 == 0 || idx < NF4) {
+          const int pix = idx / (C / 4), c4 = idx - pix * (C / 4);
+          const int pr = pix / 18, pc = pix - pr * 18;
+          unsigned h0, m0, l0, h1, m1, l1;
+          split3_pair(v[it][0], v[it][1], h0, m0, l0);
+          split3_pair(v[it][2], v[it][3], h1, m1, l1);
+          char* dst = smem + pr * L::ROWP + pc * L::PB + L::chunk_slot(c4 >> 1, pc) + (c4 & 1) * 8;
+          *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
+          *reinterpret_cast<u32x2_t*>(dst + L::PLANE) = (u32x2_t){m0, m1};
+          *reinterpret_cast<u32x2_t*>(dst + 2 * L::PLANE) = (u32x2_t){l0, l1};
+        }
       }
     }
-  }
-  __syncthreads();
-
-  // ---- K loop: no barrier ---------------------------------------------------------------------------------
-  const int nblk = wave % NBLK, kc = wave / NBLK;
-  const int px = lr & 15, pyl = lr >> 4;
-  const int NB32 = p.Nout / 32;
-  const unsigned short* bq = p.wq + ((int64_t)(tile_n * NBLK + nblk) * 3) * 512 + lane * 8;
-  const int64_t bstep = (int64_t)NB32 * 3 * 512;  // ushorts per k-step
-  f32x16 acc[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
-  auto load_b = [&](int ks, bf16x8_t (&b)[3]) {
-    const unsigned short* q = bq + ks * bstep;
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8_t*>(q + pl * 512);
-  };
-  // byte offset (inside plane 0, row block 0) of this lane's A operand of k-step ks
-  auto a_offset = [&](int ks) -> int {
-    const int tap = ks / CS, cs = ks - tap * CS;
-    const int kh = tap / 3, kw = tap - kh * 3;
-    const int dyr = 1 + p.off_h + kh * p.k_mul, dxr = 1 + p.off_w + kw * p.k_mul;
-    const int q = px + dxr;
-    return (pyl + dyr) * L::ROWP + q * L::PB + L::chunk_slot(cs * 2 + lh, q);
-  };
-  auto read_a = [&](int off, int half, bf16x8_t (&a)[2][3]) {
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      constexpr int APL[3] = {2, 0, 1};  // consumption order of the planes (a3, a1, a2)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        a[i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(smem + APL[u] * L::PLANE + (2 * half + i) * 2 * L::ROWP + off);
-    }
-  };
-  auto mma_half = [&](int half, bf16x8_t (&a)[2][3], bf16x8_t (&b)[3]) {
-    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
-#pragma unroll
-    for (int term = 0; term < 6; ++term)
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-        acc[2 * half + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA_[term]], b[PB_[term]], acc[2 * half + i], 0, 0, 0);
-  };
-
-  {
-    bf16x8_t a0[2][3], a1[2][3], bcur[3], bnxt[3];
-    int ks = kc;
-    int off = a_offset(ks < NKS ? ks : 0);
-    load_b(ks < NKS ? ks : 0, bcur);
-    read_a(off, 0, a0);
-    for (; ks < NKS; ks += KS) {
-      const int kn = (ks + KS < NKS) ? ks + KS : ks;  // the tail re-reads the last step (unused)
-      load_b(kn, bnxt);
-      read_a(off, 1, a1);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_half(0, a0, bcur);
-      __builtin_amdgcn_sched_barrier(0);
-      off = a_offset(kn);
-      read_a(off, 0, a0);
-      __builtin_amdgcn_sched_barrier(0);
-      mma_half(1, a1, bcur);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int pl = 0; pl < 3; ++pl) bcur[pl] = bnxt[pl];
-    }
-  }
-
-  // ---- K classes summed in the fixed order 0 + 1 (+ 2 + 3) through LDS (the patch is dead) ------------------
-  if constexpr (KS > 1) {
-    float* red = reinterpret_cast<float*>(smem);  // [(KS-1) * NBLK][64][64 lanes]
     __syncthreads();
-    if (kc > 0) {
-      float* dst = red + ((kc - 1) * NBLK + nblk) * 4096 + lane;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) dst[(i * 16 + r) * 64] = acc[i][r];
-    }
-    __syncthreads();
-    if (kc > 0) return;
-#pragma unroll 1
-    for (int k = 1; k < KS; ++k) {  // (not unrolled: three rounds of 64 reads in flight at once would spill)
-      const float* src = red + ((k - 1) * NBLK + nblk) * 4096 + lane;
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][r] += src[(i * 16 + r) * 64];
-    }
-  }
+    if (dbg) ts[3] = __builtin_amdgcn_s_memtime();
 
-  // ---- epilogue: this wave holds the tile's 128 rows of its 32 columns -------------------------------------------
-  const int col = (int)tile_n * BN + nblk * 32 + lr;
-  const float bv = (p.flags & SG_EPI_BIAS) ? p.bias[col] : 0.f;
-  const bool do_relu = (p.flags & SG_EPI_RELU) != 0;
-  float* yo = p.y + ((int64_t)img * p.OH * p.OW + (int64_t)by * 8 * p.OW + bx * 16) * p.y_ld + col;
+    // ---- K loop: no barrier ---------------------------------------------------------------------------------
+    const unsigned short* bq = p.wq + ((int64_t)(tile_n * NBLK + nblk) * 3) * 512 + lane * 8;
+    f32x16 acc[4];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int rb = (r & 3) + 8 * (r >> 2) + 4 * lh;  // row of the 32-row block = pixel (2i + rb/16, rb%16)
-      float v = acc[i][r] + bv;
-      acc[i][r] = v;
-      if (do_relu) v = fmaxf(v, 0.f);
-      yo[((int64_t)(2 * i + (rb >> 4)) * p.OW + (rb & 15)) * p.y_ld] = v;
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+    auto load_b = [&](int ks, bf16x8_t (&b)[3]) {
+      const unsigned short* q = bq + ks * bstep;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8_t*>(q + pl * 512);
+    };
+    // byte offset (inside plane 0, row block 0) of this lane's A operand of k-step ks
+    auto a_offset = [&](int ks) -> int {
+      const int tap = ks / CS, cs = ks - tap * CS;
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int dyr = 1 + p.off_h + kh * p.k_mul, dxr = 1 + p.off_w + kw * p.k_mul;
+      const int q = px + dxr;
+      return (pyl + dyr) * L::ROWP + q * L::PB + L::chunk_slot(cs * 2 + lh, q);
+    };
+    auto read_a = [&](int off, int half, bf16x8_t (&a)[2][3]) {
+#pragma unroll
+      for (int u = 0; u < 3; ++u) {
+        constexpr int APL[3] = {2, 0, 1};  // consumption order of the planes (a3, a1, a2)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          a[i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(smem + APL[u] * L::PLANE + (2 * half + i) * 2 * L::ROWP + off);
+      }
+    };
+    auto mma_half = [&](int half, bf16x8_t (&a)[2][3], bf16x8_t (&b)[3]) {
+      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
+#pragma unroll
+      for (int term = 0; term < 6; ++term)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[2 * half + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA_[term]], b[PB_[term]], acc[2 * half + i], 0, 0, 0);
+    };
+    {
+      // Fully unrolled (NJ <= 18 steps of 12 reads + 24 MFMAs): with a rolled loop the fragment reads are loop-carried
+      // and the compiler waits lgkmcnt(0) before every first MFMA - on the reads it has just issued; straight-line code
+      // gets counted waits, and the B double buffer needs no register copies.
+      constexpr int NJ = (NKS + KS - 1) / KS;
+      constexpr int PD = 2;  // B fragments are fetched PD k-steps ahead (an L2 round trip under load outlasts one k-step)
+      bf16x8_t a[2][2][3], b[PD + 1][3];
+      int off = a_offset(kc);
+#pragma unroll
+      for (int d = 0; d < PD; ++d) {
+        const int kd = kc + d * KS;
+        load_b(kd < NKS ? kd : kc, b[d]);
+      }
+      read_a(off, 0, a[0]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int ks = kc + j * KS;
+        if ((NKS % KS != 0 && j == NJ - 1 && ks >= NKS) || (p.ablate & 1)) continue;  // uniform (ragged K split: C = 32, KS = 4)
+        const int kn = (ks + KS < NKS) ? ks + KS : ks;  // the tail re-reads the last step (unused)
+        if (j + PD < NJ) {
+          const int kp = ks + PD * KS;
+          load_b(kp < NKS ? kp : ks, b[(j + PD) % (PD + 1)]);
+        }
+        read_a(off, 1, a[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(0, a[0], b[j % (PD + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (j + 1 < NJ) {
+          off = a_offset(kn);
+          read_a(off, 0, a[0]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mma_half(1, a[1], b[j % (PD + 1)]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-  // BatchNormalization statistics of the tile (see conv_x6_kernel): sum, then centred sum of squares, over its 128 rows
-  if (p.stats) {
+
+    if (dbg) ts[4] = __builtin_amdgcn_s_memtime();
+    // ---- K classes: 32-row block i of a column block is finalised by the wave of class i % KS, which sums the
+    // classes' partials in the fixed order 0, 1, .. (its own from registers, the others' through LDS; the patch is dead)
+    if constexpr (KS > 1) {
+      float* red = reinterpret_cast<float*>(smem);  // [NBLK][4 blocks][KS - 1 foreign classes][16][64 lanes]
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int own = i % KS;
+        if (kc != own) {
+          float* dst = red + ((nblk * 4 + i) * (KS - 1) + (kc - (kc > own ? 1 : 0))) * 1024 + lane;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dst[r * 64] = acc[i][r];
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int own = i % KS;
+        if (kc == own) {
+          f32x16 tot;
+#pragma unroll
+          for (int k = 0; k < KS; ++k) {
+            f32x16 val;
+            if (k == own) {
+              val = acc[i];
+            } else {
+              const float* src = red + ((nblk * 4 + i) * (KS - 1) + (k - (k > own ? 1 : 0))) * 1024 + lane;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) val[r] = src[r * 64];
+            }
+            if (k == 0) tot = val;
+            else tot += val;
+          }
+          acc[i] = tot;
+        }
+      }
+    }
+
+    // ---- epilogue: each wave stores the blocks it finalised (all four when KS == 1) --------------------------------
+    const int col = (int)tile_n * BN + nblk * 32 + lr;
+    const float bv = (p.flags & SG_EPI_BIAS) ? p.bias[col] : 0.f;
+    float* yo = p.y + ((int64_t)img * p.OH * p.OW + (int64_t)by * 8 * p.OW + bx * 16) * p.y_ld + col;
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) {
+      if (KS == 1 || kc == i % KS) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += acc[i][r];
-    s += __shfl_xor(s, 32, 64);
-    const float mu = s * (1.f / 128.f);
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float d = acc[i][r] - mu;
-        q = fmaf(d, d, q);
+        for (int r = 0; r < 16; ++r) {
+          const int rb = (r & 3) + 8 * (r >> 2) + 4 * lh;  // row of the 32-row block = pixel (2i + rb/16, rb%16)
+          float v = acc[i][r] + bv;
+          acc[i][r] = v;
+          s += v;
+          if (do_relu) v = fmaxf(v, 0.f);
+          if (!dbg) yo[((int64_t)(2 * i + (rb >> 4)) * p.OW + (rb & 15)) * p.y_ld] = v;
+        }
       }
-    q += __shfl_xor(q, 32, 64);
-    if (lh == 0) {
-      p.stats[((int64_t)tile_m * 2) * p.Nout + col] = s;
-      p.stats[((int64_t)tile_m * 2 + 1) * p.Nout + col] = q;
+    }
+    if (dbg) {
+      ts[5] = __builtin_amdgcn_s_memtime();
+      const uint32_t it = (tile - xcd_remap(blockIdx.x, gridDim.x)) / gridDim.x;
+      const uint32_t bb = blockIdx.x, nc = gridDim.x / (uint32_t)wg_per_cu;  // slots 0..31: blocks 0..31, 32..63: their CU mates
+      if (tl == 0 && (bb < 32 || (bb >= nc && bb < nc + 32)) && it < 16) {
+        float* o = p.y + ((int64_t)(bb < 32 ? bb : bb - nc + 32) * 16 + it) * 8;
+        for (int k = 0; k < 5; ++k) o[k] = (float)(ts[k + 1] - ts[k]);
+        o[5] = (float)(ts[3] & 0xffffff);  // K-loop start
+        o[6] = (float)(((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) << 8) | ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xffu));
+        o[7] = (float)(ts[4] & 0xffffff);  // K-loop end
+      }
+    }
+    // BatchNormalization statistics of the tile (see conv_x6_kernel): sum, then centred sum of squares, over its 128
+    // rows; with KS > 1 the rows of a column block are spread over KS waves, combined through LDS in a fixed order
+    if (p.stats) {
+      float* sl = reinterpret_cast<float*>(smem + STAT_OFF);
+      s += __shfl_xor(s, 32, 64);
+      if constexpr (KS > 1) {
+        if (lh == 0) sl[wave * 32 + lr] = s;
+        __syncthreads();
+        s = 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) s += sl[(k * NBLK + nblk) * 32 + lr];
+      }
+      const float mu = s * (1.f / 128.f);
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (KS == 1 || kc == i % KS) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float d = acc[i][r] - mu;
+            q = fmaf(d, d, q);
+          }
+        }
+      }
+      q += __shfl_xor(q, 32, 64);
+      if constexpr (KS > 1) {
+        if (lh == 0) sl[128 + wave * 32 + lr] = q;
+        __syncthreads();
+        q = 0.f;
+#pragma unroll
+        for (int k = 0; k < KS; ++k) q += sl[128 + (k * NBLK + nblk) * 32 + lr];
+      }
+      if (lh == 0 && kc == 0) {
+        p.stats[((int64_t)tile_m * 2) * p.Nout + col] = s;
+        p.stats[((int64_t)tile_m * 2 + 1) * p.Nout + col] = q;
+      }
     }
   }
 }
@@ -260,15 +363,18 @@ inline bool x6p_ok(const IgemmParams& p, int KH, int KW) {
 }
 
 template <int C, int BN>
-int launch_x6p(const IgemmParams& p, hipStream_t st) {
+int launch_x6p(const IgemmParams& p, int num_cus, hipStream_t st) {
   constexpr int KS = 4 / (BN / 32), NBLK = BN / 32;
-  constexpr size_t red = (size_t)(KS - 1) * NBLK * 4096 * sizeof(float);
-  constexpr size_t lds = X6P<C>::PATCH > red ? (size_t)X6P<C>::PATCH : red;
-  static bool attr_done = false;
-  if (!attr_done) {
+  constexpr size_t red = (KS > 1) ? (size_t)4 * NBLK * (KS - 1) * 4096 : 0;
+  constexpr size_t lds = (X6P<C>::PATCH > red ? (size_t)X6P<C>::PATCH : red) + 2 * 4 * 32 * sizeof(float);
+  static int wg_per_cu = 0;
+  if (!wg_per_cu) {
     int rc = set_dyn_lds(conv_x6p_kernel<C, BN>, lds);
     if (rc) return rc;
-    attr_done = true;
+    int nb = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_x6p_kernel<C, BN>, 256, lds);
+    if (e != hipSuccess || nb < 1) nb = 1;
+    wg_per_cu = nb > 4 ? 4 : nb;
   }
   const int tiles_x = p.OW / 16, tiles_y = p.OH / 8;
   const int64_t tiles = (int64_t)(p.M / 128) * (p.Nout / BN);
@@ -276,14 +382,28 @@ int launch_x6p(const IgemmParams& p, hipStream_t st) {
     sg_set_error("conv_x6p: bad tile count %lld", (long long)tiles);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL((conv_x6p_kernel<C, BN>), dim3((unsigned)tiles), dim3(256), lds, st, p, tiles_x, tiles_y);
+  const int64_t slots = (int64_t)num_cus * wg_per_cu;
+  const int64_t grid = tiles < slots ? tiles : slots;
+  // start offset of the CU's 2nd (3rd) workgroup: one K loop of a tile at ~1.1 TFLOP/s per CU (fp32-equivalent), in
+  // 10 ns ticks; only when every workgroup walks at least two tiles (SG_X6P_DELAY overrides, 0 = off)
+  static int dly_env = -2;
+  if (dly_env == -2) dly_env = getenv("SG_X6P_DELAY") ? atoi(getenv("SG_X6P_DELAY")) : -1;
+  int delay = 0;
+  if (grid == slots && wg_per_cu > 1 && tiles >= 2 * slots)
+    delay = dly_env >= 0 ? dly_env : (int)(2.0 * 128 * BN * 9 * C / 1.1e6 * 100.0 + 0.5);
+  hipLaunchKernelGGL((conv_x6p_kernel<C, BN>), dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, (int)tiles, delay, wg_per_cu);
   SG_LAUNCH_CHECK("conv_x6p_kernel");
   return 0;
 }
 
 // split the weights fragment-major (in `ws`, x6_planes_bytes() is enough) and run the patch kernel
-int run_x6p(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void* ws, hipStream_t st) {
+int run_x6p(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void* ws, int num_cus, hipStream_t st) {
   const int K = p.K, N = p.Nout;
+  {
+    static int abl = -1;  // SG_X6P_ABLATE (timing only, results wrong): 1 = no K loop, 2 = no patch loads
+    if (abl < 0) abl = getenv("SG_X6P_ABLATE") ? atoi(getenv("SG_X6P_ABLATE")) & 7 : 0;
+    p.ablate = abl;
+  }
   p.wq = (const unsigned short*)ws;
   const int64_t threads = (int64_t)(K / 16) * (N / 32) * 64;
   const dim3 grid((unsigned)sg_cdiv(threads, 256));
@@ -294,11 +414,11 @@ int run_x6p(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void*
   SG_LAUNCH_CHECK("split3_weights_frag_kernel");
   const int bn = N >= 128 ? 128 : N;
   if (p.C == 32) {
-    if (bn == 32) return launch_x6p<32, 32>(p, st);
-    if (bn == 64) return launch_x6p<32, 64>(p, st);
-    return launch_x6p<32, 128>(p, st);
+    if (bn == 32) return launch_x6p<32, 32>(p, num_cus, st);
+    if (bn == 64) return launch_x6p<32, 64>(p, num_cus, st);
+    return launch_x6p<32, 128>(p, num_cus, st);
   }
-  if (bn == 32) return launch_x6p<64, 32>(p, st);
-  if (bn == 64) return launch_x6p<64, 64>(p, st);
-  return launch_x6p<64, 128>(p, st);
+  if (bn == 32) return launch_x6p<64, 32>(p, num_cus, st);
+  if (bn == 64) return launch_x6p<64, 64>(p, num_cus, st);
+  return launch_x6p<64, 128>(p, num_cus, st);
 }
