@@ -77,13 +77,12 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
   constexpr int KS = 4 / NBLK;      // K classes: 4, 2, 1
   constexpr int CS = C / 16;        // k-steps per tap
   constexpr int NKS = 9 * CS;
-  constexpr int NF4 = 180 * C / 4;  // float4 of the patch
-  constexpr int NIT = (NF4 + 255) / 256;
   constexpr int RED = (KS > 1) ? 4 * NBLK * (KS - 1) * 4096 : 0;          // bytes of the K-class exchange
   constexpr int STAT_OFF = (L::PATCH > RED) ? L::PATCH : RED;             // [2][4 waves][32] floats behind it
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int t = threadIdx.x, wave = t >> 6;
+  const int t = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);  // scalar: K class, k-steps, taps and B addresses stay on the SALU
   const int nblk = wave % NBLK, kc = wave / NBLK;
   const uint32_t ntn = (uint32_t)p.Nout / BN;
   const int NB32 = p.Nout / 32;
@@ -115,24 +114,30 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
     asm volatile("" : "+v"(tl));
     const int lane = tl & 63, lr = lane & 31, lh = lane >> 5;
     const int px = lr & 15, pyl = lr >> 4;
+    int kcl = kc;  // likewise the K class: the per-step scalars (tap, offsets, B addresses) of all unrolled steps would
+    asm volatile("" : "+s"(kcl));  // be hoisted and spill the SGPR file
 
     const bool dbg = (p.ablate & 4) != 0;  // timing diagnostics: phase durations into y instead of the result
     uint64_t ts[6];
     if (dbg) ts[0] = __builtin_amdgcn_s_memtime();
-    // ---- the patch: rows by*8-1 .. by*8+8, columns bx*16-1 .. bx*16+16 of image img, zero outside the image ----
+    // ---- the patch: rows by*8-1 .. by*8+8, columns bx*16-1 .. bx*16+16 of image img, zero outside the image.
+    // A wave pass covers PPW consecutive pixels of one patch row (C/4 lanes per pixel, one float4 each); the
+    // 10 x NPASS (row, pass) slots go round-robin to the four waves, so row and pass - and with them the row's base
+    // address, its bounds test and its LDS row - are scalar, and a lane's share is a few adds per slot.
     {
+      constexpr int LPP = C / 4, PPW = 64 / LPP, NPASS = (18 + PPW - 1) / PPW, NSLOT = 10 * NPASS, SPW = (NSLOT + 3) / 4;
       const int y0 = (int)by * 8 - 1, x0 = (int)bx * 16 - 1;
       const float* xi = p.x + (int64_t)img * p.H * p.W * p.x_ld;
-      f32x4 v[NIT];
+      const int c4 = lane & (LPP - 1), pxl = lane / LPP;
+      f32x4 v[SPW];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int idx = tl + 256 * it;
-        const int pix = idx / (C / 4), c4 = idx - pix * (C / 4);
-        const int pr = pix / 18, pc = pix - pr * 18;
-        const int gy = y0 + pr, gx = x0 + pc;
-        const bool ok = (NF4 % 256 == 0 || idx < NF4) && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-        v[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (ok && !(p.ablate & 2)) v[it] = *reinterpret_cast<const f32x4*>(xi + ((int64_t)gy * p.W + gx) * p.x_ld + c4 * 4);
+      for (int k = 0; k < SPW; ++k) {
+        const int slot = wave + 4 * k;  // uniform
+        const int pr = slot / NPASS, ps = slot - pr * NPASS;
+        const int pc = ps * PPW + pxl, gy = y0 + pr, gx = x0 + pc;
+        const bool ok = (NSLOT % 4 == 0 || slot < NSLOT) && pc < 18 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+        v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok && !(p.ablate & 2)) v[k] = *reinterpret_cast<const f32x4*>(xi + ((int64_t)gy * p.W + gx) * p.x_ld + c4 * 4);
       }
       __syncthreads();  // the previous tile's LDS reads (K loop, K-class exchange, statistics) are done
       if (dbg) {
@@ -141,14 +146,14 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
         ts[2] = __builtin_amdgcn_s_memtime();
       }
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) {
-        const int idx = tl + 256 * it;
-        if (NF4 % 256 == 0 || idx < NF4) {
-          const int pix = idx / (C / 4), c4 = idx - pix * (C / 4);
-          const int pr = pix / 18, pc = pix - pr * 18;
+      for (int k = 0; k < SPW; ++k) {
+        const int slot = wave + 4 * k;
+        const int pr = slot / NPASS, ps = slot - pr * NPASS;
+        const int pc = ps * PPW + pxl;
+        if ((NSLOT % 4 == 0 || slot < NSLOT) && pc < 18) {
           unsigned h0, m0, l0, h1, m1, l1;
-          split3_pair(v[it][0], v[it][1], h0, m0, l0);
-          split3_pair(v[it][2], v[it][3], h1, m1, l1);
+          split3_pair(v[k][0], v[k][1], h0, m0, l0);
+          split3_pair(v[k][2], v[k][3], h1, m1, l1);
           char* dst = smem + pr * L::ROWP + pc * L::PB + L::chunk_slot(c4 >> 1, pc) + (c4 & 1) * 8;
           *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
           *reinterpret_cast<u32x2_t*>(dst + L::PLANE) = (u32x2_t){m0, m1};
@@ -167,10 +172,12 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-    auto load_b = [&](int ks, bf16x8_t (&b)[3]) {
+    // (B fragments are kept as integer vectors: bf16 vectors that cross the conditional steps are rebuilt element
+    // by element - 24 shift / permute instructions per k-step)
+    auto load_b = [&](int ks, u32x4_t (&b)[3]) {
       const unsigned short* q = bq + ks * bstep;
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const bf16x8_t*>(q + pl * 512);
+      for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4_t*>(q + pl * 512);
     };
     // byte offset (inside plane 0, row block 0) of this lane's A operand of k-step ks
     auto a_offset = [&](int ks) -> int {
@@ -189,13 +196,14 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
           a[i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(smem + APL[u] * L::PLANE + (2 * half + i) * 2 * L::ROWP + off);
       }
     };
-    auto mma_half = [&](int half, bf16x8_t (&a)[2][3], bf16x8_t (&b)[3]) {
+    auto mma_half = [&](int half, bf16x8_t (&a)[2][3], u32x4_t (&b)[3]) {
       constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
 #pragma unroll
       for (int term = 0; term < 6; ++term)
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-          acc[2 * half + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA_[term]], b[PB_[term]], acc[2 * half + i], 0, 0, 0);
+          acc[2 * half + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA_[term]], __builtin_bit_cast(bf16x8_t, b[PB_[term]]),
+                                                                      acc[2 * half + i], 0, 0, 0);
     };
     {
       // Fully unrolled (NJ <= 18 steps of 12 reads + 24 MFMAs): with a rolled loop the fragment reads are loop-carried
@@ -203,18 +211,22 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
       // gets counted waits, and the B double buffer needs no register copies.
       constexpr int NJ = (NKS + KS - 1) / KS;
       constexpr int PD = 2;  // B fragments are fetched PD k-steps ahead (an L2 round trip under load outlasts one k-step)
-      bf16x8_t a[2][2][3], b[PD + 1][3];
-      int off = a_offset(kc);
+      bf16x8_t a[2][2][3];
+      u32x4_t b[PD + 1][3];
+      int off = a_offset(kcl);
 #pragma unroll
       for (int d = 0; d < PD; ++d) {
-        const int kd = kc + d * KS;
-        load_b(kd < NKS ? kd : kc, b[d]);
+        const int kd = kcl + d * KS;
+        load_b(kd < NKS ? kd : kcl, b[d]);
       }
       read_a(off, 0, a[0]);
+      // (no branch inside the unrolled steps other than the ragged last one: across basic blocks the counted waits
+      // degrade to lgkmcnt(0) again)
+      if (!(p.ablate & 1))
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int ks = kc + j * KS;
-        if ((NKS % KS != 0 && j == NJ - 1 && ks >= NKS) || (p.ablate & 1)) continue;  // uniform (ragged K split: C = 32, KS = 4)
+        const int ks = kcl + j * KS;
+        if (NKS % KS != 0 && j == NJ - 1 && ks >= NKS) continue;  // uniform (ragged K split: C = 32, KS = 4)
         const int kn = (ks + KS < NKS) ? ks + KS : ks;  // the tail re-reads the last step (unused)
         if (j + PD < NJ) {
           const int kp = ks + PD * KS;
