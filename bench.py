@@ -11,7 +11,10 @@ Prints ONE JSON line on rank 0.  Extra objects:
   roofline     the north_star target kernel set = the six dilated 3x3 convs (3 ASPP + 3 SK branches) fwd +
                dgrad + wgrad: algorithmic FLOPs (nominal 2*M*N*K, SURVEY §8d: 97.84 GFLOP/tile) divided by
                their summed device time, measured with HIP events on the launch stream inside the timed
-               steps; peak = 157.3 TFLOP/s (fp32-in MFMA, MI355X_MICROARCH.md).
+               steps; peak = 2500/6 TFLOP/s on the x6 path (six bf16 MFMA passes per fp32 product), 157.3 with
+               SG_CONV_X6=0.  roofline.family: the same figure over EVERY GEMM-convolution launch of the step
+               (all of the model's conv FLOPs / their summed device time), from two extra steps after the timed
+               region so that its ~600 event pairs do not sit inside the headline number.
   cpu_baseline the CPU oracle (restatement of the TF2 path; TF itself is unavailable) timed on this box's
                host cores for the same step at a reduced batch.
 """
@@ -144,6 +147,13 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof = eng.profile_end()
+    # outside the timed region: two more steps with EVERY GEMM-convolution launch bracketed (the whole kernel family)
+    fam = {}
+    if rank == 0:
+        eng.profile_begin(all_convs=True)
+        for _ in range(2):
+            model.train_on_batch(xd, yd, return_device_scalars=True)
+        fam = eng.profile_end()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -194,6 +204,13 @@ def main():
                          "kernel": ("conv_x6_kernel / wgrad_x6_kernel" if x6 else "igemm_conv_kernel / igemm_wgrad_kernel") + " on the 6 dilated 3x3 convs (fwd+dgrad+wgrad)",
                          "ms_per_step": round(dil_ms, 3), "launches_per_step": prof.get("dilated_conv_launches", 0) // max(args.steps, 1)},
         }
+        fam_ms = fam.get("gemm_conv", 0.0) / 2
+        if fam_ms > 0:  # every convolution / pointwise / transposed-convolution GEMM launch of the step, same peak
+            out["roofline"]["family"] = {
+                "kernel": "all GEMM convolution launches of the step (conv_x6 / conv_x6p / wgrad_x6 / thin kernels + their weight-split "
+                          "and split-K reduce helpers), measured in 2 extra steps after the timed region",
+                "achieved": round(step_tflop / (fam_ms / 1e3), 2), "frac": round(step_tflop / (fam_ms / 1e3) / peak, 4),
+                "ms_per_step": round(fam_ms, 3), "launches_per_step": fam.get("gemm_conv_launches", 0) // 2}
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             try:

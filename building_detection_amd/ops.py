@@ -96,11 +96,18 @@ class Engine:
         return C.c_void_p(self._ws.data_ptr()), C.c_size_t(self._ws.numel())
 
     # -- in-run timing of tagged launches with HIP events recorded on the launch stream (bench.py roofline) --
-    def profile_begin(self):
+    def profile_begin(self, all_convs=False):
+        """all_convs: every GEMM-convolution launch (conv2d_fwd / dgrad / wgrad: Conv2D, SeparableConv pointwise,
+        Conv2DTranspose) is bracketed under the tag "gemm_conv" as well (bench.py's whole-family figure)."""
         self._prof = {}
+        self._prof_all = bool(all_convs)
+
+    def _gemm_tag(self):
+        return "gemm_conv" if getattr(self, "_prof_all", False) and getattr(self, "_prof", None) is not None else None
 
     def profile_end(self):
         prof, self._prof = getattr(self, "_prof", None) or {}, None
+        self._prof_all = False
         torch.cuda.synchronize(self.device)
         out = {}
         for tag, evs in prof.items():
@@ -143,11 +150,13 @@ class Engine:
         if want_stats:
             st = self.empty(self.lib.sg_conv2d_fwd_stats_bytes(C.byref(d)) // 4)
             tiles = C.c_int(0)
-            check(self.lib.sg_conv2d_fwd_stats(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y),
-                                               flags, wsp, wsn, _ptr(st), C.byref(tiles)), "sg_conv2d_fwd_stats")
+            with self.timed(self._gemm_tag()):
+                check(self.lib.sg_conv2d_fwd_stats(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y),
+                                                   flags, wsp, wsn, _ptr(st), C.byref(tiles)), "sg_conv2d_fwd_stats")
             return y, ((st, tiles.value) if tiles.value > 0 else None)
-        check(self.lib.sg_conv2d_fwd_ws(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags,
-                                        wsp, wsn), "sg_conv2d_fwd_ws")
+        with self.timed(self._gemm_tag()):
+            check(self.lib.sg_conv2d_fwd_ws(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags,
+                                            wsp, wsn), "sg_conv2d_fwd_ws")
         return y
 
     def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None):
@@ -157,8 +166,9 @@ class Engine:
         need = self.lib.sg_conv2d_dgrad_ws_bytes(C.byref(d))
         wsp, wsn = self.ws(need)
         flags = (_lib.SG_EPI_BIAS if bias is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
-        check(self.lib.sg_conv2d_dgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
-                                       flags, wsp, wsn), "sg_conv2d_dgrad")
+        with self.timed(self._gemm_tag()):
+            check(self.lib.sg_conv2d_dgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
+                                           flags, wsp, wsn), "sg_conv2d_dgrad")
         return dx
 
     def conv2d_wgrad(self, x, dy, d: ConvDesc, want_bias=True, dw=None, db=None):
@@ -169,8 +179,9 @@ class Engine:
             db = self.empty(d.Cout)
         need = self.lib.sg_conv2d_wgrad_ws_bytes(self.h, C.byref(d))
         wsp, wsn = self.ws(need)
-        check(self.lib.sg_conv2d_wgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
-                                       _ptr(db) if want_bias else None, wsp, wsn), "sg_conv2d_wgrad")
+        with self.timed(self._gemm_tag()):
+            check(self.lib.sg_conv2d_wgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+                                           _ptr(db) if want_bias else None, wsp, wsn), "sg_conv2d_wgrad")
         return dw, (db if want_bias else None)
 
     def bias_grad(self, dy, db):
