@@ -68,6 +68,10 @@ __global__ __launch_bounds__(256) void seg_finalize_kernel(const Op op, const in
 #pragma unroll
   for (int o = 0; o < NO; ++o) s[o] = 0.0;
   if (c < C) {
+    // unrolled for the narrow ops so that the partial rows' loads are in flight together (the adds stay in order): BN
+    // backward's finalize 15 -> 6 us; with NOUT = 9 (depthwise wgrad) the same unroll spills and runs 5x slower
+    constexpr int UNROLL = NO <= 2 ? 8 : 1;
+#pragma unroll UNROLL
     for (int z = zl; z < S; z += 4) {
       const float* p = part + (((int64_t)seg * S + z) * NO) * C + c;
 #pragma unroll
