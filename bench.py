@@ -148,12 +148,15 @@ def main():
     dt = time.perf_counter() - t0
     prof = eng.profile_end()
     # outside the timed region: two more steps with EVERY GEMM-convolution launch bracketed (the whole kernel family)
+    # (every rank runs them - the data-parallel step all-reduces - but only rank 0 brackets its launches)
     fam = {}
     if rank == 0:
         eng.profile_begin(all_convs=True)
-        for _ in range(2):
-            model.train_on_batch(xd, yd, return_device_scalars=True)
+    for _ in range(2):
+        model.train_on_batch(xd, yd, return_device_scalars=True)
+    if rank == 0:
         fam = eng.profile_end()
+    sync()
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
