@@ -61,12 +61,12 @@ __global__ __launch_bounds__(256) void split3_weights_frag_kernel(const float* _
   o[128] = (u32x4_t){l[0], l[1], l[2], l[3]};
 }
 
-// Persistent: gridDim.x = (workgroups that fit one CU) x CUs; workgroup g walks tiles g, g + gridDim.x, ...  All
-// tiles cost the same, so workgroups that start together stay in lockstep - every CU's workgroups load their patches
-// together, run their K loops together, store together, and the memory phase and the MFMA phase simply add up
-// (measured: 0.46 ms + 1.42 ms = 1.87 ms on 512x512 64->64).  `delay` (100 MHz ticks) therefore holds back the
-// second (third) workgroup of each CU by one (two) K-loop times at the start; the offset then persists and one
-// workgroup's patch load / epilogue runs under the other's MFMAs.
+// Persistent: gridDim.x = (workgroups that fit one CU) x CUs; workgroup g walks tiles g, g + gridDim.x, ...
+// The timing-only ablations add up (512x512 64->64: 0.46 ms without the K loop + 1.42 ms without the patch loads =
+// the 1.87 ms of the whole), which looked like the workgroups of a CU marching in lockstep.  `delay` (100 MHz ticks,
+// SG_X6P_DELAY, default 0) holds back the second (third) workgroup of each CU at the start to test that picture: it
+// changed nothing - the in-kernel clocks (SG_X6P_ABLATE=4) show CU mates already out of phase, a lone K loop at ~60 %
+// of the pipe and overlapped ones barely slower.
 __device__ unsigned g_x6p_arrivals[2048];  // per CU: workgroups that have started there (never reset; used modulo)
 
 template <int C, int BN>
@@ -196,15 +196,6 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
           a[i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(smem + APL[u] * L::PLANE + (2 * half + i) * 2 * L::ROWP + off);
       }
     };
-    auto mma_half = [&](int half, bf16x8_t (&a)[2][3], u32x4_t (&b)[3]) {
-      constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
-#pragma unroll
-      for (int term = 0; term < 6; ++term)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          acc[2 * half + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA_[term]], __builtin_bit_cast(bf16x8_t, b[PB_[term]]),
-                                                                      acc[2 * half + i], 0, 0, 0);
-    };
     {
       // Fully unrolled (NJ <= 18 steps of 12 reads + 24 MFMAs): with a rolled loop the fragment reads are loop-carried
       // and the compiler waits lgkmcnt(0) before every first MFMA - on the reads it has just issued; straight-line code
@@ -220,29 +211,49 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
         load_b(kd < NKS ? kd : kcl, b[d]);
       }
       read_a(off, 0, a[0]);
-      // (no branch inside the unrolled steps other than the ragged last one: across basic blocks the counted waits
-      // degrade to lgkmcnt(0) again)
+      // One piece of the next operands per MFMA, fenced, as in conv_x6_kernel's fused step: a wave issues in order, so
+      // whatever follows a run of MFMAs starts only when the last of them has issued and must fit its 32 cycles or
+      // the pipe idles; one read / load / address piece after each MFMA hides under that MFMA instead.  Half 0 carries
+      // the six A reads of half 1 and the three B loads of step j + PD, half 1 the address of step j + 1 and its
+      // first six A reads.  (No branch inside the unrolled steps other than the ragged last one: across basic blocks
+      // the counted waits degrade to lgkmcnt(0) again.)
+      auto read_a_piece = [&](int o, int half, int q, bf16x8_t (&fr)[2][3]) {
+        constexpr int APL[3] = {2, 0, 1};
+        const int u = q >> 1, i = q & 1;
+        fr[i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(smem + APL[u] * L::PLANE + (2 * half + i) * 2 * L::ROWP + o);
+      };
+      auto mfma_one = [&](int half, int m, bf16x8_t (&fr)[2][3], u32x4_t (&bb)[3]) {
+        constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
+        const int term = m >> 1, i = m & 1;
+        acc[2 * half + i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[i][PA_[term]], __builtin_bit_cast(bf16x8_t, bb[PB_[term]]),
+                                                                    acc[2 * half + i], 0, 0, 0);
+      };
       if (!(p.ablate & 1))
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int ks = kcl + j * KS;
         if (NKS % KS != 0 && j == NJ - 1 && ks >= NKS) continue;  // uniform (ragged K split: C = 32, KS = 4)
         const int kn = (ks + KS < NKS) ? ks + KS : ks;  // the tail re-reads the last step (unused)
-        if (j + PD < NJ) {
-          const int kp = ks + PD * KS;
-          load_b(kp < NKS ? kp : ks, b[(j + PD) % (PD + 1)]);
+        const int kp = (ks + PD * KS < NKS) ? ks + PD * KS : ks;
+        const unsigned short* qb = bq + kp * bstep;
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+          mfma_one(0, m, a[0], b[j % (PD + 1)]);
+          if (m < 6) read_a_piece(off, 1, m, a[1]);
+          else if (m < 9 && j + PD < NJ) b[(j + PD) % (PD + 1)][m - 6] = *reinterpret_cast<const u32x4_t*>(qb + (m - 6) * 512);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        read_a(off, 1, a[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(0, a[0], b[j % (PD + 1)]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (j + 1 < NJ) {
-          off = a_offset(kn);
-          read_a(off, 0, a[0]);
+        int offn = off;
+#pragma unroll
+        for (int m = 0; m < 12; ++m) {
+          mfma_one(1, m, a[1], b[j % (PD + 1)]);
+          if (j + 1 < NJ) {
+            if (m == 0) offn = a_offset(kn);
+            else if (m <= 6) read_a_piece(offn, 0, m - 1, a[0]);
+          }
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);
-        mma_half(1, a[1], b[j % (PD + 1)]);
-        __builtin_amdgcn_sched_barrier(0);
+        off = offn;
       }
     }
 
@@ -396,13 +407,14 @@ int launch_x6p(const IgemmParams& p, int num_cus, hipStream_t st) {
   }
   const int64_t slots = (int64_t)num_cus * wg_per_cu;
   const int64_t grid = tiles < slots ? tiles : slots;
-  // start offset of the CU's 2nd (3rd) workgroup: one K loop of a tile at ~1.1 TFLOP/s per CU (fp32-equivalent), in
-  // 10 ns ticks; only when every workgroup walks at least two tiles (SG_X6P_DELAY overrides, 0 = off)
+  // Experiment switch, default OFF (measured: no effect, the workgroups of a CU are not in lockstep): SG_X6P_DELAY = start
+  // offset of the CU's 2nd (3rd) workgroup in 10 ns ticks (-1: one K loop of a tile at ~1.1 TFLOP/s per CU); only when
+  // every workgroup walks at least two tiles
   static int dly_env = -2;
-  if (dly_env == -2) dly_env = getenv("SG_X6P_DELAY") ? atoi(getenv("SG_X6P_DELAY")) : -1;
+  if (dly_env == -2) dly_env = getenv("SG_X6P_DELAY") ? atoi(getenv("SG_X6P_DELAY")) : 0;
   int delay = 0;
-  if (grid == slots && wg_per_cu > 1 && tiles >= 2 * slots)
-    delay = dly_env >= 0 ? dly_env : (int)(2.0 * 128 * BN * 9 * C / 1.1e6 * 100.0 + 0.5);
+  if (dly_env != 0 && grid == slots && wg_per_cu > 1 && tiles >= 2 * slots)
+    delay = dly_env > 0 ? dly_env : (int)(2.0 * 128 * BN * 9 * C / 1.1e6 * 100.0 + 0.5);
   hipLaunchKernelGGL((conv_x6p_kernel<C, BN>), dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, (int)tiles, delay, wg_per_cu);
   SG_LAUNCH_CHECK("conv_x6p_kernel");
   return 0;
