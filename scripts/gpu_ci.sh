@@ -44,6 +44,11 @@ for s in $STAGES; do
            run_stage pmc_mfma 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- python3 scripts/dilated_bench.py
            run_stage pmc_lds 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d "$OUT/pmc_lds" -- python3 scripts/dilated_bench.py
            unset ONLY_DILATED ITERS ;;
+    pmc3)  # the same counters over the LDS-patch kernel (scripts/patch_bench.py, one timed iteration per launch)
+           export ITERS=1
+           run_stage pmc_mfma 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- python3 scripts/patch_bench.py
+           run_stage pmc_lds 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d "$OUT/pmc_lds" -- python3 scripts/patch_bench.py
+           unset ITERS ;;
     full)  run_stage full 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -s -p no:cacheprovider ;;
     infer) run_stage infer 600 python scripts/bench_infer.py ;;
     census) run_stage census 600 python scripts/conv_census.py ;;

@@ -11,6 +11,7 @@ import sys
 from collections import defaultdict
 
 src, dst = sys.argv[1], sys.argv[2]
+bench = sys.argv[3] if len(sys.argv) > 3 else "scripts/dilated_bench.py (ONLY_DILATED=1 ITERS=1)"
 SIMDS = 256 * 4
 agg = defaultdict(lambda: defaultdict(float))
 calls = defaultdict(int)
@@ -19,14 +20,15 @@ for sub in ("pmc_mfma", "pmc_lds"):
     seen = set()
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        fam = "x6_fwd_dgrad" if "conv_x6_kernel" in k else "x6_wgrad" if "wgrad_x6_kernel" in k else None
+        fam = ("x6_fwd_dgrad" if "conv_x6_kernel" in k else "x6_wgrad" if "wgrad_x6_kernel" in k
+               else "x6_patch" if "conv_x6p_kernel" in k else None)
         if fam is None:
             continue
         agg[fam][r["Counter_Name"]] += float(r["Counter_Value"])
         if sub == "pmc_mfma" and r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r["Dispatch_Id"] not in seen:
             seen.add(r["Dispatch_Id"])
             calls[fam] += 1
-out = {"source": f"{src}/pmc_mfma + pmc_lds: rocprofv3 --kernel-trace --pmc ... -- python3 scripts/dilated_bench.py (ONLY_DILATED=1 ITERS=1)",
+out = {"source": f"{src}/pmc_mfma + pmc_lds: rocprofv3 --kernel-trace --pmc ... -- python3 {bench}",
        "note": "MFMA busy share = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 1024 SIMDs); LDS conflict share = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE",
        "kernels": {}}
 for fam, c in agg.items():
