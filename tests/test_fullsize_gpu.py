@@ -121,3 +121,44 @@ def test_full_size_512_bs16(engine, name, oracle_fn):
     assert abs(fd0 - gd) <= 0.05 * max(abs(gd), abs(fd0)) + 1e-6, (fds, fd0, gd)
     del g1, g2, d, w0, f0
     torch.cuda.empty_cache()
+
+
+# Convolution kernels at the BASELINE sizes through identities that hold for any size: forward, dgrad and wgrad are the
+# three faces of one trilinear form, <conv(x; w), dy> = <x, dgrad(dy; w)> = <w, wgrad(x, dy)> (exact in real arithmetic;
+# fp32 kernels + fp64 inner products agree to ~1e-6).  One case per kernel family of the DeepLabv3+ step.
+ADJ = [
+    ("aspp_d12_2048_256", 16, 32, 2048, 256, 3, 12),   # the north_star dilated conv: conv_x6_kernel / wgrad_x6_kernel
+    ("middle_pw_728", 16, 32, 728, 728, 1, 1),        # the 48 pointwise GEMMs of the middle flow
+    ("decoder_512_64_64", 16, 512, 64, 64, 3, 1),     # LDS-patch kernel (forward + dgrad), x6 wgrad with tiles spanning taps
+    ("decoder_512_64_32", 8, 512, 64, 32, 3, 1),      # patch kernel with the four-way K split (N = 32)
+]
+
+
+@pytest.mark.parametrize("case", ADJ, ids=[c[0] for c in ADJ])
+def test_conv_trilinear_identities_full_size(engine, case):
+    _, n, hw, cin, cout, k, dil = case
+    torch.cuda.empty_cache()
+    g = torch.Generator(device="cuda").manual_seed(hw + cin)
+    x = torch.rand(n, hw, hw, cin, generator=g, device="cuda") * 2 - 1
+    w = (torch.rand(k, k, cin, cout, generator=g, device="cuda") * 2 - 1) * (1.0 / np.sqrt(k * k * cin))
+    d = engine.conv_desc(tuple(x.shape), cout, k, k, 1, dil, "same")
+    y = engine.conv2d_fwd(x, w, None, desc=d)
+    dy = torch.rand(*y.shape, generator=g, device="cuda") * 2 - 1
+    dx = engine.conv2d_dgrad(dy, w, d)
+    dw, _ = engine.conv2d_wgrad(x, dy, d, want_bias=False)
+
+    def dot(a, b):  # fp64 inner product in chunks (the tensors are up to 1 GiB)
+        a, b = a.reshape(-1), b.reshape(-1)
+        s = 0.0
+        for i in range(0, a.numel(), 1 << 26):
+            s += float((a[i:i + (1 << 26)].double() * b[i:i + (1 << 26)].double()).sum().item())
+        return s
+
+    t_y, t_x, t_w = dot(y, dy), dot(x, dx), dot(w, dw)
+    scale = float(y.double().norm().item() * dy.double().norm().item())
+    print(f"{case[0]}: <y,dy> {t_y:.9e}  <x,dx> {t_x:.9e}  <w,dw> {t_w:.9e}  (|y||dy| = {scale:.3e})")
+    assert abs(t_y - t_x) <= 2e-6 * scale and abs(t_y - t_w) <= 2e-6 * scale
+    # and run-to-run bit-identity of all three (fixed-order split-K and K-class sums, no float atomics)
+    assert torch.equal(engine.conv2d_fwd(x, w, None, desc=d), y)
+    assert torch.equal(engine.conv2d_dgrad(dy, w, d), dx)
+    assert torch.equal(engine.conv2d_wgrad(x, dy, d, want_bias=False)[0], dw)
