@@ -119,7 +119,11 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
 
     const bool dbg = (p.ablate & 4) != 0;  // timing diagnostics: phase durations into y instead of the result
     uint64_t ts[6];
-    if (dbg) ts[0] = __builtin_amdgcn_s_memtime();
+    uint64_t rt0 = 0;
+    if (dbg) {
+      ts[0] = __builtin_amdgcn_s_memtime();
+      rt0 = __builtin_amdgcn_s_memrealtime();
+    }
     // ---- the patch: rows by*8-1 .. by*8+8, columns bx*16-1 .. bx*16+16 of image img, zero outside the image.
     // A wave pass covers PPW consecutive pixels of one patch row (C/4 lanes per pixel, one float4 each); the
     // 10 x NPASS (row, pass) slots go round-robin to the four waves, so row and pass - and with them the row's base
@@ -320,11 +324,12 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
       const uint32_t it = (tile - xcd_remap(blockIdx.x, gridDim.x)) / gridDim.x;
       const uint32_t bb = blockIdx.x, nc = gridDim.x / (uint32_t)wg_per_cu;  // slots 0..31: blocks 0..31, 32..63: their CU mates
       if (tl == 0 && (bb < 32 || (bb >= nc && bb < nc + 32)) && it < 16) {
-        float* o = p.y + ((int64_t)(bb < 32 ? bb : bb - nc + 32) * 16 + it) * 8;
+        float* o = p.y + ((int64_t)(bb < 32 ? bb : bb - nc + 32) * 16 + it) * 12;
         for (int k = 0; k < 5; ++k) o[k] = (float)(ts[k + 1] - ts[k]);
         o[5] = (float)(ts[3] & 0xffffff);  // K-loop start
         o[6] = (float)(((__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u) << 8) | ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 8) & 0xffu));
         o[7] = (float)(ts[4] & 0xffffff);  // K-loop end
+        o[8] = (float)(__builtin_amdgcn_s_memrealtime() - rt0);  // the tile in 10 ns ticks: shader clock = cycles / ticks x 100 MHz
       }
     }
     // BatchNormalization statistics of the tile (see conv_x6_kernel): sum, then centred sum of squares, over its 128

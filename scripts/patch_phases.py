@@ -21,7 +21,7 @@ for h, cin, cout in [(512, 64, 64), (512, 32, 32), (512, 64, 32)]:
     torch.cuda.synchronize()
     e.conv2d_fwd(x, w, None, desc=d, out=y)
     torch.cuda.synchronize()
-    t = y.view(-1)[: 64 * 16 * 8].view(64, 16, 8).cpu()
+    t = y.view(-1)[: 64 * 16 * 12].view(64, 16, 12).cpu()
     names = ["top->barrier", "loads landed", "split+write+bar", "K loop", "exchange+epilogue"]
     print(f"{h}x{h} {cin}->{cout}: shader-clock cycles per phase (mean over 64 workgroups), tiles 0, 1, 2, 8, 15")
     for k, nm in enumerate(names):
@@ -37,5 +37,7 @@ for h, cin, cout in [(512, 64, 64), (512, 32, 32), (512, 64, 32)]:
             print(f"  CU key {cu:#x}: " + " | ".join(f"WG{b}: " + " ".join(f"[{(int(t[b, i, 5]) - base) % (1 << 24)}..{(int(t[b, i, 7]) - base) % (1 << 24)}]" for i in (4, 5, 6)) for b in bs))
             shown += 1
     print(f"  CUs seen: {len(by_cu)} for 64 workgroups")
+    clk = (t[:, 1:, :5].sum(-1) / t[:, 1:, 8].clamp(min=1)).median().item() * 100.0  # MHz
+    print(f"  shader clock inside the kernel: {clk:.0f} MHz (cycles per tile / 10 ns ticks per tile, median)")
     tot = t[:, 1:, :5].sum(-1).mean().item()
     print(f"  per tile (steady) {tot:.0f} cycles; start stamps of WG0..3 tile 1: {[int(t[b, 1, 5]) for b in range(4)]}")
