@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
           acc[i][r] = v;
           s += v;
           if (do_relu) v = fmaxf(v, 0.f);
-          if (!dbg) yo[((int64_t)(2 * i + (rb >> 4)) * p.OW + (rb & 15)) * p.y_ld] = v;
+          if (!dbg && !(p.ablate & 8)) yo[((int64_t)(2 * i + (rb >> 4)) * p.OW + (rb & 15)) * p.y_ld] = v;
         }
       }
     }
@@ -429,8 +429,8 @@ int launch_x6p(const IgemmParams& p, int num_cus, hipStream_t st) {
 int run_x6p(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void* ws, int num_cus, hipStream_t st) {
   const int K = p.K, N = p.Nout;
   {
-    static int abl = -1;  // SG_X6P_ABLATE (timing only, results wrong): 1 = no K loop, 2 = no patch loads
-    if (abl < 0) abl = getenv("SG_X6P_ABLATE") ? atoi(getenv("SG_X6P_ABLATE")) & 7 : 0;
+    static int abl = -1;  // SG_X6P_ABLATE (timing only, results wrong): 1 = no K loop, 2 = no patch loads, 4 = phase clocks into y, 8 = no y stores
+    if (abl < 0) abl = getenv("SG_X6P_ABLATE") ? atoi(getenv("SG_X6P_ABLATE")) & 15 : 0;
     p.ablate = abl;
   }
   p.wq = (const unsigned short*)ws;
