@@ -1,0 +1,134 @@
+"""The reference's training input pipeline, host side: `decode_img`, `decode_lbel`,
+`train_data_gen`, `val_data_gen` of train_model/DeepLabv3plus.py:32-153 (the other four training scripts carry
+the same text), restated without OpenCV / TensorFlow - names, arguments, yield shapes and dtypes as there.
+
+What is exact and what is not (OpenCV is absent here, so nothing below could be checked against cv2 itself):
+  * file decoding goes through Pillow (`cv.imread` = 8-bit, 3 channels, BGR; then BGR2RGB): identical for the 8-bit
+    RGB / gray PNG / TIFF tiles of the WHU set;
+  * `cv.resize(img, (512, 512))` is the identity for 512x512 tiles - the case of the data set - and that case is
+    exact; other sizes go through a half-pixel-centre bilinear resize in float with round-half-up, which can differ
+    from cv2's 11-bit fixed-point kernel by one grey level (flagged in the docstring of `_resize_bilinear_u8`);
+  * `cv.cvtColor(BGR2GRAY)` uses cv2's published 14-bit integer weights (4899 R + 9617 G + 1868 B + 8192) >> 14,
+    which is the identity on grey label images;
+  * `tf.keras.utils.to_categorical(label, 2)` truncates label / 255 to int, so only pixels equal to 255 are class 1;
+  * the edge bands are 5 iterations of a 3x3 erode / dilate (borders do not erode / dilate: cv2's default border value),
+    `building_detection_amd.data.edge_weight_channels`; with `engine=` they are built on the GPU instead
+    (`sg_edge_labels`, bit-identical, tests/test_ops_gpu.py::test_edge_labels_match_generator);
+  * `label_smooth=True` raises: the reference reads `p_label_smooth` / `f_label_smooth`, which no file defines
+    (`DeepLabv3plus.py:74`), so that branch cannot run there either.
+"""
+from __future__ import annotations
+
+import itertools
+
+import numpy as np
+
+from .data import edge_weight_channels
+
+SIZE = 512  # the reference resizes every tile and label to 512 x 512 (`:35`, `:45`)
+
+
+def _imread_bgr_order_free(path) -> np.ndarray:
+    """uint8 [H,W,3] in RGB order (= cv.cvtColor(cv.imread(path), cv.COLOR_BGR2RGB))."""
+    from PIL import Image
+    with Image.open(path) as im:
+        if im.mode in ("I;16", "I;16B", "I;16L", "I"):  # cv.imread's default flag reduces 16-bit data to 8 bits
+            a = np.asarray(im, np.uint32)
+            im = Image.fromarray((a >> 8).astype(np.uint8) if a.max() > 255 else a.astype(np.uint8))
+        return np.asarray(im.convert("RGB"), np.uint8)
+
+
+def _resize_bilinear_u8(img: np.ndarray, size=(SIZE, SIZE)) -> np.ndarray:
+    """cv.resize(img, size) with the default INTER_LINEAR.  Identity (a copy) when the size already matches - exact.
+    Otherwise: half-pixel centres, edge clamp, float arithmetic, round half up.  cv2 computes the same kernel in
+    11-bit fixed point; the two can differ by one grey level (unverified here: no cv2)."""
+    h, w = img.shape[:2]
+    ow, oh = size
+    if (h, w) == (oh, ow):
+        return img.copy()
+
+    def taps(n_in, n_out):
+        src = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
+        i0 = np.floor(src).astype(np.int64)
+        f = src - i0
+        return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), f
+
+    y0, y1, fy = taps(h, oh)
+    x0, x1, fx = taps(w, ow)
+    a = img.astype(np.float64)
+    if a.ndim == 2:
+        a = a[..., None]
+    top = a[y0][:, x0] * (1 - fx)[None, :, None] + a[y0][:, x1] * fx[None, :, None]
+    bot = a[y1][:, x0] * (1 - fx)[None, :, None] + a[y1][:, x1] * fx[None, :, None]
+    out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
+    out = np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
+    return out[..., 0] if img.ndim == 2 else out
+
+
+def decode_img(img_path) -> np.ndarray:
+    """`DeepLabv3plus.py:32-39`: RGB tile, resized to 512x512, float32, / 127.5 - 1  ->  [512,512,3] in [-1, 1]."""
+    img = _resize_bilinear_u8(_imread_bgr_order_free(img_path))
+    return np.array(img, np.float32) / 127.5 - 1
+
+
+def decode_lbel(label_path) -> np.ndarray:
+    """`DeepLabv3plus.py:42-50` (the reference's spelling): grey label, resized, float32 / 255  ->  [512,512,1]."""
+    rgb = _imread_bgr_order_free(label_path).astype(np.int32)
+    gray = ((rgb[..., 0] * 4899 + rgb[..., 1] * 9617 + rgb[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+    gray = _resize_bilinear_u8(gray)
+    return (np.array(gray[..., np.newaxis], np.float32)) / 255
+
+
+def to_categorical(label: np.ndarray, num_classes: int = 2) -> np.ndarray:
+    """tf.keras.utils.to_categorical: integer truncation of the values, trailing unit axis dropped, float32 one-hot."""
+    y = np.array(label, dtype="int")
+    if y.ndim > 1 and y.shape[-1] == 1:
+        y = y.reshape(y.shape[:-1])
+    out = np.zeros(y.shape + (num_classes,), np.float32)
+    np.put_along_axis(out, y[..., None], 1.0, axis=-1)
+    return out
+
+
+def _sample(img, seg, label_smooth, loss, engine):
+    image = decode_img(img)
+    label = decode_lbel(seg)
+    one_hot = to_categorical(label, num_classes=2)
+    if label_smooth:
+        raise NameError("label_smooth=True reads p_label_smooth / f_label_smooth, which the reference never defines "
+                        "(train_model/DeepLabv3plus.py:74): that branch cannot run there either")
+    if loss == "edge_focal_loss":
+        lab2 = np.squeeze(label)
+        if engine is not None:  # the same four channels from the GPU kernel (one-hot of label == 1, f_edge, p_edge)
+            import torch
+            y = engine.edge_labels(torch.from_numpy(np.ascontiguousarray(lab2[None])).to(engine.device))
+            return image, y[0].cpu().numpy().astype(np.float64)
+        f_edge, p_edge = edge_weight_channels(lab2)
+        one_hot = np.concatenate((one_hot, f_edge[..., np.newaxis], p_edge[..., np.newaxis]), axis=-1)  # float64, as there
+    return image, one_hot
+
+
+def _gen(img_path, lab_path, BATCH_SIZE, label_smooth, loss, engine):
+    images, label = img_path, lab_path
+    images.sort()  # in place, as the reference does to its caller's lists
+    label.sort()
+    zipped = itertools.cycle(zip(images, label))
+    while True:
+        x_train, y_train = [], []
+        for _ in range(BATCH_SIZE):
+            img, seg = next(zipped)
+            x, y = _sample(img, seg, label_smooth, loss, engine)
+            x_train.append(x)
+            y_train.append(y)
+        yield np.array(x_train), np.array(y_train)
+
+
+def train_data_gen(img_path, lab_path, BATCH_SIZE, label_smooth=False, loss="edge_focal_loss", engine=None):
+    """`DeepLabv3plus.py:53-107`: endless generator of (x float32 [N,512,512,3], y [N,512,512,4] float64 with
+    loss="edge_focal_loss", else [N,512,512,2] float32) over the sorted, cycled (image, label) pairs.
+    `engine` (an `ops.Engine`, not in the reference): build the label channels with the GPU kernel."""
+    return _gen(img_path, lab_path, BATCH_SIZE, label_smooth, loss, engine)
+
+
+def val_data_gen(img_path, lab_path, BATCH_SIZE, label_smooth=False, loss="edge_focal_loss", engine=None):
+    """`DeepLabv3plus.py:110-153`: the same generator over the validation lists."""
+    return _gen(img_path, lab_path, BATCH_SIZE, label_smooth, loss, engine)

@@ -1,0 +1,91 @@
+"""Host input pipeline: decode_img / decode_lbel / train_data_gen / val_data_gen restated from
+train_model/DeepLabv3plus.py:32-153, against files written here with Pillow and against the label restatement that
+the synthetic benchmark batches already use (building_detection_amd.data)."""
+import numpy as np
+import pytest
+
+from building_detection_amd import input_pipeline as IP
+from building_detection_amd.data import edge_weight_channels
+
+PIL = pytest.importorskip("PIL.Image")
+
+
+def _write_pair(tmp_path, i, rng, size=512, soft=False):
+    img = rng.integers(0, 256, size=(size, size, 3), dtype=np.uint8)
+    lab = np.zeros((size, size), np.uint8)
+    for _ in range(4):
+        r0, c0 = int(rng.integers(0, size - 80)), int(rng.integers(0, size - 80))
+        lab[r0:r0 + int(rng.integers(20, 80)), c0:c0 + int(rng.integers(20, 80))] = 255
+    lab[:12, :30] = 255          # a building touching the border: borders neither erode nor dilate inwards
+    if soft:
+        lab[100:110, 100:110] = 128  # grey levels other than 0 / 255 are background for to_categorical
+    pi, pl = tmp_path / f"img_{i:03d}.png", tmp_path / f"lab_{i:03d}.png"
+    PIL.fromarray(img).save(pi)
+    PIL.fromarray(np.repeat(lab[..., None], 3, -1)).save(pl)  # labels are stored as 3-channel grey images
+    return str(pi), str(pl), img, lab
+
+
+def test_decode_img_and_label_are_exact_for_512_tiles(tmp_path):
+    rng = np.random.default_rng(5)
+    pi, pl, img, lab = _write_pair(tmp_path, 0, rng, soft=True)
+    x = IP.decode_img(pi)
+    assert x.dtype == np.float32 and x.shape == (512, 512, 3)
+    assert np.array_equal(x, img.astype(np.float32) / 127.5 - 1)          # RGB order, no resampling at 512x512
+    y = IP.decode_lbel(pl)
+    assert y.dtype == np.float32 and y.shape == (512, 512, 1)
+    assert np.array_equal(y[..., 0], lab.astype(np.float32) / 255)         # the integer grey weights are the identity on grey
+    oh = IP.to_categorical(y, 2)
+    assert oh.shape == (512, 512, 2) and oh.dtype == np.float32
+    assert np.array_equal(oh[..., 1], (lab == 255).astype(np.float32))      # 128/255 truncates to class 0
+    assert np.array_equal(oh.sum(-1), np.ones((512, 512), np.float32))
+
+
+def test_bgr2gray_integer_weights():
+    # cv2's 14-bit weights on a colour pixel: (4899 R + 9617 G + 1868 B + 8192) >> 14
+    from PIL import Image
+    import io
+    px = np.array([[[255, 0, 0], [0, 255, 0], [0, 0, 255], [10, 200, 30]]], np.uint8)
+    buf = io.BytesIO()
+    Image.fromarray(np.tile(px, (512, 128, 1))).save(buf, format="PNG")
+    buf.seek(0)
+    g = IP.decode_lbel(buf)[0, :4, 0] * 255
+    assert list(np.round(g).astype(int)) == [76, 150, 29, (4899 * 10 + 9617 * 200 + 1868 * 30 + 8192) >> 14]
+
+
+def test_resize_only_when_needed():
+    a = np.arange(512 * 512, dtype=np.uint32).reshape(512, 512).astype(np.uint8)
+    assert np.array_equal(IP._resize_bilinear_u8(a), a)
+    b = np.full((256, 256, 3), 77, np.uint8)
+    r = IP._resize_bilinear_u8(b)
+    assert r.shape == (512, 512, 3) and np.all(r == 77)
+    ramp = np.tile(np.arange(256, dtype=np.uint8)[None, :], (256, 1))  # 2x up-sampling of a ramp: half-pixel centres
+    r = IP._resize_bilinear_u8(ramp)
+    assert r[0, 0] == 0 and r[0, 1] == 0 and r[0, 2] == 1 and r[0, 511] == 255 and np.all(np.diff(r[0].astype(int)) >= 0)
+
+
+@pytest.mark.parametrize("gen", [IP.train_data_gen, IP.val_data_gen], ids=["train", "val"])
+def test_generator_protocol_and_labels(tmp_path, gen):
+    rng = np.random.default_rng(11)
+    pairs = [_write_pair(tmp_path, i, rng) for i in range(3)]
+    imgs, labs = [p[0] for p in pairs][::-1], [p[1] for p in pairs][::-1]  # unsorted on purpose
+    g = gen(imgs, labs, 2)
+    x, y = next(g)
+    assert imgs == sorted(imgs) and labs == sorted(labs)            # the reference sorts its caller's lists in place
+    assert x.shape == (2, 512, 512, 3) and x.dtype == np.float32
+    assert y.shape == (2, 512, 512, 4) and y.dtype == np.float64    # one-hot (f32) joined with float64 edge bands
+    for k in range(2):
+        mask = (pairs[k][3] == 255).astype(np.float32)
+        f_edge, p_edge = edge_weight_channels(mask)
+        assert np.array_equal(x[k], pairs[k][2].astype(np.float32) / 127.5 - 1)
+        assert np.array_equal(y[k, ..., 0], 1 - mask) and np.array_equal(y[k, ..., 1], mask)
+        assert np.array_equal(y[k, ..., 2], f_edge) and np.array_equal(y[k, ..., 3], p_edge)
+        assert set(np.unique(y[k, ..., 2:])) <= {1.0, 2.0}
+        assert not np.any((y[k, ..., 3] == 2) & (mask == 0)) and not np.any((y[k, ..., 2] == 2) & (mask == 1))
+    x2, _ = next(g)                                                  # 3 samples, batches of 2: the cycle wraps
+    assert np.array_equal(x2[0], pairs[2][2].astype(np.float32) / 127.5 - 1)
+    assert np.array_equal(x2[1], x[0])
+    # other losses: plain one-hot labels, float32
+    _, y2 = next(gen(imgs, labs, 1, loss="focal_loss"))
+    assert y2.shape == (1, 512, 512, 2) and y2.dtype == np.float32
+    with pytest.raises(NameError):
+        next(gen(imgs, labs, 1, label_smooth=True))

@@ -86,3 +86,31 @@ def test_vote(engine):
     rng = np.random.default_rng(0)
     masks = [(rng.random((300, 280)) > 0.5).astype(np.uint8) * 255 for _ in range(5)]
     np.testing.assert_array_equal(PL.vote(masks, 3), OP.vote_ref(masks, 3))
+
+
+def test_file_generator_feeds_fit_generator(engine, tmp_path):
+    """train_data_gen / val_data_gen over files on disk drive fit_generator exactly as the reference's
+    training script does (DeepLabv3plus.py:840-849); the GPU-built label channels equal the host-built ones."""
+    from PIL import Image
+    from building_detection_amd import input_pipeline as IP, zoo
+    from building_detection_amd.losses import edge_focal_loss, PA, IoU, MIoU, F1_score
+    rng = np.random.default_rng(3)
+    imgs, labs = [], []
+    for i in range(2):
+        lab = np.zeros((512, 512), np.uint8)
+        lab[60 + 100 * i:200 + 100 * i, 40:300] = 255
+        lab[:9, 480:] = 255
+        pi, pl = tmp_path / f"i{i}.png", tmp_path / f"l{i}.png"
+        Image.fromarray(rng.integers(0, 256, size=(512, 512, 3), dtype=np.uint8)).save(pi)
+        Image.fromarray(lab).save(pl)
+        imgs.append(str(pi)); labs.append(str(pl))
+    xh, yh = next(IP.train_data_gen(list(imgs), list(labs), 2))
+    xd, yd = next(IP.train_data_gen(list(imgs), list(labs), 2, engine=engine))
+    assert np.array_equal(xh, xd) and yd.dtype == np.float64 and np.array_equal(yh, yd)
+    model = zoo.Xception_DeepLabV3_Plus_bam((512, 512, 3), 2)
+    model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
+    hist = model.fit_generator(IP.train_data_gen(list(imgs), list(labs), 1), steps_per_epoch=2, epochs=1, verbose=0,
+                               validation_data=IP.val_data_gen(list(imgs), list(labs), 1), validation_steps=1)
+    logs = hist.history
+    for k in ("loss", "PA", "IoU", "MIoU", "F1_score", "val_loss", "val_PA"):
+        assert k in logs and np.isfinite(logs[k][-1]), (k, logs)
