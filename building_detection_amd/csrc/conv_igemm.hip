@@ -1064,13 +1064,15 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
     }
     p.ablate = abl;
   }
-  // Structure by tile count (measured, profiles/r01_ab_x6.txt, r01_ab_x6_interleave.txt): up to ~4 tiles per CU
-  // the double-buffered one-workgroup-per-CU form with the hand-interleaved step wins (ASPP forward 1.02 -> 0.89
-  // ms, pointwise 728 forward 0.150 -> 0.137 ms); with many tiles the two-workgroups-per-CU single-buffer form
-  // does (ASPP dgrad 0.83 vs 0.94 ms, decoder 128->64 dgrad 0.92 vs 1.03 ms).  SG_X6_VARIANT overrides.
+  // Structure by tile count (measured, profiles/r01_ab_x6.txt, r01_ab_x6_interleave.txt, r01_ab_tiles1024.txt): up to
+  // 3 tiles per CU the double-buffered one-workgroup-per-CU form with the hand-interleaved step wins (ASPP forward
+  // 1.02 -> 0.89 ms, pointwise 728 forward 0.150 -> 0.137 ms); from 4 tiles per CU - i.e. two full rounds of the
+  // two-workgroups-per-CU single-buffer form - that one does (1024 tiles: 64x64 512->256 forward 887 vs 930 us,
+  // 1024->1024 pointwise 233 vs 252 us; ASPP dgrad 0.83 vs 0.94 ms, decoder 128->64 dgrad 0.92 vs 1.03 ms).
+  // SG_X6_VARIANT overrides.
   const int64_t tiles = sg_cdiv(p.M, BM) * sg_cdiv(p.Nout, bn);
   int var = x6_variant();
-  if (var < 0) var = (tiles <= 4 * (int64_t)num_cus) ? 1 : 0;
+  if (var < 0) var = (tiles <= 3 * (int64_t)num_cus) ? 1 : 0;
   if (bn == 128) {
     switch (var) {
       case 0: return launch_x6<128, 2, 4, 1>(p, st);
