@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from building_detection_amd.ops import get_engine  # noqa: E402
 from building_detection_amd.data import synthetic_batch  # noqa: E402
 from oracle import tfops as T  # noqa: E402

@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from building_detection_amd import zoo  # noqa: E402
 from building_detection_amd.data import synthetic_batch  # noqa: E402
 from building_detection_amd.losses import edge_focal_loss  # noqa: E402
