@@ -1036,7 +1036,9 @@ void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false) {
   // decided from ONE image's footprint, never from the batch: the K order fixes the rounding order, and
   // inference must not depend on how many tiles travel together (tests/test_fullsize_gpu.py)
   const int64_t img_bytes = (int64_t)p.H * p.W * p.x_ld * 4;
-  p.cb = ((conv_l2(x6) & 2) && ut && ntaps > 1 && spt > 4 && spt % 4 == 0 && img_bytes > (2ll << 20)) ? 4 : 0;
+  static int cbv = -1;  // experiment switch SG_CONV_CB: slabs per channel block of the K order (default 4)
+  if (cbv < 0) cbv = getenv("SG_CONV_CB") ? atoi(getenv("SG_CONV_CB")) : 4;
+  p.cb = ((conv_l2(x6) & 2) && ut && ntaps > 1 && spt > cbv && spt % cbv == 0 && img_bytes > (2ll << 20)) ? cbv : 0;
 }
 
 #include "conv_x6.h"
