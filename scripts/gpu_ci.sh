@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench, rocprof summary.  Every stage runs under its own timeout; a
 # stage that times out or is killed aborts the session (no further GPU step after a hang).
-#   usage: scripts/gpu_ci.sh <tag> [stages...]      stages: tests smoke bench prof dp1 pmc full infer census
+#   usage: scripts/gpu_ci.sh <tag> [stages...]      stages: tests smoke bench prof dp1 pmc pmc2 pmc3 full infer census nodes bw
 set -u
 TAG=${1:-run}; shift || true
 STAGES=${*:-"tests smoke bench prof"}
