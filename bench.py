@@ -82,6 +82,32 @@ def cpu_baseline(threads, batch, size, steps, model=None):
     return out
 
 
+def spawn_ranks(n: int) -> int:
+    """Start `n` copies of this script as ranks 0..n-1 of one job (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+    environment, rendezvous on 127.0.0.1), wait for them, return the worst exit code.  Rank 0's stdout (the JSON
+    line) is passed through; the other ranks' stdout goes to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        for p in procs:
+            rc = max(rc, abs(p.wait()))
+    finally:
+        for p in procs:  # a rank that died leaves the others in a collective: end exactly the children we started
+            if p.poll() is None:
+                p.terminate()
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -92,24 +118,37 @@ def main():
     ap.add_argument("--model", default="v3plus")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--comm", default=os.environ.get("SG_BENCH_COMM", "sg"), choices=["sg", "torch"],
+                    help="gradient all-reduce transport: sg = RCCL through libsegengine's sg_comm_* (C ABI), torch = "
+                         "torch.distributed 'nccl' (also RCCL)")
     ap.add_argument("--force-dp", action="store_true",
                     help="run the RCCL data-parallel path even with one rank (rehearsal on a 1-GPU box)")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU).  The parent
+        # never touches the GPU (no HIP call before or after the spawn), it only relays rank 0's JSON line.
+        raise SystemExit(spawn_ranks(args.gpus))
 
     import torch
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start one process per GPU "
+                         f"(python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {torch.cuda.device_count()} GPU(s) visible")
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.comm == "torch":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:  # the process group is only the rendezvous of the 128-byte RCCL id and the host-side barrier
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from building_detection_amd import zoo
     from building_detection_amd.data import synthetic_batch
@@ -124,7 +163,7 @@ def main():
     model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
     if dist is not None:
         from building_detection_amd.dist import DataParallel
-        DataParallel(model)
+        DataParallel(model, comm=args.comm)
 
     # rank r takes tiles [16 r, 16 r + 16) of the global synthetic batch (weak scaling)
     x, y = synthetic_batch(args.batch, args.size, args.size, seed=1103 + rank)
@@ -158,7 +197,7 @@ def main():
         fam = eng.profile_end()
     sync()
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.comm == "torch" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3
@@ -195,6 +234,8 @@ def main():
             "dtype_note": "fp32 tensors, fp32 accumulation; conv products as 6 bf16 MFMA passes over an exact 3-way split" if x6 else "fp32 MFMA",
             "config": {"workload": f"{LABEL.get(args.model, args.model)} {args.size}x{args.size} bs={args.batch}/GPU fp32, "
                                    f"train step, {'dp%d' % world if world > 1 else 'single GPU'}",
+                       "comm": None if dist is None else ("RCCL via sg_comm_* (libsegengine C ABI)" if args.comm == "sg"
+                                                          else "RCCL via torch.distributed nccl"),
                        "global_batch": world * args.batch, "model_flops_per_step_tflop": round(step_tflop, 3),
                        "step_achieved_tflops": round(step_tflop / (ms_per_step / 1e3), 2),
                        "final_loss": float(loss.item())},

@@ -12,7 +12,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsegengine.so")
 
-SG_F32, SG_BF16 = 0, 1
+SG_F32, SG_BF16, SG_I64 = 0, 1, 2
+SG_COMM_ID_BYTES = 128
 SG_EPI_BIAS, SG_EPI_RELU = 1, 2
 SG_ACT_RELU, SG_ACT_SIGMOID = 0, 1
 SG_LOSS_CE2, SG_LOSS_FOCAL, SG_LOSS_EDGE_FOCAL = 0, 1, 2
@@ -98,6 +99,13 @@ _SIGNATURES = {
     "sg_argmax_accumulate_i8": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i]),
     "sg_vote_ge": (_i, [_vp, _vp, _i, _pp, _i64, _i, _vp]),
     "sg_fill_f32": (_i, [_vp, _vp, _vp, _i64, _f]),
+    "sg_scale_f32": (_i, [_vp, _vp, _vp, _i64, _f]),
+    "sg_comm_unique_id": (_i, [_vp]),
+    "sg_comm_init": (_i, [_vp, _i, _i, _i, _pp]),
+    "sg_comm_allreduce_sum": (_i, [_vp, _vp, _i, _vp, _i64]),
+    "sg_comm_rank": (_i, [_vp]),
+    "sg_comm_nranks": (_i, [_vp]),
+    "sg_comm_destroy": (_i, [_vp]),
 }
 
 _lib = None

@@ -17,6 +17,11 @@ __global__ void fill_f32_kernel(float* __restrict__ p, int64_t n, float v) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (; i < n; i += stride) p[i] = v;
 }
+__global__ void scale_f32_kernel(float* __restrict__ p, int64_t n, float a) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) p[i] *= a;
+}
 }  // namespace
 
 extern "C" {
@@ -67,6 +72,16 @@ int sg_fill_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float value) {
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)p, n, value);
   SG_LAUNCH_CHECK("fill_f32_kernel");
+  return 0;
+}
+
+int sg_scale_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float a) {
+  SG_CHECK_ARG(ctx && (p || n == 0), "sg_scale_f32: null argument");
+  if (n <= 0) return 0;
+  int64_t blocks = sg_cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(scale_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)p, n, a);
+  SG_LAUNCH_CHECK("scale_f32_kernel");
   return 0;
 }
 

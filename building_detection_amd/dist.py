@@ -5,15 +5,25 @@ Partitioning: every rank holds a full weight replica (same seed), takes its own 
 and normalises BatchNorm over them (plain DP, per-replica BN).  The only exchange is ONE sum-all-reduce of the
 flat fp32 gradient arena per step, cut into buckets that are contiguous arena ranges.  Weight gradients land in
 the arena in reverse layer order during the backward sweep, so bucket k is complete as soon as the sweep has
-passed the first node owning parameters in it; it is then handed to RCCL (torch.distributed 'nccl' backend,
-which queues it on its own HIP stream behind an event on the compute stream) while backward continues.  The
-1/world scaling is folded into the Adam kernel (`grad_scale`), so no extra pass touches the gradients.
+passed the first node owning parameters in it; it is then handed to RCCL on a communication stream behind an
+event on the compute stream, while backward continues.  The 1/world scaling is folded into the Adam kernel
+(`grad_scale`), so no extra pass touches the gradients.  The training loss and the four confusion counts are
+summed over the ranks as well (metrics of the GLOBAL batch), BatchNorm moving statistics are averaged when a
+checkpoint is written, and only rank 0 writes it.
+
+Two transports behind one interface (`comm=`):
+  "sg"     libsegengine's own sg_comm_* entry points (RCCL through the C ABI, include/segengine.h); the 128-byte
+           RCCL id travels through the torch.distributed rendezvous store of whatever process group exists
+           (gloo is enough), the collectives run on a HIP stream this module owns.
+  "torch"  torch.distributed all_reduce on the default group (backend 'nccl' = RCCL on the GPU; 'gloo' on the CPU,
+           which is what the world-size-2 tests here use).
 
 xGMI is point-to-point (7 links/GPU): RCCL picks ring/tree per message size; buckets are kept large
 (default 48 MB, ~6 for DeepLabv3+'s 258 MB) so each collective is bandwidth- rather than latency-bound.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import List, Optional, Tuple
 
 
@@ -36,60 +46,184 @@ def plan_buckets(param_ranges: List[Tuple[int, int, int]], total: int, bucket_el
     return buckets
 
 
-class BucketReducer:
-    """Device-agnostic bucketed sum-all-reduce of a flat arena (works on CPU tensors with gloo in tests)."""
+class TorchTransport:
+    """torch.distributed collectives (nccl = RCCL on GPU tensors, gloo on CPU tensors)."""
 
-    def __init__(self, arena, buckets, group=None):
+    name = "torch"
+
+    def __init__(self, group=None):
         import torch.distributed as dist
-        self.dist = dist
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self._works = []
+
+    def allreduce_async(self, t):
+        self._works.append(self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def join(self):
+        for w in self._works:
+            w.wait()  # stream-level dependency for nccl; blocks the host only for gloo
+        self._works = []
+
+    def broadcast(self, t, src=0):
+        self.dist.broadcast(t, src=src, group=self.group)
+
+    def barrier(self):
+        self.dist.barrier(group=self.group)
+
+
+class SgTransport:
+    """RCCL through libsegengine's C ABI (sg_comm_*), on a communication stream of its own.
+
+    allreduce_async(t): the comm stream waits for everything queued so far on the compute stream (the kernels that
+    produced `t`), then runs the in-place sum; join(): the compute stream waits for the comm stream.  No host sync."""
+
+    name = "sg"
+
+    def __init__(self, device, group=None):
+        import torch
+        import torch.distributed as dist
+        from . import _lib
+        self.torch, self._lib, self.lib = torch, _lib, _lib.load()
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+        self.device = torch.device("cuda", device) if isinstance(device, int) else device
+        ident = [None]
+        if self.rank == 0:
+            buf = C.create_string_buffer(_lib.SG_COMM_ID_BYTES)
+            _lib.check(self.lib.sg_comm_unique_id(buf), "sg_comm_unique_id")
+            ident[0] = bytes(buf.raw)
+        dist.broadcast_object_list(ident, src=0, group=group)  # any backend: the id is 128 opaque host bytes
+        h = C.c_void_p()
+        _lib.check(self.lib.sg_comm_init(ident[0], self.rank, self.world, self.device.index, C.byref(h)), "sg_comm_init")
+        self.h = h
+        self.stream = torch.cuda.Stream(self.device)
+        self._pending = False
+
+    def _dtype(self, t):
+        torch = self.torch
+        return {torch.float32: self._lib.SG_F32, torch.bfloat16: self._lib.SG_BF16, torch.int64: self._lib.SG_I64}[t.dtype]
+
+    def allreduce_async(self, t):
+        torch = self.torch
+        assert t.is_cuda and t.is_contiguous()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        self._lib.check(self.lib.sg_comm_allreduce_sum(self.h, C.c_void_p(self.stream.cuda_stream), self._dtype(t),
+                                                       C.c_void_p(t.data_ptr()), t.numel()), "sg_comm_allreduce_sum")
+        t.record_stream(self.stream)
+        self._pending = True
+
+    def join(self):
+        if self._pending:
+            self.torch.cuda.current_stream(self.device).wait_stream(self.stream)
+            self._pending = False
+
+    def broadcast(self, t, src=0):
+        """Rank `src`'s values to every rank, as a sum of (t on src, zeros elsewhere) - set-up time only."""
+        if self.rank != src:
+            t.zero_()
+        self.allreduce_async(t)
+        self.join()
+
+    def barrier(self):
+        one = self.torch.zeros(1, dtype=self.torch.float32, device=self.device)
+        self.allreduce_async(one)
+        self.join()
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.torch.cuda.synchronize(self.device)
+            self.lib.sg_comm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BucketReducer:
+    """Bucketed sum-all-reduce of a flat arena, fired bucket by bucket from the backward sweep (device-agnostic: the
+    tests drive it with CPU tensors over gloo)."""
+
+    def __init__(self, arena, buckets, transport=None, group=None):
         self.arena = arena
-        self.group = group
+        self.tp = transport if transport is not None else TorchTransport(group)
         # fire in the order the backward sweep completes them: highest ready index first
         self.buckets = sorted(buckets, key=lambda b: -b[2])
         self.next = 0
-        self.works = []
+        self.fired: List[Tuple[int, int]] = []  # (node index at which it fired, bucket start): for the tests
 
     def reset(self):
         self.next = 0
-        self.works = []
+        self.fired = []
 
     def node_done(self, node_index: int):
         """Called after each node's backward (descending index): launch every bucket that is now complete."""
         while self.next < len(self.buckets) and self.buckets[self.next][2] >= node_index:
             s, e, _ = self.buckets[self.next]
-            self.works.append(self.dist.all_reduce(self.arena[s:e], op=self.dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.tp.allreduce_async(self.arena[s:e])
+            self.fired.append((node_index, s))
             self.next += 1
 
     def finish(self):
         self.node_done(-1)
-        for w in self.works:
-            w.wait()  # stream-level dependency for nccl; blocks the host only for gloo
-        self.works = []
+        self.tp.join()
 
 
 class DataParallel:
     """Attach to a compiled Model: `DataParallel(model)`; the model's train_on_batch then all-reduces."""
 
-    def __init__(self, model, bucket_mb: float = 48.0, group=None):
+    def __init__(self, model, bucket_mb: float = 48.0, group=None, comm: str = "auto"):
         import torch.distributed as dist
         if not dist.is_initialized():
-            raise RuntimeError("init torch.distributed (backend 'nccl' = RCCL) before DataParallel")
-        self.world = dist.get_world_size(group)
+            raise RuntimeError("init torch.distributed before DataParallel (backend 'nccl' = RCCL for comm='torch'; "
+                               "'gloo' is enough as the rendezvous of comm='sg')")
         self.model = model
         self.group = group
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
-        self.reducer: Optional[BucketReducer] = None
         model.dist = self
         rt = model._runtime()
+        if comm == "auto":
+            comm = "torch" if dist.get_backend(group) == "nccl" else "sg"
+        self.tp = SgTransport(rt.eng.device, group) if comm == "sg" else TorchTransport(group)
+        self.world, self.rank = self.tp.world, self.tp.rank
         # identical replicas: broadcast rank-0 weights and BN statistics once
-        dist.broadcast(rt.w_train, src=0, group=group)
-        dist.broadcast(rt.w_frozen, src=0, group=group)
-        ranges = [(n.index, p.offset, (p.size + 3) // 4 * 4) for n in model.nodes for p in n.params if p.trainable]
-        self.buckets = plan_buckets(ranges, rt.g_train.numel(), self.bucket_elems)
-        self.reducer = BucketReducer(rt.g_train, self.buckets, group)
+        self.tp.broadcast(rt.w_train, src=0)
+        self.tp.broadcast(rt.w_frozen, src=0)
+        self.buckets = plan_buckets(param_ranges(model), rt.g_train.numel(), self.bucket_elems)
+        self.reducer = BucketReducer(rt.g_train, self.buckets, self.tp)
         rt.on_node_done = self.reducer.node_done
 
     def allreduce_grads(self, rt) -> float:
         self.reducer.finish()
         self.reducer.reset()
         return 1.0 / self.world
+
+    def reduce_step_scalars(self, loss, counts):
+        """Loss -> mean over the ranks (every rank's loss is the mean over its own equally sized shard), confusion
+        counts -> sums: the logs then describe the global batch on every rank."""
+        self.tp.allreduce_async(loss)
+        if counts is not None:
+            self.tp.allreduce_async(counts)
+        self.tp.join()
+        self.model._runtime().eng.scale(loss, 1.0 / self.world)
+        return loss, counts
+
+    def sync_moving_stats(self, rt):
+        """BatchNorm moving mean / variance averaged over the replicas (each has followed its own shards): called
+        when a checkpoint is written, never inside the step."""
+        self.tp.allreduce_async(rt.w_frozen)
+        self.tp.join()
+        rt.eng.scale(rt.w_frozen, 1.0 / self.world)
+
+    def barrier(self):
+        self.tp.barrier()
+
+
+def param_ranges(model) -> List[Tuple[int, int, int]]:
+    """(node index, arena offset, padded size) of every trainable parameter, in arena (= creation) order."""
+    return [(n.index, p.offset, (p.size + 3) // 4 * 4) for n in model.nodes for p in n.params if p.trainable]

@@ -7,7 +7,9 @@ tf.keras `get_weights()` layouts (HWIO, depthwise [kh,kw,C,1], Conv2DTranspose [
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes as C
+import threading
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -80,10 +82,19 @@ class Engine:
         if not torch.cuda.is_available():
             raise _lib.SgError("no HIP device visible; building_detection_amd requires an MI355X (gfx950) GPU")
         self.lib = _lib.load()
+        # every launch below goes to torch's CURRENT stream of `device`; make that device current so that torch's
+        # allocations, the stream handle and the sg_ctx agree (one process per GPU: LOCAL_RANK picks the device)
+        torch.cuda.set_device(device)
         self.ctx = _lib.Context(device)
         self.h = self.ctx.handle
         self.device = torch.device("cuda", device)
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        self._ws_peak = 0          # largest workspace request seen (GraphedPredict sizes its private buffer by it)
+        self._ws_pinned = False    # True while a private workspace is installed: growth is an error, not a realloc
+        # One forward / training step at a time per device: the scratch buffer above and a model's value table are
+        # shared mutable state, and the reference's Flask front end calls predict() from request threads
+        # (buildAPI.py:78,111).  Re-entrant so that predict() may call predict_device().
+        self.lock = threading.RLock()
 
     # ------------------------------------------------------------------------------------------ plumbing
     @property
@@ -91,9 +102,28 @@ class Engine:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
     def ws(self, nbytes: int):
+        nbytes = int(nbytes)
+        if nbytes > self._ws_peak:
+            self._ws_peak = nbytes
         if nbytes > self._ws.numel():
+            if self._ws_pinned:
+                raise _lib.SgError(f"workspace request of {nbytes} B exceeds the private {self._ws.numel()} B buffer of "
+                                   "the hipGraph being captured (the sizing pass saw a smaller request)")
             self._ws = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
         return C.c_void_p(self._ws.data_ptr()), C.c_size_t(self._ws.numel())
+
+    @contextlib.contextmanager
+    def private_ws(self, buf: torch.Tensor):
+        """Launches inside the block use `buf` as their scratch.  A hipGraph bakes the scratch pointer into its kernel
+        nodes, so every captured graph owns its buffer: the engine's shared one may be re-grown (= freed) by any
+        later eager call, and a replay would then write into whatever tensor owns that block by then."""
+        with self.lock:
+            old, old_pin = self._ws, self._ws_pinned
+            self._ws, self._ws_pinned = buf, True
+            try:
+                yield
+            finally:
+                self._ws, self._ws_pinned = old, old_pin
 
     # -- in-run timing of tagged launches with HIP events recorded on the launch stream (bench.py roofline) --
     def profile_begin(self, all_convs=False):
@@ -478,6 +508,11 @@ class Engine:
 
     def fill(self, t, value=0.0):
         check(self.lib.sg_fill_f32(self.h, self.stream, _ptr(t), t.numel(), float(value)), "sg_fill_f32")
+        return t
+
+
+    def scale(self, t, a):
+        check(self.lib.sg_scale_f32(self.h, self.stream, _ptr(t), t.numel(), float(a)), "sg_scale_f32")
         return t
 
 

@@ -202,8 +202,17 @@ class Model:
         return [rt.grad(p).detach().cpu().numpy().copy() for p in self.params if p.trainable]
 
     def save_weights(self, path):
+        """Under data parallelism the BatchNorm moving statistics of the replicas are averaged first and only rank 0
+        writes the file; every rank must call it (it is a collective then)."""
         from .weights_io import save_weights
+        if self.dist is not None:
+            self.dist.sync_moving_stats(self._runtime())
+            if self.dist.rank != 0:
+                self.dist.barrier()
+                return
         save_weights(self, path)
+        if self.dist is not None:
+            self.dist.barrier()
 
     def load_weights(self, path):
         from .weights_io import load_weights
@@ -227,9 +236,12 @@ class Model:
         x = np.asarray(x)
         outs = []
         for i in range(0, x.shape[0], batch_size):
-            xb = torch.from_numpy(np.ascontiguousarray(x[i:i + batch_size], dtype=np.float32)).to(rt.eng.device)
-            outs.append(rt.forward(xb, training=False).cpu().numpy())
-            rt.release()
+            xh = torch.from_numpy(np.ascontiguousarray(x[i:i + batch_size], dtype=np.float32))
+            # serialised per device (buildAPI.py:78,111 calls predict from Flask request threads on shared models):
+            # the value table of the sweep and the engine's scratch buffer are not re-entrant
+            with rt.eng.lock:
+                outs.append(rt.forward(xh.to(rt.eng.device), training=False).cpu().numpy())
+                rt.release()
         return np.concatenate(outs, 0)
 
     def _last_use(self):
@@ -252,8 +264,9 @@ class Model:
     def predict_device(self, x_dev):
         """Device tensor in, device tensor out (used by the tile pipeline and the benchmark)."""
         rt = self._runtime()
-        y = rt.forward(x_dev, training=False)
-        rt.release()
+        with rt.eng.lock:
+            y = rt.forward(x_dev, training=False)
+            rt.release()
         return y
 
     def __call__(self, x, training=False):
@@ -268,32 +281,36 @@ class Model:
         if self.optimizer is None or self.loss_kind is None:
             raise RuntimeError("compile() the model before training")
         rt = self._runtime()
-        xd, yd = rt.to_device(x), rt.to_device(y)
-        p = rt.forward(xd, training=True)
-        loss = rt.eng.loss_fwd(self.loss_kind, p, yd)
-        counts = rt.eng.confusion_counts(p, yd) if self.metric_names else None
-        dp = rt.eng.loss_bwd(self.loss_kind, p, yd, 1.0)
-        rt.backward(dp)
-        grad_scale = 1.0
-        if self.dist is not None:
-            grad_scale = self.dist.allreduce_grads(rt)
-        opt = self.optimizer
-        opt.iterations += 1
-        t = opt.iterations
-        lr_t = float(opt.lr) * math.sqrt(1.0 - opt.beta_2 ** t) / (1.0 - opt.beta_1 ** t)
-        rt.eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, lr_t, opt.beta_1, opt.beta_2, opt.epsilon, grad_scale)
-        rt.release()
+        with rt.eng.lock:
+            xd, yd = rt.to_device(x), rt.to_device(y)
+            p = rt.forward(xd, training=True)
+            loss = rt.eng.loss_fwd(self.loss_kind, p, yd)
+            counts = rt.eng.confusion_counts(p, yd) if self.metric_names else None
+            dp = rt.eng.loss_bwd(self.loss_kind, p, yd, 1.0)
+            rt.backward(dp)
+            grad_scale = 1.0
+            if self.dist is not None:
+                grad_scale = self.dist.allreduce_grads(rt)
+                loss, counts = self.dist.reduce_step_scalars(loss, counts)  # logs describe the GLOBAL batch
+            opt = self.optimizer
+            opt.iterations += 1
+            t = opt.iterations
+            lr_t = float(opt.lr) * math.sqrt(1.0 - opt.beta_2 ** t) / (1.0 - opt.beta_1 ** t)
+            rt.eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, lr_t, opt.beta_1, opt.beta_2, opt.epsilon,
+                             grad_scale)
+            rt.release()
         if return_device_scalars:
             return loss, counts
         return self._logs(loss, counts)
 
     def test_on_batch(self, x, y):
         rt = self._runtime()
-        xd, yd = rt.to_device(x), rt.to_device(y)
-        p = rt.forward(xd, training=False)
-        loss = rt.eng.loss_fwd(self.loss_kind, p, yd)
-        counts = rt.eng.confusion_counts(p, yd) if self.metric_names else None
-        rt.release()
+        with rt.eng.lock:
+            xd, yd = rt.to_device(x), rt.to_device(y)
+            p = rt.forward(xd, training=False)
+            loss = rt.eng.loss_fwd(self.loss_kind, p, yd)
+            counts = rt.eng.confusion_counts(p, yd) if self.metric_names else None
+            rt.release()
         return self._logs(loss, counts)
 
     def _logs(self, loss, counts):
@@ -376,19 +393,29 @@ class GraphedPredict:
         rt = model._runtime()
         self.torch, self.rt = torch, rt
         shape = (batch,) + tuple(model.inputs[0].shape[1:])
-        self.x = rt.eng.zeros(*shape)
-        for _ in range(2):  # warm-up outside capture: workspace growth, first-launch attribute calls
-            rt.forward(self.x, training=False)
-            rt.release()
-        torch.cuda.synchronize(rt.eng.device)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.y = rt.forward(self.x, training=False)
-        rt.values = {}
+        eng = rt.eng
+        with eng.lock:
+            self.x = eng.zeros(*shape)
+            eng._ws_peak = 0
+            for _ in range(2):  # warm-up outside capture: first-launch attribute calls, and the sizing pass of the scratch
+                rt.forward(self.x, training=False)
+                rt.release()
+            torch.cuda.synchronize(eng.device)
+            # The graph's kernel nodes carry the scratch pointer: give this graph a buffer of its own (sized by the
+            # warm-up pass), never the engine's shared one, which a later eager call or another model may re-grow.
+            self.ws = torch.empty(max(eng._ws_peak, 256) + 256, dtype=torch.uint8, device=eng.device)
+            self.graph = torch.cuda.CUDAGraph()
+            with eng.private_ws(self.ws):
+                with torch.cuda.graph(self.graph):
+                    self.y = rt.forward(self.x, training=False)
+            rt.values = {}
 
     def __call__(self, x_dev):
-        self.x.copy_(x_dev, non_blocking=True)
-        self.graph.replay()
+        """Replays the graph on x_dev.  The returned tensor is the graph's static output buffer: consume (or clone) it
+        before the next call."""
+        with self.rt.eng.lock:
+            self.x.copy_(x_dev, non_blocking=True)
+            self.graph.replay()
         return self.y
 
 
@@ -401,7 +428,7 @@ class _Runtime:
         self.torch = torch
         self.model = model
         dev = int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() and torch.cuda.device_count() > 1 else 0
-        self.eng = get_engine(dev)
+        self.eng = get_engine(dev)  # makes `dev` torch's current device (Engine.__init__)
         e = self.eng
         self.w_train = e.zeros(max(model._n_train, ALIGN))
         self.g_train = e.zeros(max(model._n_train, ALIGN))

@@ -39,9 +39,11 @@ extern "C" {
 #define SG_EINVAL   (-1)  /* bad argument / unsupported shape */
 #define SG_EWORKSPACE (-2) /* workspace too small */
 #define SG_EUNSUPPORTED (-3)
+#define SG_ECOMM    (-4)  /* RCCL reported an error (sg_comm_*) */
 
 #define SG_F32  0
 #define SG_BF16 1
+#define SG_I64  2         /* sg_comm_allreduce_sum only (the four confusion counts) */
 
 /* epilogue flags for conv-like ops */
 #define SG_EPI_BIAS 1
@@ -295,6 +297,28 @@ int sg_vote_ge(sg_ctx* ctx, void* stream, int nmasks, const void* const* masks, 
                void* out_u8);
 /* fill n floats with value (workspace / gradient zeroing without leaving the stream) */
 int sg_fill_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float value);
+/* p[i] *= a in place (1/nranks on the summed loss and on the summed BatchNorm moving statistics of the replicas) */
+int sg_scale_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float a);
+
+/* ------------------------------------------------------------------------------------- data parallelism
+ * The reference trains on one device (train_model/DeepLabv3plus.py:844 fit_generator; no tf.distribute anywhere):
+ * this is the new exchange step of SURVEY.md 8e — one process per GPU, identical replicas, rank r trains on its
+ * own tiles, the flat gradient arena is summed over the ranks once per step (RCCL over xGMI), 1/nranks folded
+ * into sg_adam_step's grad_scale.  RCCL is resolved with dlopen at the first call (SG_EUNSUPPORTED if absent).
+ *   sg_comm_unique_id   rank 0 only: writes SG_COMM_ID_BYTES opaque bytes the caller hands to every rank.
+ *   sg_comm_init        collective over the nranks processes; binds to `device`.
+ *   sg_comm_allreduce_sum  in-place sum of buf[count] (SG_F32 / SG_BF16 / SG_I64) over the ranks, queued on
+ *                       `stream`; no host synchronisation (the host orders it against the compute stream with
+ *                       events, building_detection_amd/dist.py).
+ *   sg_comm_destroy     frees the communicator. */
+#define SG_COMM_ID_BYTES 128
+typedef struct sg_comm sg_comm;
+int sg_comm_unique_id(void* id_out);
+int sg_comm_init(const void* id, int rank, int nranks, int device, sg_comm** out);
+int sg_comm_allreduce_sum(sg_comm* comm, void* stream, int dtype, void* buf, int64_t count);
+int sg_comm_rank(const sg_comm* comm);
+int sg_comm_nranks(const sg_comm* comm);
+int sg_comm_destroy(sg_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,121 @@
+"""Data-parallel step on the GPU: RCCL through libsegengine's sg_comm_* and through torch.distributed.
+
+World size 1 runs on the one-GPU box (the collective degenerates to a copy, but the whole path - id exchange,
+communicator, comm stream, bucket hooks, scalar reductions, rank-0 checkpoint - executes).  The world-size-2 case needs
+two GPUs and is skipped otherwise; it checks the averaged gradient against the two single-rank gradients."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build():
+    from building_detection_amd import zoo
+    from building_detection_amd.losses import edge_focal_loss, PA, IoU, MIoU, F1_score
+    m = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+    m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
+    return m
+
+
+def _worker(rank, world, port, comm, q, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.dist import DataParallel
+    torch.cuda.set_device(rank)
+    backend = "nccl" if comm == "torch" else "gloo"
+    kw = {"device_id": torch.device("cuda", rank)} if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    try:
+        shards = [synthetic_batch(2, 64, 64, seed=40 + r) for r in range(world)]
+        # single-rank references first (no DP attached): gradient arena of every shard, from the same weights
+        ref = _build()
+        rt = ref._runtime()
+        w0 = ref.get_weights()
+        grads, losses, counts = [], [], []
+        for x, y in shards:
+            xd, yd = rt.to_device(x), rt.to_device(y)
+            p = rt.forward(xd, training=True)
+            losses.append(float(rt.eng.loss_fwd(ref.loss_kind, p, yd).item()))
+            counts.append(rt.eng.confusion_counts(p, yd).cpu().numpy())
+            rt.backward(rt.eng.loss_bwd(ref.loss_kind, p, yd, 1.0))
+            grads.append(rt.g_train.clone())
+            rt.release()
+        # the data-parallel model: same weights, own shard
+        m = _build()
+        m.set_weights(w0)
+        dp = DataParallel(m, bucket_mb=8.0, comm=comm)
+        assert dp.tp.name == comm and dp.world == world
+        mrt = m._runtime()
+        x, y = shards[rank]
+        logs = m.train_on_batch(x, y)
+        gsum = mrt.g_train.clone()  # Adam does not touch the gradient arena
+        want = grads[0].clone()
+        for g in grads[1:]:
+            want += g
+        torch.cuda.synchronize()
+        err = float((gsum - want).abs().max() / want.abs().max())
+        # the step itself: Adam on the MEAN gradient == single-process Adam fed the mean gradient
+        chk = _build()
+        chk.set_weights(w0)
+        crt = chk._runtime()
+        crt.g_train.copy_(want)
+        crt.eng.adam_step(crt.w_train, crt.adam_m, crt.adam_v, crt.g_train, 1e-3 * np.sqrt(1 - 0.999) / (1 - 0.9),
+                          grad_scale=1.0 / world)
+        torch.cuda.synchronize()
+        werr = float((crt.w_train - mrt.w_train).abs().max())
+        tot = np.sum(counts, axis=0)
+        from building_detection_amd.losses import metrics_from_counts
+        mets = metrics_from_counts(*[int(v) for v in tot])
+        path = os.path.join(tmp, "ckpt.h5")
+        m.save_weights(path)  # collective: moving statistics averaged, rank 0 writes
+        q.put(dict(rank=rank, err=err, werr=werr, loss=logs["loss"], loss_want=float(np.mean(losses)),
+                   miou=logs["MIoU"], miou_want=mets["MIoU"], wrote=os.path.exists(path), buckets=len(dp.buckets)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(world, comm, tmp_path):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, world, port, comm, q, str(tmp_path))) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in procs:
+            res.append(q.get(timeout=400))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for r in res:
+        assert r["err"] < 1e-6, r           # sum order inside RCCL is the only freedom
+        assert r["werr"] < 1e-7, r
+        assert abs(r["loss"] - r["loss_want"]) < 1e-6 * max(1.0, abs(r["loss_want"])), r
+        assert abs(r["miou"] - r["miou_want"]) < 1e-6, r
+        assert r["wrote"] and r["buckets"] >= 2, r
+    return res
+
+
+@pytest.mark.parametrize("comm", ["sg", "torch"])
+def test_data_parallel_step_world1(engine, comm, tmp_path):
+    _run(1, comm, tmp_path)
+
+
+@pytest.mark.parametrize("comm", ["sg", "torch"])
+def test_data_parallel_step_world2(engine, comm, tmp_path):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run(2, comm, tmp_path)

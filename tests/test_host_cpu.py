@@ -224,3 +224,104 @@ def test_data_parallel_reducer_gloo_world2():
         # buckets [900,1000) [600,900) [300,600) [0,300) fire as the sweep passes nodes 9, 6, 3, 0 - not all at the end
         assert launched == [1, 0, 0, 1, 0, 0, 1, 0, 0, 1]
         assert delta > 0
+
+
+class _RecordingTransport:
+    """Stands in for RCCL: records which arena range was handed over, and when."""
+    name, world, rank = "rec", 1, 0
+
+    def __init__(self):
+        self.calls = []
+
+    def allreduce_async(self, t):
+        self.calls.append((t.data_ptr(), t.numel()))
+
+    def join(self):
+        pass
+
+
+@pytest.mark.parametrize("name", ["v3plus", "bam", "res34"])
+def test_buckets_fire_only_when_complete_on_the_real_graph(name):
+    """on the real (fused) graphs, replay the backward sweep of runtime._Runtime.backward - node n
+    writes the gradients of ITS parameters, then the hook fires - and check that when a bucket is handed to the
+    transport every parameter inside it has been written, that nothing is handed over twice, and that the buckets
+    cover the arena."""
+    from building_detection_amd import zoo
+    from building_detection_amd.dist import BucketReducer, param_ranges, plan_buckets
+    m = zoo.BUILDERS[name]((64, 64, 3), 2, aspp_pool=4) if name in ("v3plus", "bam") else zoo.BUILDERS[name]((64, 64, 3))
+    total = max(m._n_train, 4)
+    arena = torch.zeros(total)
+    ranges = param_ranges(m)
+    buckets = plan_buckets(ranges, total, 1 << 18)
+    assert len(buckets) >= 4
+    tp = _RecordingTransport()
+    red = BucketReducer(arena, buckets, tp)
+    written = torch.zeros(total, dtype=torch.bool)
+    base = arena.data_ptr()
+    seen = 0
+    for n in reversed(m.nodes):
+        for p in n.params:
+            if p.trainable:
+                written[p.offset:p.offset + (p.size + 3) // 4 * 4] = True
+        red.node_done(n.index)
+        for ptr, cnt in tp.calls[seen:]:
+            s = (ptr - base) // 4
+            assert bool(written[s:s + cnt].all()), f"bucket [{s},{s + cnt}) fired at node {n.index} before its gradients were all written"
+        seen = len(tp.calls)
+    red.finish()
+    spans = sorted(((ptr - base) // 4, cnt) for ptr, cnt in tp.calls)
+    pos = 0
+    for s, cnt in spans:
+        assert s == pos
+        pos += cnt
+    assert pos == total
+    # the overlap is real: the first bucket leaves long before the sweep ends
+    assert red.fired[0][0] > len(m.nodes) // 2
+
+
+def _dp_graph_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from building_detection_amd import zoo
+    from building_detection_amd.dist import BucketReducer, param_ranges, plan_buckets
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    m = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+    total = m._n_train
+    arena = torch.zeros(total)
+    red = BucketReducer(arena, plan_buckets(param_ranges(m), total, 1 << 20))
+
+    def grad_of(p, r):  # what rank r's backward writes for parameter p
+        return torch.rand(p.size, generator=torch.Generator().manual_seed(p.offset * 7 + r))
+
+    for n in reversed(m.nodes):  # the sweep of runtime._Runtime.backward: write, then the hook
+        for p in n.params:
+            if p.trainable:
+                arena[p.offset:p.offset + p.size] = grad_of(p, rank)
+        red.node_done(n.index)
+    red.finish()
+    ok = True
+    for p in m.params:
+        if p.trainable:
+            want = sum(grad_of(p, r) for r in range(world))
+            ok = ok and torch.allclose(arena[p.offset:p.offset + p.size], want, atol=1e-6)
+    q.put((rank, bool(ok), len(red.buckets)))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_real_graph_sweep_gloo_world2():
+    """World-size-2 gloo run of the bucketed reducer over the DeepLabv3+ arena with the real node order: a bucket fired
+    before its last gradient was written would miss that rank-specific value in the sum."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_dp_graph_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, nb in res:
+        assert ok, f"rank {rank}: reduced arena != sum of the per-rank gradients"
+        assert nb >= 4

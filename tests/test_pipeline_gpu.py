@@ -114,3 +114,61 @@ def test_file_generator_feeds_fit_generator(engine, tmp_path):
     logs = hist.history
     for k in ("loss", "PA", "IoU", "MIoU", "F1_score", "val_loss", "val_PA"):
         assert k in logs and np.isfinite(logs[k][-1]), (k, logs)
+
+
+def test_two_live_graphs_keep_their_own_workspace(engine):
+    """a hipGraph bakes the scratch pointer into its kernel nodes.  Two captured models with different
+    workspace needs stay alive together, the engine's shared scratch is re-grown (freed) in between by a bigger eager
+    call, and interleaved replays must still equal the eager results bit for bit."""
+    from building_detection_amd import zoo
+    small = zoo.BUILDERS["hrnet"]((64, 64, 3))
+    big = zoo.BUILDERS["v3plus"]((128, 128, 3), 2, aspp_pool=8)
+    g = torch.Generator().manual_seed(21)
+    xs = (torch.rand(2, 64, 64, 3, generator=g) * 2 - 1).cuda()
+    xb = (torch.rand(2, 128, 128, 3, generator=g) * 2 - 1).cuda()
+    es, eb = small.predict_device(xs).clone(), big.predict_device(xb).clone()
+    gs = small.capture_predict(2)
+    gb = big.capture_predict(2)
+    assert gs.ws.data_ptr() != gb.ws.data_ptr() != engine._ws.data_ptr()
+    # force the shared scratch to be replaced, then scribble over whatever the allocator hands out next
+    engine.ws(engine._ws.numel() * 2 + (64 << 20))
+    junk = [torch.full((1 << 22,), float("nan"), device="cuda") for _ in range(8)]
+    for _ in range(2):
+        assert torch.equal(gs(xs), es)
+        assert torch.equal(gb(xb), eb)
+    del junk
+    assert torch.equal(small.predict_device(xs), es)  # eager path still fine on the re-grown shared scratch
+    assert torch.equal(gb(xb), eb)
+
+
+def test_predict_is_serialised_across_threads(engine):
+    """SURVEY 8(b-1) threading note (buildAPI.py:78,111: Flask request threads share the models): concurrent
+    predict() calls on ONE model, and on two models sharing the device, return exactly the single-threaded result."""
+    import threading
+    from building_detection_amd import zoo
+    m1 = zoo.BUILDERS["hrnet"]((64, 64, 3))
+    m2 = zoo.BUILDERS["v3plus"]((64, 64, 3), 2, aspp_pool=4)
+    rng = np.random.default_rng(5)
+    xs = [rng.uniform(-1, 1, size=(2, 64, 64, 3)) for _ in range(4)]
+    ref1 = [m1.predict(x) for x in xs]
+    ref2 = [m2.predict(x) for x in xs]
+    errs = []
+
+    def worker(model, refs, order):
+        try:
+            for _ in range(6):
+                for i in order:
+                    got = model.predict(xs[i])
+                    if not np.array_equal(got, refs[i]):
+                        errs.append(f"{model.name}: input {i} differs")
+        except Exception as e:  # a clobbered value table shows up as KeyError / shape errors
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(m1, ref1, [0, 1, 2, 3])),
+          threading.Thread(target=worker, args=(m1, ref1, [3, 2, 1, 0])),
+          threading.Thread(target=worker, args=(m2, ref2, [1, 3, 0, 2]))]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs[:5]
