@@ -99,6 +99,7 @@ _SIGNATURES = {
     "sg_argmax_accumulate_i8": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i]),
     "sg_vote_ge": (_i, [_vp, _vp, _i, _pp, _i64, _i, _vp]),
     "sg_fill_f32": (_i, [_vp, _vp, _vp, _i64, _f]),
+    "sg_trace_mark": (_i, [_vp, _vp, _i, _i]),
     "sg_scale_f32": (_i, [_vp, _vp, _vp, _i64, _f]),
     "sg_comm_unique_id": (_i, [_vp]),
     "sg_comm_init": (_i, [_vp, _i, _i, _i, _pp]),

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import contextlib
 import ctypes as C
+import os
 import threading
 from typing import Optional, Sequence, Tuple
 
@@ -52,6 +53,10 @@ def _chk(t: torch.Tensor, name: str):
         raise _lib.SgError(f"{name}: tensor must be contiguous")
 
 
+_TRACE_MARK = os.environ.get("SG_TRACE_MARK", "0") == "1"
+_MARK_TAGS = {"dilated_conv": 0, "gemm_conv": 1}
+
+
 class _Timed:
     """`with eng.timed(tag):` brackets the launches inside with two HIP events on the current stream while a
     profile is open (eng.profile_begin()); otherwise it is free."""
@@ -63,6 +68,8 @@ class _Timed:
 
     def __enter__(self):
         if getattr(self.eng, "_prof", None) is not None and self.tag:
+            if _TRACE_MARK and self.tag in _MARK_TAGS:  # named marker kernels for a rocprofv3 kernel trace
+                self.eng.lib.sg_trace_mark(self.eng.h, self.eng.stream, _MARK_TAGS[self.tag], 0)
             self.a = torch.cuda.Event(enable_timing=True)
             self.a.record(torch.cuda.current_stream(self.eng.device))
         return self
@@ -72,6 +79,8 @@ class _Timed:
             b = torch.cuda.Event(enable_timing=True)
             b.record(torch.cuda.current_stream(self.eng.device))
             self.eng._prof.setdefault(self.tag, []).append((self.a, b))
+            if _TRACE_MARK and self.tag in _MARK_TAGS:
+                self.eng.lib.sg_trace_mark(self.eng.h, self.eng.stream, _MARK_TAGS[self.tag], 1)
         return False
 
 

@@ -297,6 +297,10 @@ int sg_vote_ge(sg_ctx* ctx, void* stream, int nmasks, const void* const* masks, 
                void* out_u8);
 /* fill n floats with value (workspace / gradient zeroing without leaving the stream) */
 int sg_fill_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float value);
+/* Profiling aid: launches an empty one-thread kernel named sg_trace_mark_kernel<tag, end> on `stream`, so that a
+ * rocprofv3 --kernel-trace of a whole training step shows where a group of launches begins (end = 0) and ends
+ * (end = 1).  tag 0 = the north_star dilated-convolution set, tag 1 = any GEMM convolution (scripts/trace_dilated.py). */
+int sg_trace_mark(sg_ctx* ctx, void* stream, int tag, int end);
 /* p[i] *= a in place (1/nranks on the summed loss and on the summed BatchNorm moving statistics of the replicas) */
 int sg_scale_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float a);
 
