@@ -226,6 +226,21 @@ def main():
             traffic = int(tr["set_bytes_per_step"])
             traffic_note = ("bytes per step of the kernel set, L2-miss side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits "
                             "included); algorithmic bytes of the set = %d" % int(tr["algorithmic_bytes_per_step"]))
+        # Executed share of the nominal FLOPs: the kernels skip whole padding taps (exact: the skipped products are x0), so
+        # the matrix pipe executes fewer bf16 MFMA operations than 6 x nominal.  Counted by SQ_INSTS_VALU_MFMA_MOPS_BF16
+        # (x512 FLOP) in a separate rocprofv3 --pmc pass over this kernel set (scripts/pmc_mfma.py); it depends on the
+        # shapes only, not on the run.
+        exec_ratio, exec_note = None, "no PMC pass for this configuration"
+        pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_mfma.json")
+        if args.batch == 16 and args.size == 512 and x6 and os.path.exists(pj):
+            with open(pj) as f:
+                k = json.load(f)["kernels"]
+            # the profiled script launches every forward 3x, dgrad / wgrad 2x (warm-up + ITERS=1): 30 and 12 launches
+            executed = (k["x6_fwd_dgrad"]["bf16_mfma_flops"] * 12 / k["x6_fwd_dgrad"]["launches"]
+                        + k["x6_wgrad"]["bf16_mfma_flops"] * 6 / k["x6_wgrad"]["launches"]) / 6.0  # fp32-equivalent
+            exec_ratio = executed / (dil_tflop * 1e12)
+            exec_note = ("bf16 MFMA FLOPs executed per step (SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512, profiles/r01_pmc_mfma.json) / 6 "
+                         "/ nominal FLOPs: padding taps of the dilated convs are skipped, not multiplied")
         out = {
             "metric": f"{args.size}x{args.size} tiles/sec fwd+bwd {LABEL.get(args.model, args.model)} (full train step: fwd+loss+bwd+Adam)",
             "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
@@ -244,6 +259,9 @@ def main():
                          "frac": None if achieved is None else round(achieved / peak, 4),
                          "peak_note": peak_note,
                          "frac_vs_fp32_mfma_peak": None if achieved is None else round(achieved / FP32_MFMA_PEAK_TFLOPS, 4),
+                         "executed_share_of_nominal": None if exec_ratio is None else round(exec_ratio, 4),
+                         "frac_executed": None if (achieved is None or exec_ratio is None) else round(achieved * exec_ratio / peak, 4),
+                         "frac_executed_note": exec_note,
                          "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": ("conv_x6_kernel / wgrad_x6_kernel" if x6 else "igemm_conv_kernel / igemm_wgrad_kernel") + " on the 6 dilated 3x3 convs (fwd+dgrad+wgrad)",
                          "ms_per_step": round(dil_ms, 3), "launches_per_step": prof.get("dilated_conv_launches", 0) // max(args.steps, 1)},

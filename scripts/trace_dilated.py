@@ -12,8 +12,25 @@ first timed step so that each of the 18 launch groups (6 convs x fwd / wgrad / d
 import csv
 import glob
 import json
+import re
 import sys
 from collections import defaultdict
+
+
+def short_name(name: str) -> str:
+    """'void (anonymous namespace)::conv_x6_kernel<128, 2, 4, 1>(Args...)' -> 'conv_x6_kernel<128, 2, 4, 1>'"""
+    n = name.replace("(anonymous namespace)::", "")
+    n = re.sub(r"^void\s+", "", n)
+    depth, out = 0, []
+    for ch in n:  # cut at the argument list: the first '(' outside template brackets
+        if ch == "<":
+            depth += 1
+        elif ch == ">":
+            depth -= 1
+        elif ch == "(" and depth == 0:
+            break
+        out.append(ch)
+    return "".join(out).strip()[:100]
 
 src, steps, dst = sys.argv[1], int(sys.argv[2]), sys.argv[3]
 rows_out = sys.argv[4] if len(sys.argv) > 4 else None
@@ -36,12 +53,15 @@ for s, e, name, grid, wg in rows:
         continue
     if inside and "sg_trace_mark_kernel" not in name:
         cur.append((name, grid, wg, e - s))
-per_step_groups = len(groups) // steps
+# bench.py runs 2 more steps after the timed ones with EVERY conv bracketed (roofline.family): they carry the same
+# dilated markers, so the trace holds steps + 2 steps' worth of groups; only the first `steps` are the timed region
+per_step_groups = len(groups) // (steps + 2) if len(groups) % (steps + 2) == 0 else len(groups) // steps
+groups = groups[:per_step_groups * steps]
 by_name = defaultdict(lambda: [0, 0])
 tot = 0
 for g in groups:
     for name, grid, wg, d in g:
-        short = name.split("(")[0]
+        short = short_name(name)
         by_name[short][0] += 1
         by_name[short][1] += d
         tot += d
@@ -58,4 +78,4 @@ if rows_out:
         w.writerow(["group", "kernel", "grid", "workgroup", "duration_us"])
         for gi, g in enumerate(groups[:per_step_groups]):
             for name, grid, wg, d in g:
-                w.writerow([gi, name.split("(")[0][:120], grid, wg, round(d / 1e3, 2)])
+                w.writerow([gi, short_name(name), grid, wg, round(d / 1e3, 2)])

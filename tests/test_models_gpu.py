@@ -74,12 +74,18 @@ def test_inference_parity(engine, name, size, kw):
     print(f"{name}: |gpu-cpu32|={err_gpu32:.2e} |gpu-fp64|={err_gpu64:.2e} |cpu32-fp64|={err_cpu64:.2e}")
     assert err_gpu32 <= 1e-3, f"{name}: north_star bar: max |p_gpu - p_cpu| = {err_gpu32:.3e} > 1e-3"
     assert err_gpu64 <= 4 * err_cpu64 + 1e-4, f"{name}: gpu fp32 error {err_gpu64:.3e} vs cpu fp32 error {err_cpu64:.3e}"
+    # argmax masks: bit-identical wherever the oracle's own class margin exceeds TIE (an fp32 evaluation - the CPU
+    # oracle's as much as the GPU's - cannot resolve a margin below its own distance from fp64); the pixels inside
+    # the margin are counted and printed, never silently excused
+    TIE = max(1e-6, 2 * err_cpu64)
     mg, mc = pg[..., 1] > pg[..., 0], p64[..., 1] > p64[..., 0]
-    diff = mg != mc
-    if diff.any():
-        margin = float(np.abs(p64[..., 1] - p64[..., 0])[diff].max())
-        assert margin <= 2 * err_gpu64 + 1e-7, f"{name}: {int(diff.sum())} mask pixels differ outside near-ties (margin {margin:.3e})"
-    print(f"{name}: argmax masks differ on {int(diff.sum())} of {diff.size} pixels (near-ties only)")
+    margin = np.abs(p64[..., 1] - p64[..., 0])
+    strict = margin > TIE
+    bad = int((mg != mc)[strict].sum())
+    excused = int((mg != mc)[~strict].sum())
+    print(f"{name}: argmax masks: {int((~strict).sum())} of {strict.size} pixels inside the tie margin {TIE:.1e}, "
+          f"{excused} of them differ; outside the margin {bad} differ")
+    assert bad == 0, f"{name}: {bad} mask pixels differ where the oracle's margin exceeds {TIE:.1e}"
 
 
 @pytest.mark.parametrize("name,size,kw", CASES, ids=[c[0] for c in CASES])
@@ -290,31 +296,184 @@ def test_fit_generator_tracks_the_oracle_over_several_steps(engine):
     hist = model.fit_generator(gen(), steps_per_epoch=steps, epochs=1, verbose=0, callbacks=[sched, Rec()])
     assert abs(hist.history["loss"][0] - float(np.mean(losses_gpu))) < 1e-6   # epoch log = mean of the batch values
 
-    # the oracle's four steps
-    P = M.Params(weights=ws0, dtype=torch.float64)
-    tr = None
-    m = v = None
-    losses_cpu = []
-    for s, (x, y) in enumerate(batches):
-        p = M.hrnet(P, torch.from_numpy(x).double(), training=True)
-        loss = M.loss_fn("edge_focal_loss", torch.from_numpy(y).double(), p)
-        tr = P.trainable_tensors()
-        for t in tr:
-            t.grad = None
-        loss.backward()
-        losses_cpu.append(loss.item())
-        if m is None:
-            m, v = [torch.zeros_like(t) for t in tr], [torch.zeros_like(t) for t in tr]
-        lr = M.cosine_decay_with_warmup(s, 1e-3, 40, warmup_learning_rate=1e-5, warmup_steps=2)
-        M.adam_step(tr, [t.grad for t in tr], m, v, s + 1, lr)
-    print("loss per step gpu", [f"{a:.6f}" for a in losses_gpu], "cpu", [f"{a:.6f}" for a in losses_cpu])
-    # step 0 sees identical weights; afterwards the sign-like first Adam updates amplify ReLU-flip noise of the
-    # gradients into the weights, so the trajectories separate slowly (a stale-state bug separates them at once)
-    for a, b, tol in zip(losses_gpu, losses_cpu, (1e-5, 2e-3, 2e-2, 2e-2)):
-        assert abs(a - b) <= tol * abs(b), (losses_gpu, losses_cpu)
-    w_gpu = [w for w, prm in zip(model.get_weights(), model.params) if prm.trainable]
-    num = sum(float(np.square(a.astype(np.float64) - t.detach().numpy()).sum()) for a, t in zip(w_gpu, tr))
-    den = sum(float(np.square(t.detach().numpy() - w0.astype(np.float64)).sum())
-              for t, w0 in zip(tr, [w for w, prm in zip(ws0, model.params) if prm.trainable]))
-    print(f"weights after {steps} steps: |w_gpu - w_cpu| / |w_cpu - w_0| = {(num / den) ** 0.5:.3f}")
-    assert (num / den) ** 0.5 <= 0.35   # the update itself is reproduced (sign-like Adam steps amplify ReLU-flip noise)
+    # the oracle's four steps, in fp64 (the yardstick) AND in fp32 (what a correct fp32 implementation does)
+    def oracle_run(dtype):
+        P = M.Params(weights=ws0, dtype=dtype)
+        tr = m = v = None
+        losses = []
+        for s, (x, y) in enumerate(batches):
+            p = M.hrnet(P, torch.from_numpy(x).to(dtype), training=True)
+            loss = M.loss_fn("edge_focal_loss", torch.from_numpy(y).to(dtype), p)
+            tr = P.trainable_tensors()
+            for t in tr:
+                t.grad = None
+            loss.backward()
+            losses.append(loss.item())
+            if m is None:
+                m, v = [torch.zeros_like(t) for t in tr], [torch.zeros_like(t) for t in tr]
+            lr = M.cosine_decay_with_warmup(s, 1e-3, 40, warmup_learning_rate=1e-5, warmup_steps=2)
+            M.adam_step(tr, [t.grad for t in tr], m, v, s + 1, lr)
+        return losses, [t.detach().double().numpy() for t in tr]
+
+    l64, w64 = oracle_run(torch.float64)
+    l32, w32 = oracle_run(torch.float32)
+    print("loss per step gpu", [f"{a:.6f}" for a in losses_gpu], "cpu fp32", [f"{a:.6f}" for a in l32], "cpu fp64",
+          [f"{a:.6f}" for a in l64])
+    # Step 0 sees identical weights.  Afterwards Adam's first updates are sign-like (m / sqrt(v) = +-1 whatever the
+    # gradient's size), which turns fp32 rounding of small gradients into O(lr) weight differences: the fp32 CPU oracle
+    # itself leaves the fp64 trajectory by 3e-5 / 3.5e-3 / 1.5e-2 at steps 1 / 2 / 3 (measured here, printed above).
+    # The engine is held to that yardstick: its distance from fp64 may not exceed K times the fp32 oracle's own.
+    K = 3.0
+    for i, (a, c, b) in enumerate(zip(losses_gpu, l32, l64)):
+        assert abs(a - b) <= K * abs(c - b) + 1e-5 * abs(b), f"step {i}: gpu {a} cpu-fp32 {c} fp64 {b}"
+    w0 = [w.astype(np.float64) for w, prm in zip(ws0, model.params) if prm.trainable]
+    w_gpu = [w.astype(np.float64) for w, prm in zip(model.get_weights(), model.params) if prm.trainable]
+    den = sum(float(np.square(t - o).sum()) for t, o in zip(w64, w0))
+    r_gpu = (sum(float(np.square(a - t).sum()) for a, t in zip(w_gpu, w64)) / den) ** 0.5
+    r_cpu = (sum(float(np.square(a - t).sum()) for a, t in zip(w32, w64)) / den) ** 0.5
+    print(f"weights after {steps} steps, |w - w_fp64| / |w_fp64 - w_0|: gpu {r_gpu:.3f}, cpu fp32 oracle {r_cpu:.3f}")
+    assert r_gpu <= 1.5 * r_cpu + 0.02   # the update itself is reproduced as well as an fp32 CPU run reproduces it
+
+
+def _chain2_reference(seed):
+    """fp64 autograd reference of the multi-op chain of test_backward_chain_exact_multi_op; also returns the smallest
+    |pre-activation| in front of the two ReLUs that are not applied to an input (a flip there is fp32 noise, not a bug)."""
+    from building_detection_amd.data import synthetic_batch
+    from oracle import tfops as T
+    g = torch.Generator().manual_seed(seed)
+    N, H, C, C2 = 2, 32, 64, 32
+    D = torch.float64
+
+    def rn(*s, scale=1.0):
+        return torch.randn(*s, generator=g) * scale
+
+    t = dict(x=rn(N, H, H, C), dw=rn(3, 3, C, 1, scale=0.3), pw=rn(1, 1, C, C, scale=0.1), bpw=rn(C, scale=0.1),
+             gam=1 + rn(C, scale=0.1), bet=rn(C, scale=0.1), wk=rn(1, 1, C, C, scale=0.1), bk=rn(C, scale=0.1),
+             ws=rn(1, 1, C, 1, scale=0.2), bs=rn(1, scale=0.1), wc1=rn(1, 1, C, C // 16, scale=0.3), bc1=rn(C // 16, scale=0.1),
+             wc2=rn(1, 1, C // 16, C, scale=0.3), bc2=rn(C, scale=0.1), wT=rn(3, 3, C2, C, scale=0.05), bT=rn(C2, scale=0.05),
+             w5=rn(1, 1, C2, 2, scale=0.3), b5=rn(2, scale=0.1))
+    _, y = synthetic_batch(N, 2 * H, 2 * H, seed=5)
+
+    def centre_of_widest_gap(v):
+        """per channel (last axis): minus the midpoint of the widest gap between consecutive sorted values inside
+        [-0.3, 0.3] sigma - adding it as the bias puts every pre-activation of the channel at least half that gap from 0"""
+        flat = v.reshape(-1, v.shape[-1])
+        out = torch.zeros(v.shape[-1], dtype=D)
+        for c in range(v.shape[-1]):
+            col = flat[:, c].sort().values
+            sd = float(col.std())
+            col = col[(col > -0.3 * sd) & (col < 0.3 * sd)]
+            gaps = col[1:] - col[:-1]
+            i = int(gaps.argmax())
+            out[c] = -(col[i] + col[i + 1]) / 2
+        return out
+
+    with torch.no_grad():  # choose the two biases in front of ReLUs so that no pre-activation sits near 0 (see docstring)
+        q = {k: v.to(D) for k, v in t.items()}
+        z1 = T.separable_conv2d(torch.relu(q["x"]), q["dw"], q["pw"], q["bpw"])
+        a0, _, _ = T.batch_norm(z1, q["gam"], torch.zeros(C, dtype=D), torch.zeros(C, dtype=D), torch.ones(C, dtype=D), True)
+        t["bet"] = centre_of_widest_gap(a0).float()
+        s = torch.relu(a0 + t["bet"].to(D)) + T.conv2d(q["x"], q["wk"], q["bk"])
+        sl = T.conv2d(s, q["ws"], q["bs"])
+        cl = T.conv2d(T.conv2d(T.global_avg_pool(s).view(N, 1, 1, C), q["wc1"], q["bc1"]), q["wc2"], q["bc2"])
+        u0 = T.conv2d_transpose(s * (torch.sigmoid(sl) + torch.sigmoid(cl)), q["wT"], None)
+        t["bT"] = centre_of_widest_gap(u0).float()
+    p = {k: v.to(D).clone().requires_grad_() for k, v in t.items()}
+    z1 = T.separable_conv2d(torch.relu(p["x"]), p["dw"], p["pw"], p["bpw"])
+    a1, _, _ = T.batch_norm(z1, p["gam"], p["bet"], torch.zeros(C, dtype=D), torch.ones(C, dtype=D), True)
+    s = torch.relu(a1) + T.conv2d(p["x"], p["wk"], p["bk"])
+    sl = T.conv2d(s, p["ws"], p["bs"])
+    cl = T.conv2d(T.conv2d(T.global_avg_pool(s).view(N, 1, 1, C), p["wc1"], p["bc1"]), p["wc2"], p["bc2"])  # no ReLU between (v3plus.py:147-167)
+    y2 = s * (torch.sigmoid(sl) + torch.sigmoid(cl))
+    pre_u = T.conv2d_transpose(y2, p["wT"], p["bT"])
+    u = torch.relu(pre_u)
+    prob = torch.softmax(T.conv2d(u, p["w5"], p["b5"]), -1)
+    loss = M.loss_fn("edge_focal_loss", torch.from_numpy(y).to(D), prob)
+    loss.backward()
+    margin = min(float(a1.detach().abs().min()), float(pre_u.detach().abs().min()))
+    return t, y, {k: v.grad for k, v in p.items()}, loss.item(), margin
+
+
+def test_backward_chain_exact_multi_op(engine):
+    """ONE chain through SeparableConv2D (pre-ReLU folded into the depthwise gather, BN statistics
+    from the pointwise epilogue) -> BatchNormalization(train)+ReLU -> Add with a 1x1 projection -> scSE (sSE conv, GAP ->
+    two 1x1 convs, fused combine) -> Conv2DTranspose 3x3 s2 + ReLU -> 1x1 softmax head -> edge_focal_loss, launched op
+    by op exactly as layers.py launches it; loss and EVERY gradient (all 16 weights and the input) within 1e-5 of fp64
+    autograd, relative to the tensor's largest entry.  BN's beta and the transposed
+    convolution's bias are placed (per channel, in the widest gap of the pre-activations around 0) so that no ReLU input
+    lies within 1e-5 of zero (asserted): there is no flip noise to excuse."""
+    from building_detection_amd import _lib
+    e = engine
+    t, y, ref, loss_ref, margin = _chain2_reference(seed=2)
+    assert margin > 1e-5, f"seed puts a ReLU pre-activation at {margin:.1e}: pick another seed"
+    d = {k: v.cuda().contiguous() for k, v in t.items()}
+    yd = torch.from_numpy(y).float().cuda()
+    x = d["x"]
+    N, H, _, C = x.shape
+    C2 = d["wT"].shape[2]
+    RELU = _lib.SG_ACT_RELU
+    # ---- forward (layers._SepConvNode / _BNNode / _AddNode / scse_block / _ConvTNode / _ConvNode)
+    tt = e.dwconv_fwd(x, d["dw"], 1, True)
+    z1, st = e.conv2d_fwd(tt, d["pw"], d["bpw"], want_stats=True)
+    mm, mv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    if st is not None:
+        y1, mean, invstd = e.bn_train_fwd_from_tiles(z1, st[0], st[1], d["gam"], d["bet"], mm, mv, relu=True)
+    else:
+        y1, mean, invstd = e.bn_train_fwd(z1, d["gam"], d["bet"], mm, mv, relu=True)
+    skip = e.conv2d_fwd(x, d["wk"], d["bk"])
+    s = e.add_n([y1, skip])
+    sl = e.conv2d_fwd(s, d["ws"], d["bs"])
+    gp = e.avgpool_fwd(s, H, H)
+    c1 = e.conv2d_fwd(gp, d["wc1"], d["bc1"])
+    cl = e.conv2d_fwd(c1, d["wc2"], d["bc2"])
+    y2 = e.scse_fwd(s, sl, cl)
+    fd = e.conv_desc((N, 2 * H, 2 * H, C2), C, 3, 3, 2, 1, "same")
+    u = e.conv2d_dgrad(y2, d["wT"], fd, bias=d["bT"], relu=True)
+    prob = e.softmax2_fwd(e.conv2d_fwd(u, d["w5"], d["b5"]))
+    loss = float(e.loss_fwd(2, prob, yd).item())
+    assert abs(loss - loss_ref) <= 2e-6 * abs(loss_ref), (loss, loss_ref)
+    # ---- backward
+    got = {}
+    dz = e.softmax2_bwd(prob, e.loss_bwd(2, prob, yd))
+    d5 = e.conv_desc(tuple(u.shape), 2, 1, 1)
+    got["w5"], got["b5"] = e.conv2d_wgrad(u, dz, d5)
+    du = e.conv2d_dgrad(dz, d["w5"], d5)
+    dzu = e.act_bwd(u, du, RELU)
+    got["wT"], _ = e.conv2d_wgrad(dzu, y2, fd, want_bias=False)
+    got["bT"] = e.bias_grad(dzu, e.empty(C2))
+    dy2 = e.conv2d_fwd(dzu, d["wT"], None, desc=fd)
+    ds, dsl, dcl = e.scse_bwd(s, sl, cl, dy2)
+    dc2 = e.conv_desc(tuple(c1.shape), C, 1, 1)
+    got["wc2"], got["bc2"] = e.conv2d_wgrad(c1, dcl, dc2)
+    dc1v = e.conv2d_dgrad(dcl, d["wc2"], dc2)
+    dc1 = e.conv_desc(tuple(gp.shape), C // 16, 1, 1)
+    got["wc1"], got["bc1"] = e.conv2d_wgrad(gp, dc1v, dc1)
+    dgp = e.conv2d_dgrad(dc1v, d["wc1"], dc1)
+    ds_g = e.avgpool_bwd(dgp, tuple(s.shape), H, H)
+    dsd = e.conv_desc(tuple(s.shape), 1, 1, 1)
+    got["ws"], got["bs"] = e.conv2d_wgrad(s, dsl, dsd)
+    ds_s = e.conv2d_dgrad(dsl, d["ws"], dsd)
+    ds = e.add_n([ds, ds_g, ds_s])
+    dk = e.conv_desc(tuple(x.shape), C, 1, 1)
+    got["wk"], got["bk"] = e.conv2d_wgrad(x, ds, dk)
+    dx_skip = e.conv2d_dgrad(ds, d["wk"], dk)
+    dz1, got["gam"], got["bet"] = e.bn_train_bwd(z1, y1, ds, d["gam"], mean, invstd, relu=True, beta=d["bet"])
+    dpw = e.conv_desc(tuple(tt.shape), C, 1, 1)
+    got["pw"], got["bpw"] = e.conv2d_wgrad(tt, dz1, dpw)
+    dt = e.conv2d_dgrad(dz1, d["pw"], dpw)
+    ddw = e.conv_desc(tuple(x.shape), C, 3, 3, 1, 1, "same")
+    got["dw"] = e.dwconv_wgrad(x, dt, ddw, True)
+    got["x"] = e.add_n([e.dwconv_dgrad(dt, d["dw"], ddw, x=x, pre_relu=True), dx_skip])
+    worst = ("", 0.0)
+    for k, r in ref.items():
+        a, b = got[k].detach().cpu().double().reshape(-1), r.reshape(-1)
+        rel = float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
+        if rel > worst[1]:
+            worst = (k, rel)
+        # bpw feeds BatchNormalization: its true gradient is 0 (fp64 autograd returns ~1e-19); hold it to noise level
+        if k == "bpw":
+            assert float(a.abs().max()) <= 1e-6 * float(ref["pw"].abs().max()), (k, float(a.abs().max()))
+            continue
+        assert rel <= 1e-5, (k, rel)
+    print(f"multi-op chain: loss gpu {loss:.7f} fp64 {loss_ref:.7f}; worst gradient {worst[0]} rel {worst[1]:.2e}; "
+          f"smallest |ReLU pre-activation| {margin:.2e}")

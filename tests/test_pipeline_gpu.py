@@ -44,11 +44,26 @@ def test_detection_matches_reference_loop(engine, h, w):
     # smooth blobs so the mask is not pure noise
     img[h // 4:h // 2, w // 5:w // 2] //= 3
     got = PL.detection(img, None, model, batch=3)
-    ref = OP.detection_ref(img, oracle_predict_fn(ws))
+    # the restatement's predict_fn also records where ITS class margin is below 1e-6 (an fp32 evaluation cannot resolve
+    # such a pixel): the masks must agree exactly everywhere else; the near-tie pixels are counted and printed
+    base_fn = oracle_predict_fn(ws)
+    (ch, cw), origins = PL.tile_origins(h, w, True)
+    near = np.zeros((ch, cw), bool)
+    it = iter(origins)
+
+    def fn(tile):
+        p = base_fn(tile)
+        i, j = next(it)  # detection_ref visits the tiles in tile_origins order (predict.py:105-106)
+        near[i:i + 512, j:j + 512] |= np.abs(p[0, ..., 1] - p[0, ..., 0]) <= 1e-6
+        return p
+
+    ref = OP.detection_ref(img, fn)
     assert got.shape == ref.shape == (h, w) and got.dtype == np.uint8
-    mism = int((got != ref).sum())
-    # fp32 (engine) vs fp64 (restatement) can flip exact near-ties only
-    assert mism <= 1e-4 * h * w, f"{mism} of {h * w} mask pixels differ"
+    diff = got != ref
+    strict_bad = int((diff & ~near[:h, :w]).sum())
+    print(f"{h}x{w}: {int(near[:h, :w].sum())} near-tie pixels, {int((diff & near[:h, :w]).sum())} of them differ; "
+          f"{strict_bad} differ elsewhere")
+    assert strict_bad == 0, f"{strict_bad} of {h * w} mask pixels differ outside the 1e-6 tie margin"
     assert set(np.unique(got)) <= {0, 255}
     if w > h + 360:  # the reference's column loop never reaches the right-hand tiles (predict.py:106)
         assert got[:, 872:].max() == 0
