@@ -6,9 +6,10 @@
 
 namespace {
 
+template <typename T>
 struct BnStatsOp {
   static constexpr int NOUT = 2;
-  const float* __restrict__ x;
+  const T* __restrict__ x;
   int C;
   int64_t rows;
   float* moving_mean;
@@ -33,7 +34,7 @@ struct BnStatsOp {
   __device__ __forceinline__ void finalize(int, int c, const double (&s)[2]) const {
     const double n = (double)rows;
     const double m1 = s[0] / n;
-    const double mean = (double)x[c] + m1;
+    const double mean = (double)ld1<T>(x + c) + m1;
     double var = s[1] / n - m1 * m1;
     if (var < 0.0) var = 0.0;
     save_mean[c] = (float)mean;
@@ -44,11 +45,12 @@ struct BnStatsOp {
   }
 };
 
+template <typename T>
 struct BnBwdOp {
   static constexpr int NOUT = 2;  // sum dy, sum dy * xhat
-  const float* __restrict__ x;
-  const float* __restrict__ y;
-  const float* __restrict__ dy;
+  const T* __restrict__ x;
+  const T* __restrict__ y;
+  const T* __restrict__ dy;
   const float* __restrict__ mean;
   const float* __restrict__ invstd;
   const float* __restrict__ gamma;  // with beta: the ReLU mask is recomputed from x instead of read from y
@@ -91,10 +93,10 @@ struct BnBwdOp {
   }
 };
 
-template <int V>
-__global__ void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+template <int V, typename T>
+__global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ mean,
                                 const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float* __restrict__ y, int64_t rows, int C, int relu,
+                                const float* __restrict__ beta, T* __restrict__ y, int64_t rows, int C, int relu,
                                 float eps, int infer, FastDiv fd_cv) {
   const uint32_t cv = C / V;
   const uint32_t total = (uint32_t)(rows * cv);
@@ -119,12 +121,12 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, const float* __rest
   }
 }
 
-template <int V>
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
-                                    const float* __restrict__ dy, const float* __restrict__ mean,
+template <int V, typename T>
+__global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                    const T* __restrict__ dy, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ dgamma,
-                                    const float* __restrict__ dbeta, float* __restrict__ dx, int64_t rows, int C, int relu,
+                                    const float* __restrict__ dbeta, T* __restrict__ dx, int64_t rows, int C, int relu,
                                     FastDiv fd_cv) {
   const uint32_t cv = C / V;
   const uint32_t total = (uint32_t)(rows * cv);
@@ -170,6 +172,21 @@ inline unsigned ew_blocks(int64_t total) {
   return (unsigned)b;
 }
 
+template <typename T>
+int launch_bn_apply(hipStream_t st, bool vec, const T* x, const float* mean, const float* invstd, const float* gamma,
+                    const float* beta, T* y, int64_t rows, int C, int relu, float eps, int infer) {
+  const int V = vec ? 4 : 1;
+  const unsigned blocks = ew_blocks(rows * (C / V));
+  if (vec)
+    hipLaunchKernelGGL((bn_apply_kernel<4, T>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, y, rows, C, relu, eps,
+                       infer, make_fastdiv((uint32_t)(C / V)));
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, y, rows, C, relu, eps,
+                       infer, make_fastdiv((uint32_t)(C / V)));
+  SG_LAUNCH_CHECK("bn_apply_kernel");
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -186,7 +203,7 @@ int sg_bn_train_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
                     const void* beta, void* moving_mean, void* moving_var, void* y, void* save_mean,
                     void* save_invstd, float momentum, float eps, int relu, int unbiased_update, void* ws,
                     size_t ws_bytes) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_train_fwd: bad ctx/dtype");
+  SG_CHECK_ARG(ctx && (dtype == SG_F32 || dtype == SG_BF16), "sg_bn_train_fwd: bad ctx/dtype");
   SG_CHECK_ARG(rows > 0 && C > 0 && x && gamma && beta && moving_mean && moving_var && y && save_mean && save_invstd,
                "sg_bn_train_fwd: bad argument");
   SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_train_fwd: tensor exceeds 2^31 elements");
@@ -197,29 +214,24 @@ int sg_bn_train_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
     return SG_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  BnStatsOp op;
-  op.x = (const float*)x; op.C = C; op.rows = rows;
-  op.moving_mean = (float*)moving_mean; op.moving_var = (float*)moving_var;
-  op.save_mean = (float*)save_mean; op.save_invstd = (float*)save_invstd;
-  op.momentum = momentum; op.eps = eps; op.unbiased = unbiased_update;
-  int rc = seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_stats");
-  if (rc) return rc;
-  const int V = vec ? 4 : 1;
-  const unsigned blocks = ew_blocks(rows * (C / V));
-  if (vec)
-    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)save_mean,
-                       (const float*)save_invstd, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, eps, 0, make_fastdiv((uint32_t)(C / V)));
-  else
-    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)save_mean,
-                       (const float*)save_invstd, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, eps, 0, make_fastdiv((uint32_t)(C / V)));
-  SG_LAUNCH_CHECK("bn_apply_kernel");
+  SG_DTYPE_SWITCH(dtype, "sg_bn_train_fwd", {
+    BnStatsOp<T> op;
+    op.x = (const T*)x; op.C = C; op.rows = rows;
+    op.moving_mean = (float*)moving_mean; op.moving_var = (float*)moving_var;
+    op.save_mean = (float*)save_mean; op.save_invstd = (float*)save_invstd;
+    op.momentum = momentum; op.eps = eps; op.unbiased = unbiased_update;
+    int rc = seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_stats");
+    if (rc) return rc;
+    return launch_bn_apply<T>(st, vec, (const T*)x, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
+                              (const float*)beta, (T*)y, rows, C, relu, eps, 0);
+  });
   return 0;
 }
 
 int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* y,
                     const void* dy, const void* gamma, const void* beta, const void* save_mean, const void* save_invstd,
                     void* dx, void* dgamma, void* dbeta, int relu, void* ws, size_t ws_bytes) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_train_bwd: bad ctx/dtype");
+  SG_CHECK_ARG(ctx && (dtype == SG_F32 || dtype == SG_BF16), "sg_bn_train_bwd: bad ctx/dtype");
   SG_CHECK_ARG(rows > 0 && C > 0 && x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta,
                "sg_bn_train_bwd: bad argument");
   SG_CHECK_ARG(!relu || y || beta, "sg_bn_train_bwd: relu set but neither y nor beta given");
@@ -231,66 +243,52 @@ int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
     return SG_EWORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  BnBwdOp op;
-  op.x = (const float*)x; op.y = (const float*)y; op.dy = (const float*)dy;
-  op.mean = (const float*)save_mean; op.invstd = (const float*)save_invstd;
-  op.gamma = (const float*)gamma; op.beta = (const float*)beta;
-  op.dgamma = (float*)dgamma; op.dbeta = (float*)dbeta; op.C = C; op.relu = relu;
-  int rc = seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_bwd_reduce");
-  if (rc) return rc;
-  const int V = vec ? 4 : 1;
-  const unsigned blocks = ew_blocks(rows * (C / V));
-  if (vec)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)y,
-                       (const float*)dy, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
-                       (const float*)beta, (const float*)dgamma, (const float*)dbeta, (float*)dx, rows, C, relu,
-                       make_fastdiv((uint32_t)(C / V)));
-  else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)y,
-                       (const float*)dy, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
-                       (const float*)beta, (const float*)dgamma, (const float*)dbeta, (float*)dx, rows, C, relu,
-                       make_fastdiv((uint32_t)(C / V)));
-  SG_LAUNCH_CHECK("bn_bwd_apply_kernel");
+  SG_DTYPE_SWITCH(dtype, "sg_bn_train_bwd", {
+    BnBwdOp<T> op;
+    op.x = (const T*)x; op.y = (const T*)y; op.dy = (const T*)dy;
+    op.mean = (const float*)save_mean; op.invstd = (const float*)save_invstd;
+    op.gamma = (const float*)gamma; op.beta = (const float*)beta;
+    op.dgamma = (float*)dgamma; op.dbeta = (float*)dbeta; op.C = C; op.relu = relu;
+    int rc = seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_bwd_reduce");
+    if (rc) return rc;
+    const int V = vec ? 4 : 1;
+    const unsigned blocks = ew_blocks(rows * (C / V));
+    if (vec)
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<4, T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
+                         (const float*)save_mean, (const float*)save_invstd, (const float*)gamma, (const float*)beta,
+                         (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));
+    else
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<1, T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
+                         (const float*)save_mean, (const float*)save_invstd, (const float*)gamma, (const float*)beta,
+                         (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));
+    SG_LAUNCH_CHECK("bn_bwd_apply_kernel");
+  });
   return 0;
 }
 
 int sg_bn_apply(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* gamma,
                 const void* beta, const void* mean, const void* invstd, void* y, int relu) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_apply: bad ctx/dtype");
+  SG_CHECK_ARG(ctx && (dtype == SG_F32 || dtype == SG_BF16), "sg_bn_apply: bad ctx/dtype");
   SG_CHECK_ARG(rows > 0 && C > 0 && x && gamma && beta && mean && invstd && y, "sg_bn_apply: bad argument");
   SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_apply: tensor exceeds 2^31 elements");
   const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
-  const int V = vec ? 4 : 1;
-  const unsigned blocks = ew_blocks(rows * (C / V));
-  hipStream_t st = (hipStream_t)stream;
-  if (vec)
-    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)mean,
-                       (const float*)invstd, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, 0.f, 0,
-                       make_fastdiv((uint32_t)(C / V)));
-  else
-    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)mean,
-                       (const float*)invstd, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, 0.f, 0,
-                       make_fastdiv((uint32_t)(C / V)));
-  SG_LAUNCH_CHECK("bn_apply_kernel");
+  SG_DTYPE_SWITCH(dtype, "sg_bn_apply", {
+    return launch_bn_apply<T>((hipStream_t)stream, vec, (const T*)x, (const float*)mean, (const float*)invstd, (const float*)gamma,
+                              (const float*)beta, (T*)y, rows, C, relu, 0.f, 0);
+  });
   return 0;
 }
 
 int sg_bn_infer(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* gamma,
                 const void* beta, const void* moving_mean, const void* moving_var, void* y, float eps, int relu) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_infer: bad ctx/dtype");
+  SG_CHECK_ARG(ctx && (dtype == SG_F32 || dtype == SG_BF16), "sg_bn_infer: bad ctx/dtype");
   SG_CHECK_ARG(rows > 0 && C > 0 && x && gamma && beta && moving_mean && moving_var && y, "sg_bn_infer: bad argument");
   SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_infer: tensor exceeds 2^31 elements");
   const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
-  const int V = vec ? 4 : 1;
-  const unsigned blocks = ew_blocks(rows * (C / V));
-  hipStream_t st = (hipStream_t)stream;
-  if (vec)
-    hipLaunchKernelGGL((bn_apply_kernel<4>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)moving_mean,
-                       (const float*)moving_var, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, eps, 1, make_fastdiv((uint32_t)(C / V)));
-  else
-    hipLaunchKernelGGL((bn_apply_kernel<1>), dim3(blocks), dim3(256), 0, st, (const float*)x, (const float*)moving_mean,
-                       (const float*)moving_var, (const float*)gamma, (const float*)beta, (float*)y, rows, C, relu, eps, 1, make_fastdiv((uint32_t)(C / V)));
-  SG_LAUNCH_CHECK("bn_apply_kernel(infer)");
+  SG_DTYPE_SWITCH(dtype, "sg_bn_infer", {
+    return launch_bn_apply<T>((hipStream_t)stream, vec, (const T*)x, (const float*)moving_mean, (const float*)moving_var,
+                              (const float*)gamma, (const float*)beta, (T*)y, rows, C, relu, eps, 1);
+  });
   return 0;
 }
 

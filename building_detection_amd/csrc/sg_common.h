@@ -70,3 +70,85 @@ __device__ __forceinline__ uint32_t xcd_remap(uint32_t bid, uint32_t nwg) {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---- storage element types: fp32, or bf16 storage with fp32 arithmetic (SG_BF16) ---------------------------------
+// Every kernel computes in fp32 registers; T only says how an activation element lies in HBM.  A "chunk" is the
+// 16-byte access unit: 4 floats or 8 bf16.
+typedef __bf16 bf16_t;
+typedef unsigned int u32x2_c __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4_c __attribute__((ext_vector_type(4)));
+
+template <typename T>
+struct EL;
+template <>
+struct EL<float> {
+  static constexpr int BYTES = 4, CH = 4, DT = SG_F32;
+};
+template <>
+struct EL<bf16_t> {
+  static constexpr int BYTES = 2, CH = 8, DT = SG_BF16;
+};
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+// round-to-nearest-even through the hardware conversion (v_cvt_pk_bf16_f32 keeps NaN a NaN)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  return __builtin_bit_cast(unsigned short, (bf16_t)f);
+}
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+  typedef float f32x2_c __attribute__((ext_vector_type(2)));
+  typedef bf16_t bf16x2_c __attribute__((ext_vector_type(2)));
+  const f32x2_c v = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_c));
+}
+
+template <typename T>
+__device__ __forceinline__ float ld1(const T* __restrict__ p) {
+  if constexpr (sizeof(T) == 4) return *p;
+  else return bf16_bits_to_f32(*reinterpret_cast<const unsigned short*>(p));
+}
+template <typename T>
+__device__ __forceinline__ void st1(T* __restrict__ p, float v) {
+  if constexpr (sizeof(T) == 4) *p = v;
+  else *reinterpret_cast<unsigned short*>(p) = f32_to_bf16_bits(v);
+}
+// four consecutive elements (16-byte or 8-byte aligned access)
+template <typename T>
+__device__ __forceinline__ f32x4 ld4(const T* __restrict__ p) {
+  if constexpr (sizeof(T) == 4) {
+    return *reinterpret_cast<const f32x4*>(p);
+  } else {
+    const u32x2_c r = *reinterpret_cast<const u32x2_c*>(p);
+    f32x4 o = {__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+               __uint_as_float(r[1] & 0xffff0000u)};
+    return o;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void st4(T* __restrict__ p, const f32x4 v) {
+  if constexpr (sizeof(T) == 4) {
+    *reinterpret_cast<f32x4*>(p) = v;
+  } else {
+    const u32x2_c r = {pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3])};
+    *reinterpret_cast<u32x2_c*>(p) = r;
+  }
+}
+// eight consecutive elements of a bf16 tensor (one 16-byte access) <-> two f32x4
+__device__ __forceinline__ void ld8_bf16(const bf16_t* __restrict__ p, f32x4& a, f32x4& b) {
+  const u32x4_c r = *reinterpret_cast<const u32x4_c*>(p);
+  a = (f32x4){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+              __uint_as_float(r[1] & 0xffff0000u)};
+  b = (f32x4){__uint_as_float(r[2] << 16), __uint_as_float(r[2] & 0xffff0000u), __uint_as_float(r[3] << 16),
+              __uint_as_float(r[3] & 0xffff0000u)};
+}
+__device__ __forceinline__ void st8_bf16(bf16_t* __restrict__ p, const f32x4 a, const f32x4 b) {
+  const u32x4_c r = {pack2_bf16(a[0], a[1]), pack2_bf16(a[2], a[3]), pack2_bf16(b[0], b[1]), pack2_bf16(b[2], b[3])};
+  *reinterpret_cast<u32x4_c*>(p) = r;
+}
+
+// host-side dispatch on the ABI's dtype argument: CALL is a generic lambda taking a null pointer of the element type
+#define SG_DTYPE_SWITCH(dtype, who, ...)                                          \
+  do {                                                                            \
+    if ((dtype) == SG_F32) { typedef float T; __VA_ARGS__; }                      \
+    else if ((dtype) == SG_BF16) { typedef bf16_t T; __VA_ARGS__; }               \
+    else { sg_set_error("%s: dtype %d", who, (int)(dtype)); return SG_EINVAL; }   \
+  } while (0)

@@ -157,4 +157,24 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const float (&o)[V]) 
   }
 }
 
+// bf16 storage: V = 4 is one 8-byte access, V = 1 a 2-byte one; values widen to fp32 in registers
+template <int V>
+__device__ __forceinline__ void ldv(const bf16_t* __restrict__ p, float (&o)[V]) {
+  if constexpr (V == 4) {
+    const f32x4 t = ld4<bf16_t>(p);
+    o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
+  } else {
+    o[0] = ld1<bf16_t>(p);
+  }
+}
+template <int V>
+__device__ __forceinline__ void stv(bf16_t* __restrict__ p, const float (&o)[V]) {
+  if constexpr (V == 4) {
+    const f32x4 t = {o[0], o[1], o[2], o[3]};
+    st4<bf16_t>(p, t);
+  } else {
+    st1<bf16_t>(p, o[0]);
+  }
+}
+
 static inline bool sg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -12,18 +12,19 @@ inline unsigned ew_blocks(int64_t total) {
   return (unsigned)b;
 }
 
+template <typename T>
 struct DwParams {
-  const float* __restrict__ x;   // forward input (or mask source for dgrad)
-  const float* __restrict__ w;   // [KH][KW][C]
-  const float* __restrict__ dy;
-  float* __restrict__ out;
+  const T* __restrict__ x;       // forward input (or mask source for dgrad)
+  const float* __restrict__ w;   // [KH][KW][C] (fp32 master weights whatever the activation storage)
+  const T* __restrict__ dy;
+  T* __restrict__ out;
   int N, H, W, C, Ho, Wo, KH, KW, stride, dil, pad_t, pad_l, x_ld, y_ld, pre_relu;
   FastDiv fd_cv, fd_w, fd_h;  // decomposition of the flat index: channel chunk, then width, then height
 };
 
 // y[n,oh,ow,c] = sum_taps relu?(x[n, oh*s - pt + kh*d, ow*s - pl + kw*d, c]) * w[kh,kw,c]
-template <int V>
-__global__ void dw_fwd_kernel(const DwParams p) {
+template <int V, typename T>
+__global__ void dw_fwd_kernel(const DwParams<T> p) {
   const uint32_t cv = p.C / V;
   const uint32_t total = (uint32_t)((int64_t)p.N * p.Ho * p.Wo * cv), stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -53,8 +54,8 @@ __global__ void dw_fwd_kernel(const DwParams p) {
 }
 
 // dx[n,ih,iw,c] = sum_taps dy[n,(ih+pt-kh*d)/s,(iw+pl-kw*d)/s,c] * w[kh,kw,c]   (* [x>0] if pre_relu)
-template <int V>
-__global__ void dw_dgrad_kernel(const DwParams p) {
+template <int V, typename T>
+__global__ void dw_dgrad_kernel(const DwParams<T> p) {
   const uint32_t cv = p.C / V;
   const uint32_t total = (uint32_t)((int64_t)p.N * p.H * p.W * cv), stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -94,10 +95,11 @@ __global__ void dw_dgrad_kernel(const DwParams p) {
 }
 
 // dw[kh,kw,c] = sum_{n,oh,ow} relu?(x[n,ih,iw,c]) * dy[n,oh,ow,c]  — 9 outputs per channel
+template <typename T>
 struct DwWgradOp {
   static constexpr int NOUT = 9;
-  const float* __restrict__ x;
-  const float* __restrict__ dy;
+  const T* __restrict__ x;
+  const T* __restrict__ dy;
   float* dw;
   int H, W, C, Ho, Wo, stride, dil, pad_t, pad_l, x_ld, y_ld, pre_relu;
   FastDiv fd_w, fd_h;
@@ -133,11 +135,12 @@ struct DwWgradOp {
 // ---- stride-1 3x3 'same' fast paths: each thread owns one 16-byte channel chunk and a run of 4 output columns,
 // so the 3 x 6 input window is loaded once (18 loads for 4 outputs instead of 36) and the 9 kernel taps live in
 // registers.  Forward and dgrad are the same stencil (dgrad: kernel flipped, dy as input, optional [x > 0] mask).
+template <typename T>
 struct DwRunParams {
-  const float* __restrict__ in;    // x (fwd) or dy (dgrad)
+  const T* __restrict__ in;        // x (fwd) or dy (dgrad)
   const float* __restrict__ w;     // [3][3][C]
-  const float* __restrict__ mask;  // dgrad with pre_relu: forward input, else null
-  float* __restrict__ out;
+  const T* __restrict__ mask;      // dgrad with pre_relu: forward input, else null
+  T* __restrict__ out;
   int N, H, W, C, in_ld, out_ld, mask_ld, relu_in, flip;
   int lc;                          // lanes per run along the channels (set by launch_dw_run)
   int runs_per_row;                // W / 4
@@ -147,8 +150,8 @@ struct DwRunParams {
 
 // RR output rows per run: the (RR + 2) x 6 input window is loaded once for RR x 4 outputs - 4.5 loads per output
 // at RR = 1, 2.25 at RR = 4 (fd_h divides by H / RR then)
-template <int RR>
-__global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams p) {
+template <int RR, typename T>
+__global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams<T> p) {
   // p.lc lanes (a power of two <= 64) cover the channel chunks of one run; with few channels (C = 64: 16 chunks)
   // a wave takes several runs instead of idling three quarters of its lanes
   const int lc = p.lc, rpb = 256 / lc;
@@ -172,13 +175,13 @@ __global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams p) {
     for (int a = 0; a < RR + 2; ++a) {
       const int ih = oh0 - 1 + a;
       if ((unsigned)ih >= (unsigned)p.H) continue;
-      const float* rowp = p.in + ((int64_t)(n * p.H + ih) * p.W) * p.in_ld + c;
+      const T* rowp = p.in + ((int64_t)(n * p.H + ih) * p.W) * p.in_ld + c;
       f32x4 v[6];
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
         const int iw = ow0 - 1 + b;
         const bool ok = (unsigned)iw < (unsigned)p.W;
-        const f32x4 t = *reinterpret_cast<const f32x4*>(rowp + (int64_t)(ok ? iw : 0) * p.in_ld);
+        const f32x4 t = ld4<T>(rowp + (int64_t)(ok ? iw : 0) * p.in_ld);
         v[b] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
         if (p.relu_in) {
 #pragma unroll
@@ -203,22 +206,22 @@ __global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams p) {
       for (int k = 0; k < 4; ++k) {
         f32x4 o = acc[rr][k];
         if (p.mask) {
-          const f32x4 m = *reinterpret_cast<const f32x4*>(p.mask + (opix + k) * p.mask_ld + c);
+          const f32x4 m = ld4<T>(p.mask + (opix + k) * p.mask_ld + c);
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = m[e] > 0.f ? o[e] : 0.f;
         }
-        *reinterpret_cast<f32x4*>(p.out + (opix + k) * p.out_ld + c) = o;
+        st4<T>(p.out + (opix + k) * p.out_ld + c, o);
       }
     }
   }
 }
 
 // wgrad, same window: a "row" of the segmented reducer is a run of RR rows x 4 output pixels
-template <int RR>
+template <int RR, typename T>
 struct DwWgradRunOp {
   static constexpr int NOUT = 9;
-  const float* __restrict__ x;
-  const float* __restrict__ dy;
+  const T* __restrict__ x;
+  const T* __restrict__ dy;
   float* dw;
   int H, W, C, x_ld, y_ld, pre_relu;
   FastDiv fd_rpr, fd_h;
@@ -234,21 +237,21 @@ struct DwWgradRunOp {
     f32x4 g[RR][4];
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
-      const float* gp = dy + ((int64_t)(n * H + oh0 + rr) * W + ow0) * y_ld + c;
+      const T* gp = dy + ((int64_t)(n * H + oh0 + rr) * W + ow0) * y_ld + c;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) g[rr][k] = *reinterpret_cast<const f32x4*>(gp + (int64_t)k * y_ld);
+      for (int k = 0; k < 4; ++k) g[rr][k] = ld4<T>(gp + (int64_t)k * y_ld);
     }
 #pragma unroll
     for (int a = 0; a < RR + 2; ++a) {
       const int ih = oh0 - 1 + a;
       if ((unsigned)ih >= (unsigned)H) continue;
-      const float* rowp = x + ((int64_t)(n * H + ih) * W) * x_ld + c;
+      const T* rowp = x + ((int64_t)(n * H + ih) * W) * x_ld + c;
       f32x4 v[6];
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
         const int iw = ow0 - 1 + b;
         const bool ok = (unsigned)iw < (unsigned)W;
-        const f32x4 t = *reinterpret_cast<const f32x4*>(rowp + (int64_t)(ok ? iw : 0) * x_ld);
+        const f32x4 t = ld4<T>(rowp + (int64_t)(ok ? iw : 0) * x_ld);
         v[b] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
         if (pre_relu) {
 #pragma unroll
@@ -291,8 +294,9 @@ inline int dw_rows_per_run(int H, int64_t pixels, bool wgrad) {
   return (want >= 4 && H % 4 == 0) ? 4 : ((want >= 2 && H % 2 == 0) ? 2 : 1);
 }
 
-int launch_dw_run(const DwRunParams& p_in, hipStream_t st) {
-  DwRunParams p = p_in;
+template <typename T>
+int launch_dw_run(const DwRunParams<T>& p_in, hipStream_t st) {
+  DwRunParams<T> p = p_in;
   const int rr = dw_rows_per_run(p.H, (int64_t)p.N * p.H * p.W, false);
   p.nruns = (int64_t)p.N * (p.H / rr) * p.runs_per_row;
   p.fd_h = make_fastdiv((uint32_t)(p.H / rr));
@@ -304,25 +308,26 @@ int launch_dw_run(const DwRunParams& p_in, hipStream_t st) {
   const int64_t cap = sg_cdiv(16384, gx);
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
-  if (rr == 4) hipLaunchKernelGGL(dw_s1_run_kernel<4>, dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
-  else if (rr == 2) hipLaunchKernelGGL(dw_s1_run_kernel<2>, dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(dw_s1_run_kernel<1>, dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
+  if (rr == 4) hipLaunchKernelGGL((dw_s1_run_kernel<4, T>), dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
+  else if (rr == 2) hipLaunchKernelGGL((dw_s1_run_kernel<2, T>), dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((dw_s1_run_kernel<1, T>), dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
   SG_LAUNCH_CHECK("dw_s1_run_kernel");
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------- pooling
+template <typename T>
 struct PoolParams {
-  const float* __restrict__ x;
-  const float* __restrict__ y;
-  const float* __restrict__ dy;
-  float* __restrict__ out;
+  const T* __restrict__ x;
+  const T* __restrict__ y;
+  const T* __restrict__ dy;
+  T* __restrict__ out;
   int N, H, W, C, Ho, Wo, k, stride, pad_t, pad_l;
   FastDiv fd_cv, fd_w, fd_h;
 };
 
-template <int V>
-__global__ void maxpool_fwd_kernel(const PoolParams p) {
+template <int V, typename T>
+__global__ void maxpool_fwd_kernel(const PoolParams<T> p) {
   const uint32_t cv = p.C / V;
   const uint32_t total = (uint32_t)((int64_t)p.N * p.Ho * p.Wo * cv), stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -352,8 +357,8 @@ __global__ void maxpool_fwd_kernel(const PoolParams p) {
 
 // Gather form (deterministic, no atomics): input element (ih,iw) receives dy of every window in which it is the
 // FIRST maximum in window scan order (row-major), which is where TF / Eigen route the gradient.
-template <int V>
-__global__ void maxpool_bwd_kernel(const PoolParams p) {
+template <int V, typename T>
+__global__ void maxpool_bwd_kernel(const PoolParams<T> p) {
   const uint32_t cv = p.C / V;
   const uint32_t total = (uint32_t)((int64_t)p.N * p.H * p.W * cv), stride = gridDim.x * blockDim.x;
   for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
@@ -408,10 +413,11 @@ __global__ void maxpool_bwd_kernel(const PoolParams p) {
 
 // AveragePooling2D(k) / GlobalAveragePooling2D as a segmented reduction: segment = output pixel (n,oh,ow),
 // rows = kh*kw window cells.
+template <typename T>
 struct AvgPoolOp {
   static constexpr int NOUT = 1;
-  const float* __restrict__ x;
-  float* y;
+  const T* __restrict__ x;
+  T* y;
   int H, W, C, Ho, Wo, kh, kw;
   FastDiv fd_howo, fd_wo, fd_kw;
   template <int V>
@@ -426,12 +432,12 @@ struct AvgPoolOp {
     for (int k = 0; k < V; ++k) acc[0][k] += xv[k];
   }
   __device__ __forceinline__ void finalize(int seg, int c, const double (&s)[1]) const {
-    y[(int64_t)seg * C + c] = (float)(s[0] / (double)(kh * kw));
+    st1<T>(y + (int64_t)seg * C + c, (float)(s[0] / (double)(kh * kw)));
   }
 };
 
-template <int V>
-__global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int N, int H, int W, int C,
+template <int V, typename T>
+__global__ void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C,
                                    int kh, int kw, int accumulate, FastDiv fd_cv, FastDiv fd_w, FastDiv fd_h) {
   const uint32_t cv = C / V;
   const uint32_t total = (uint32_t)((int64_t)N * H * W * cv), stride = gridDim.x * blockDim.x;
@@ -463,8 +469,8 @@ __global__ void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restri
   }
 }
 
-template <int V>
-__global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int C,
+template <int V, typename T>
+__global__ void upsample_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C,
                                     int sh, int sw, int y_ld, FastDiv fd_cv, FastDiv fd_w, FastDiv fd_h) {
   const uint32_t cv = C / V;
   const int OH = H * sh, OW = W * sw;
@@ -481,8 +487,8 @@ __global__ void upsample_fwd_kernel(const float* __restrict__ x, float* __restri
   }
 }
 
-template <int V>
-__global__ void upsample_bwd_kernel(const float* __restrict__ dy, int dy_ld, float* __restrict__ dx, int N, int H,
+template <int V, typename T>
+__global__ void upsample_bwd_kernel(const T* __restrict__ dy, int dy_ld, T* __restrict__ dx, int N, int H,
                                     int W, int C, int sh, int sw, int accumulate, FastDiv fd_cv, FastDiv fd_w,
                                     FastDiv fd_h) {
   const uint32_t cv = C / V;
@@ -515,7 +521,7 @@ __global__ void upsample_bwd_kernel(const float* __restrict__ dy, int dy_ld, flo
 }
 
 int dw_check(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, const char* who) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32 && d, "%s: bad ctx/dtype/desc", who);
+  SG_CHECK_ARG(ctx && (dtype == SG_F32 || dtype == SG_BF16) && d, "%s: bad ctx/dtype/desc", who);
   SG_CHECK_ARG(d->Cin == d->Cout, "%s: depthwise needs Cin == Cout (depth_multiplier 1)", who);
   SG_CHECK_ARG(d->N > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Ho > 0 && d->Wo > 0 && d->KH > 0 && d->KW > 0 &&
                    d->stride > 0 && d->dilation > 0,
@@ -526,7 +532,8 @@ int dw_check(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, const char* wh
   return 0;
 }
 
-void dw_fill(DwParams& p, const sg_conv_desc* d) {
+template <typename T>
+void dw_fill(DwParams<T>& p, const sg_conv_desc* d) {
   p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.KH = d->KH; p.KW = d->KW;
   p.stride = d->stride; p.dil = d->dilation; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
   p.x_ld = d->x_ld ? d->x_ld : d->Cin;
@@ -542,23 +549,25 @@ int sg_dwconv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   int rc = dw_check(ctx, dtype, d, "sg_dwconv2d_fwd");
   if (rc) return rc;
   SG_CHECK_ARG(x && w && y, "sg_dwconv2d_fwd: null tensor");
-  DwParams p;
-  dw_fill(p, d);
-  p.x = (const float*)x; p.w = (const float*)w; p.dy = nullptr; p.out = (float*)y; p.pre_relu = pre_relu;
-  const bool vec = (p.C % 4 == 0) && (p.x_ld % 4 == 0) && (p.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(w) && sg_aligned16(y);
-  if (vec && dw_run_ok(d)) {
-    DwRunParams r;
-    r.in = (const float*)x; r.w = (const float*)w; r.mask = nullptr; r.out = (float*)y;
-    r.N = d->N; r.H = d->H; r.W = d->W; r.C = p.C; r.in_ld = p.x_ld; r.out_ld = p.y_ld; r.mask_ld = 0;
-    r.relu_in = pre_relu; r.flip = 0; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
-    r.fd_rpr = make_fastdiv((uint32_t)r.runs_per_row); r.fd_h = make_fastdiv((uint32_t)d->H);
-    return launch_dw_run(r, (hipStream_t)stream);
-  }
-  const int V = vec ? 4 : 1;
-  p.fd_cv = make_fastdiv((uint32_t)(p.C / V)); p.fd_w = make_fastdiv((uint32_t)p.Wo); p.fd_h = make_fastdiv((uint32_t)p.Ho);
-  const unsigned blocks = ew_blocks((int64_t)p.N * p.Ho * p.Wo * (p.C / V));
-  if (vec) hipLaunchKernelGGL((dw_fwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((dw_fwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  SG_DTYPE_SWITCH(dtype, "sg_dwconv2d_fwd", {
+    DwParams<T> p;
+    dw_fill(p, d);
+    p.x = (const T*)x; p.w = (const float*)w; p.dy = nullptr; p.out = (T*)y; p.pre_relu = pre_relu;
+    const bool vec = (p.C % 4 == 0) && (p.x_ld % 4 == 0) && (p.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(w) && sg_aligned16(y);
+    if (vec && dw_run_ok(d)) {
+      DwRunParams<T> r;
+      r.in = (const T*)x; r.w = (const float*)w; r.mask = nullptr; r.out = (T*)y;
+      r.N = d->N; r.H = d->H; r.W = d->W; r.C = p.C; r.in_ld = p.x_ld; r.out_ld = p.y_ld; r.mask_ld = 0;
+      r.relu_in = pre_relu; r.flip = 0; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
+      r.fd_rpr = make_fastdiv((uint32_t)r.runs_per_row); r.fd_h = make_fastdiv((uint32_t)d->H);
+      return launch_dw_run(r, (hipStream_t)stream);
+    }
+    const int V = vec ? 4 : 1;
+    p.fd_cv = make_fastdiv((uint32_t)(p.C / V)); p.fd_w = make_fastdiv((uint32_t)p.Wo); p.fd_h = make_fastdiv((uint32_t)p.Ho);
+    const unsigned blocks = ew_blocks((int64_t)p.N * p.Ho * p.Wo * (p.C / V));
+    if (vec) hipLaunchKernelGGL((dw_fwd_kernel<4, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((dw_fwd_kernel<1, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  });
   SG_LAUNCH_CHECK("dw_fwd_kernel");
   return 0;
 }
@@ -569,24 +578,26 @@ int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
   if (rc) return rc;
   SG_CHECK_ARG(dy && w && dx, "sg_dwconv2d_dgrad: null tensor");
   SG_CHECK_ARG(!pre_relu || x_for_mask, "sg_dwconv2d_dgrad: pre_relu needs the forward input");
-  DwParams p;
-  dw_fill(p, d);
-  p.x = (const float*)x_for_mask; p.w = (const float*)w; p.dy = (const float*)dy; p.out = (float*)dx; p.pre_relu = pre_relu;
-  const bool vec = (p.C % 4 == 0) && (p.x_ld % 4 == 0) && (p.y_ld % 4 == 0) && sg_aligned16(dy) && sg_aligned16(w) &&
-                   sg_aligned16(dx) && (!pre_relu || sg_aligned16(x_for_mask));
-  if (vec && dw_run_ok(d)) {  // stride-1 dgrad = the same stencil with the kernel flipped
-    DwRunParams r;
-    r.in = (const float*)dy; r.w = (const float*)w; r.mask = pre_relu ? (const float*)x_for_mask : nullptr; r.out = (float*)dx;
-    r.N = d->N; r.H = d->H; r.W = d->W; r.C = p.C; r.in_ld = p.y_ld; r.out_ld = p.x_ld; r.mask_ld = p.x_ld;
-    r.relu_in = 0; r.flip = 1; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
-    r.fd_rpr = make_fastdiv((uint32_t)r.runs_per_row); r.fd_h = make_fastdiv((uint32_t)d->H);
-    return launch_dw_run(r, (hipStream_t)stream);
-  }
-  const int V = vec ? 4 : 1;
-  p.fd_cv = make_fastdiv((uint32_t)(p.C / V)); p.fd_w = make_fastdiv((uint32_t)p.W); p.fd_h = make_fastdiv((uint32_t)p.H);
-  const unsigned blocks = ew_blocks((int64_t)p.N * p.H * p.W * (p.C / V));
-  if (vec) hipLaunchKernelGGL((dw_dgrad_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((dw_dgrad_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  SG_DTYPE_SWITCH(dtype, "sg_dwconv2d_dgrad", {
+    DwParams<T> p;
+    dw_fill(p, d);
+    p.x = (const T*)x_for_mask; p.w = (const float*)w; p.dy = (const T*)dy; p.out = (T*)dx; p.pre_relu = pre_relu;
+    const bool vec = (p.C % 4 == 0) && (p.x_ld % 4 == 0) && (p.y_ld % 4 == 0) && sg_aligned16(dy) && sg_aligned16(w) &&
+                     sg_aligned16(dx) && (!pre_relu || sg_aligned16(x_for_mask));
+    if (vec && dw_run_ok(d)) {  // stride-1 dgrad = the same stencil with the kernel flipped
+      DwRunParams<T> r;
+      r.in = (const T*)dy; r.w = (const float*)w; r.mask = pre_relu ? (const T*)x_for_mask : nullptr; r.out = (T*)dx;
+      r.N = d->N; r.H = d->H; r.W = d->W; r.C = p.C; r.in_ld = p.y_ld; r.out_ld = p.x_ld; r.mask_ld = p.x_ld;
+      r.relu_in = 0; r.flip = 1; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
+      r.fd_rpr = make_fastdiv((uint32_t)r.runs_per_row); r.fd_h = make_fastdiv((uint32_t)d->H);
+      return launch_dw_run(r, (hipStream_t)stream);
+    }
+    const int V = vec ? 4 : 1;
+    p.fd_cv = make_fastdiv((uint32_t)(p.C / V)); p.fd_w = make_fastdiv((uint32_t)p.W); p.fd_h = make_fastdiv((uint32_t)p.H);
+    const unsigned blocks = ew_blocks((int64_t)p.N * p.H * p.W * (p.C / V));
+    if (vec) hipLaunchKernelGGL((dw_dgrad_kernel<4, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((dw_dgrad_kernel<1, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  });
   SG_LAUNCH_CHECK("dw_dgrad_kernel");
   return 0;
 }
@@ -607,74 +618,81 @@ int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
   if (rc) return rc;
   SG_CHECK_ARG(x && dy && dw, "sg_dwconv2d_wgrad: null tensor");
   SG_CHECK_ARG(d->KH == 3 && d->KW == 3, "sg_dwconv2d_wgrad: only 3x3 depthwise kernels occur on this path");
-  DwWgradOp op;
-  op.x = (const float*)x; op.dy = (const float*)dy; op.dw = (float*)dw;
-  op.H = d->H; op.W = d->W; op.C = d->Cin; op.Ho = d->Ho; op.Wo = d->Wo; op.stride = d->stride; op.dil = d->dilation;
-  op.pad_t = d->pad_t; op.pad_l = d->pad_l; op.x_ld = d->x_ld ? d->x_ld : d->Cin; op.y_ld = d->y_ld ? d->y_ld : d->Cout;
-  op.pre_relu = pre_relu;
-  op.fd_w = make_fastdiv((uint32_t)d->Wo); op.fd_h = make_fastdiv((uint32_t)d->Ho);
-  const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
-  const bool vec = (op.C % 4 == 0) && (op.x_ld % 4 == 0) && (op.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy);
-  if (vec && dw_run_ok(d)) {
-    const int rr = dw_rows_per_run(d->H, rows, true);
-    const int64_t nruns = rows / (4 * rr);
-    const SegPlan rp = seg_plan<9>(ctx->num_cus, 1, nruns, op.C, true);
-    if (!ws || ws_bytes < rp.part_bytes) {
-      sg_set_error("sg_dwconv2d_wgrad: workspace %zu < %zu", ws_bytes, rp.part_bytes);
+  SG_DTYPE_SWITCH(dtype, "sg_dwconv2d_wgrad", {
+    DwWgradOp<T> op;
+    op.x = (const T*)x; op.dy = (const T*)dy; op.dw = (float*)dw;
+    op.H = d->H; op.W = d->W; op.C = d->Cin; op.Ho = d->Ho; op.Wo = d->Wo; op.stride = d->stride; op.dil = d->dilation;
+    op.pad_t = d->pad_t; op.pad_l = d->pad_l; op.x_ld = d->x_ld ? d->x_ld : d->Cin; op.y_ld = d->y_ld ? d->y_ld : d->Cout;
+    op.pre_relu = pre_relu;
+    op.fd_w = make_fastdiv((uint32_t)d->Wo); op.fd_h = make_fastdiv((uint32_t)d->Ho);
+    const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
+    const bool vec = (op.C % 4 == 0) && (op.x_ld % 4 == 0) && (op.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy);
+    if (vec && dw_run_ok(d)) {
+      const int rr = dw_rows_per_run(d->H, rows, true);
+      const int64_t nruns = rows / (4 * rr);
+      const SegPlan rp = seg_plan<9>(ctx->num_cus, 1, nruns, op.C, true);
+      if (!ws || ws_bytes < rp.part_bytes) {
+        sg_set_error("sg_dwconv2d_wgrad: workspace %zu < %zu", ws_bytes, rp.part_bytes);
+        return SG_EWORKSPACE;
+      }
+      auto run = [&](auto ro) -> int {
+        ro.x = (const T*)x; ro.dy = (const T*)dy; ro.dw = (float*)dw; ro.H = d->H; ro.W = d->W; ro.C = op.C;
+        ro.x_ld = op.x_ld; ro.y_ld = op.y_ld; ro.pre_relu = pre_relu;
+        ro.fd_rpr = make_fastdiv((uint32_t)(d->W / 4)); ro.fd_h = make_fastdiv((uint32_t)(d->H / rr));
+        return seg_reduce_launch(ro, rp, 1, nruns, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad_run");
+      };
+      if (rr == 4) return run(DwWgradRunOp<4, T>{});
+      if (rr == 2) return run(DwWgradRunOp<2, T>{});
+      return run(DwWgradRunOp<1, T>{});
+    }
+    const SegPlan pl = seg_plan<9>(ctx->num_cus, 1, rows, op.C, vec);
+    if (!ws || ws_bytes < pl.part_bytes) {
+      sg_set_error("sg_dwconv2d_wgrad: workspace %zu < %zu", ws_bytes, pl.part_bytes);
       return SG_EWORKSPACE;
     }
-    auto run = [&](auto ro) -> int {
-      ro.x = (const float*)x; ro.dy = (const float*)dy; ro.dw = (float*)dw; ro.H = d->H; ro.W = d->W; ro.C = op.C;
-      ro.x_ld = op.x_ld; ro.y_ld = op.y_ld; ro.pre_relu = pre_relu;
-      ro.fd_rpr = make_fastdiv((uint32_t)(d->W / 4)); ro.fd_h = make_fastdiv((uint32_t)(d->H / rr));
-      return seg_reduce_launch(ro, rp, 1, nruns, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad_run");
-    };
-    if (rr == 4) return run(DwWgradRunOp<4>{});
-    if (rr == 2) return run(DwWgradRunOp<2>{});
-    return run(DwWgradRunOp<1>{});
-  }
-  const SegPlan pl = seg_plan<9>(ctx->num_cus, 1, rows, op.C, vec);
-  if (!ws || ws_bytes < pl.part_bytes) {
-    sg_set_error("sg_dwconv2d_wgrad: workspace %zu < %zu", ws_bytes, pl.part_bytes);
-    return SG_EWORKSPACE;
-  }
-  return seg_reduce_launch(op, pl, 1, rows, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad");
+    return seg_reduce_launch(op, pl, 1, rows, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad");
+  });
+  return 0;
 }
 
 int sg_maxpool_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride, int pad_t,
                    int pad_l, int Ho, int Wo, const void* x, void* y) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32 && x && y, "sg_maxpool_fwd: bad argument");
+  SG_CHECK_ARG(ctx && x && y, "sg_maxpool_fwd: bad argument");
   SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && Ho > 0 && Wo > 0 && pad_t >= 0 && pad_l >= 0,
                "sg_maxpool_fwd: bad geometry");
   SG_CHECK_ARG((int64_t)N * H * W * C < (1ll << 31), "sg_maxpool_fwd: tensor exceeds 2^31 elements");
-  PoolParams p;
-  p.x = (const float*)x; p.y = nullptr; p.dy = nullptr; p.out = (float*)y;
-  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
-  const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
-  const int V = vec ? 4 : 1;
-  p.fd_cv = make_fastdiv((uint32_t)(C / V)); p.fd_w = make_fastdiv((uint32_t)Wo); p.fd_h = make_fastdiv((uint32_t)Ho);
-  const unsigned blocks = ew_blocks((int64_t)N * Ho * Wo * (C / V));
-  if (vec) hipLaunchKernelGGL((maxpool_fwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((maxpool_fwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  SG_DTYPE_SWITCH(dtype, "sg_maxpool_fwd", {
+    PoolParams<T> p;
+    p.x = (const T*)x; p.y = nullptr; p.dy = nullptr; p.out = (T*)y;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+    const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
+    const int V = vec ? 4 : 1;
+    p.fd_cv = make_fastdiv((uint32_t)(C / V)); p.fd_w = make_fastdiv((uint32_t)Wo); p.fd_h = make_fastdiv((uint32_t)Ho);
+    const unsigned blocks = ew_blocks((int64_t)N * Ho * Wo * (C / V));
+    if (vec) hipLaunchKernelGGL((maxpool_fwd_kernel<4, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((maxpool_fwd_kernel<1, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  });
   SG_LAUNCH_CHECK("maxpool_fwd_kernel");
   return 0;
 }
 
 int sg_maxpool_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride, int pad_t,
                    int pad_l, int Ho, int Wo, const void* x, const void* y, const void* dy, void* dx) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32 && x && y && dy && dx, "sg_maxpool_bwd: bad argument");
+  SG_CHECK_ARG(ctx && x && y && dy && dx, "sg_maxpool_bwd: bad argument");
   SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && stride > 0 && Ho > 0 && Wo > 0 && pad_t >= 0 && pad_l >= 0,
                "sg_maxpool_bwd: bad geometry");
   SG_CHECK_ARG((int64_t)N * H * W * C < (1ll << 31), "sg_maxpool_bwd: tensor exceeds 2^31 elements");
-  PoolParams p;
-  p.x = (const float*)x; p.y = (const float*)y; p.dy = (const float*)dy; p.out = (float*)dx;
-  p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
-  const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y) && sg_aligned16(dy) && sg_aligned16(dx);
-  const int V = vec ? 4 : 1;
-  p.fd_cv = make_fastdiv((uint32_t)(C / V)); p.fd_w = make_fastdiv((uint32_t)W); p.fd_h = make_fastdiv((uint32_t)H);
-  const unsigned blocks = ew_blocks((int64_t)N * H * W * (C / V));
-  if (vec) hipLaunchKernelGGL((maxpool_bwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((maxpool_bwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  SG_DTYPE_SWITCH(dtype, "sg_maxpool_bwd", {
+    PoolParams<T> p;
+    p.x = (const T*)x; p.y = (const T*)y; p.dy = (const T*)dy; p.out = (T*)dx;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+    const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y) && sg_aligned16(dy) && sg_aligned16(dx);
+    const int V = vec ? 4 : 1;
+    p.fd_cv = make_fastdiv((uint32_t)(C / V)); p.fd_w = make_fastdiv((uint32_t)W); p.fd_h = make_fastdiv((uint32_t)H);
+    const unsigned blocks = ew_blocks((int64_t)N * H * W * (C / V));
+    if (vec) hipLaunchKernelGGL((maxpool_bwd_kernel<4, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((maxpool_bwd_kernel<1, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  });
   SG_LAUNCH_CHECK("maxpool_bwd_kernel");
   return 0;
 }
@@ -689,11 +707,12 @@ size_t sg_avgpool_ws_bytes(const sg_ctx* ctx, int N, int H, int W, int C, int kh
 
 int sg_avgpool_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int kh, int kw, const void* x,
                    void* y, void* ws, size_t ws_bytes) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32 && x && y, "sg_avgpool_fwd: bad argument");
+  SG_CHECK_ARG(ctx && x && y, "sg_avgpool_fwd: bad argument");
   SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && H >= kh && W >= kw, "sg_avgpool_fwd: bad geometry");
   SG_CHECK_ARG((int64_t)N * H * W * C < (1ll << 31), "sg_avgpool_fwd: tensor exceeds 2^31 elements");
-  AvgPoolOp op;
-  op.x = (const float*)x; op.y = (float*)y; op.H = H; op.W = W; op.C = C; op.Ho = H / kh; op.Wo = W / kw; op.kh = kh; op.kw = kw;
+  SG_DTYPE_SWITCH(dtype, "sg_avgpool_fwd", {
+  AvgPoolOp<T> op;
+  op.x = (const T*)x; op.y = (T*)y; op.H = H; op.W = W; op.C = C; op.Ho = H / kh; op.Wo = W / kw; op.kh = kh; op.kw = kw;
   op.fd_howo = make_fastdiv((uint32_t)(op.Ho * op.Wo)); op.fd_wo = make_fastdiv((uint32_t)op.Wo); op.fd_kw = make_fastdiv((uint32_t)kw);
   const int nseg = N * op.Ho * op.Wo;
   const bool vec = (C % 4 == 0) && sg_aligned16(x);
@@ -703,30 +722,34 @@ int sg_avgpool_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, in
     return SG_EWORKSPACE;
   }
   return seg_reduce_launch(op, pl, nseg, (int64_t)kh * kw, C, (float*)ws, (hipStream_t)stream, "avgpool_fwd");
+  });
+  return 0;
 }
 
 int sg_avgpool_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int kh, int kw, const void* dy,
                    void* dx, int accumulate) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32 && dy && dx, "sg_avgpool_bwd: bad argument");
+  SG_CHECK_ARG(ctx && dy && dx, "sg_avgpool_bwd: bad argument");
   SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && kh > 0 && kw > 0 && H >= kh && W >= kw, "sg_avgpool_bwd: bad geometry");
   SG_CHECK_ARG((int64_t)N * H * W * C < (1ll << 31), "sg_avgpool_bwd: tensor exceeds 2^31 elements");
   const bool vec = (C % 4 == 0) && sg_aligned16(dy) && sg_aligned16(dx);
   const int V = vec ? 4 : 1;
   const unsigned blocks = ew_blocks((int64_t)N * H * W * (C / V));
   const FastDiv a = make_fastdiv((uint32_t)(C / V)), b = make_fastdiv((uint32_t)W), c = make_fastdiv((uint32_t)H);
-  if (vec)
-    hipLaunchKernelGGL((avgpool_bwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
-                       (float*)dx, N, H, W, C, kh, kw, accumulate, a, b, c);
-  else
-    hipLaunchKernelGGL((avgpool_bwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy,
-                       (float*)dx, N, H, W, C, kh, kw, accumulate, a, b, c);
+  SG_DTYPE_SWITCH(dtype, "sg_avgpool_bwd", {
+    if (vec)
+      hipLaunchKernelGGL((avgpool_bwd_kernel<4, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, N, H,
+                         W, C, kh, kw, accumulate, a, b, c);
+    else
+      hipLaunchKernelGGL((avgpool_bwd_kernel<1, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)dy, (T*)dx, N, H,
+                         W, C, kh, kw, accumulate, a, b, c);
+  });
   SG_LAUNCH_CHECK("avgpool_bwd_kernel");
   return 0;
 }
 
 int sg_upsample_nearest_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int sh, int sw,
                             const void* x, void* y, int y_ld) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32 && x && y, "sg_upsample_nearest_fwd: bad argument");
+  SG_CHECK_ARG(ctx && x && y, "sg_upsample_nearest_fwd: bad argument");
   SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && sh > 0 && sw > 0, "sg_upsample_nearest_fwd: bad geometry");
   if (y_ld == 0) y_ld = C;
   SG_CHECK_ARG(y_ld >= C, "sg_upsample_nearest_fwd: y_ld < C");
@@ -735,19 +758,21 @@ int sg_upsample_nearest_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, 
   const int V = vec ? 4 : 1;
   const unsigned blocks = ew_blocks((int64_t)N * H * sh * W * sw * (C / V));
   const FastDiv a = make_fastdiv((uint32_t)(C / V)), b = make_fastdiv((uint32_t)(W * sw)), c = make_fastdiv((uint32_t)(H * sh));
-  if (vec)
-    hipLaunchKernelGGL((upsample_fwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                       (float*)y, N, H, W, C, sh, sw, y_ld, a, b, c);
-  else
-    hipLaunchKernelGGL((upsample_fwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                       (float*)y, N, H, W, C, sh, sw, y_ld, a, b, c);
+  SG_DTYPE_SWITCH(dtype, "sg_upsample_nearest_fwd", {
+    if (vec)
+      hipLaunchKernelGGL((upsample_fwd_kernel<4, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, N, H, W,
+                         C, sh, sw, y_ld, a, b, c);
+    else
+      hipLaunchKernelGGL((upsample_fwd_kernel<1, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)x, (T*)y, N, H, W,
+                         C, sh, sw, y_ld, a, b, c);
+  });
   SG_LAUNCH_CHECK("upsample_fwd_kernel");
   return 0;
 }
 
 int sg_upsample_nearest_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int sh, int sw,
                             const void* dy, int dy_ld, void* dx, int accumulate) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32 && dy && dx, "sg_upsample_nearest_bwd: bad argument");
+  SG_CHECK_ARG(ctx && dy && dx, "sg_upsample_nearest_bwd: bad argument");
   SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && sh > 0 && sw > 0, "sg_upsample_nearest_bwd: bad geometry");
   if (dy_ld == 0) dy_ld = C;
   SG_CHECK_ARG(dy_ld >= C, "sg_upsample_nearest_bwd: dy_ld < C");
@@ -756,12 +781,14 @@ int sg_upsample_nearest_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, 
   const int V = vec ? 4 : 1;
   const unsigned blocks = ew_blocks((int64_t)N * H * W * (C / V));
   const FastDiv a = make_fastdiv((uint32_t)(C / V)), b = make_fastdiv((uint32_t)W), c = make_fastdiv((uint32_t)H);
-  if (vec)
-    hipLaunchKernelGGL((upsample_bwd_kernel<4>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, dy_ld,
-                       (float*)dx, N, H, W, C, sh, sw, accumulate, a, b, c);
-  else
-    hipLaunchKernelGGL((upsample_bwd_kernel<1>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float*)dy, dy_ld,
-                       (float*)dx, N, H, W, C, sh, sw, accumulate, a, b, c);
+  SG_DTYPE_SWITCH(dtype, "sg_upsample_nearest_bwd", {
+    if (vec)
+      hipLaunchKernelGGL((upsample_bwd_kernel<4, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)dy, dy_ld, (T*)dx,
+                         N, H, W, C, sh, sw, accumulate, a, b, c);
+    else
+      hipLaunchKernelGGL((upsample_bwd_kernel<1, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)dy, dy_ld, (T*)dx,
+                         N, H, W, C, sh, sw, accumulate, a, b, c);
+  });
   SG_LAUNCH_CHECK("upsample_bwd_kernel");
   return 0;
 }

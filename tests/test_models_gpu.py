@@ -468,7 +468,7 @@ def test_backward_chain_exact_multi_op(engine):
     for k, r in ref.items():
         a, b = got[k].detach().cpu().double().reshape(-1), r.reshape(-1)
         rel = float((a - b).abs().max() / max(float(b.abs().max()), 1e-30))
-        if rel > worst[1]:
+        if rel > worst[1] and k != "bpw":
             worst = (k, rel)
         # bpw feeds BatchNormalization: its true gradient is 0 (fp64 autograd returns ~1e-19); hold it to noise level
         if k == "bpw":
