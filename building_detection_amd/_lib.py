@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsegengine.so")
 
 SG_F32, SG_BF16, SG_I64 = 0, 1, 2
+SG_HEAD_F32 = 0x100  # OR-ed into the dtype of a thin 1x1 conv on bf16 storage: its few-channel side is fp32 (softmax head)
 SG_COMM_ID_BYTES = 128
 SG_EPI_BIAS, SG_EPI_RELU = 1, 2
 SG_ACT_RELU, SG_ACT_SIGMOID = 0, 1
@@ -98,6 +99,7 @@ _SIGNATURES = {
     "sg_edge_labels": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sg_argmax_accumulate_i8": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i]),
     "sg_vote_ge": (_i, [_vp, _vp, _i, _pp, _i64, _i, _vp]),
+    "sg_cast": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),
     "sg_fill_f32": (_i, [_vp, _vp, _vp, _i64, _f]),
     "sg_trace_mark": (_i, [_vp, _vp, _i, _i]),
     "sg_scale_f32": (_i, [_vp, _vp, _vp, _i64, _f]),

@@ -21,6 +21,14 @@ __global__ void fill_f32_kernel(float* __restrict__ p, int64_t n, float v) {
 template <int TAG, int END>
 __global__ void sg_trace_mark_kernel() {}
 
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+  const int64_t nv = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) st4<TD>(dst + 4 * i, ld4<TS>(src + 4 * i));
+  const int64_t i = (nv << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (blockIdx.x == 0 && i < n) st1<TD>(dst + i, ld1<TS>(src + i));
+}
+
 __global__ void scale_f32_kernel(float* __restrict__ p, int64_t n, float a) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -76,6 +84,26 @@ int sg_fill_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float value) {
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)p, n, value);
   SG_LAUNCH_CHECK("fill_f32_kernel");
+  return 0;
+}
+
+int sg_cast(sg_ctx* ctx, void* stream, int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst) {
+  SG_CHECK_ARG(ctx && (src || n == 0) && (dst || n == 0) && n >= 0, "sg_cast: bad argument");
+  SG_CHECK_ARG((src_dtype == SG_F32 || src_dtype == SG_BF16) && (dst_dtype == SG_F32 || dst_dtype == SG_BF16), "sg_cast: dtype");
+  SG_CHECK_ARG((((uintptr_t)src | (uintptr_t)dst) & 15) == 0, "sg_cast: pointers must be 16-byte aligned");
+  if (n == 0) return 0;
+  int64_t blocks = sg_cdiv(n / 4 + 1, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipStream_t st = (hipStream_t)stream;
+  if (src_dtype == SG_F32 && dst_dtype == SG_BF16)
+    hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dtype == SG_BF16 && dst_dtype == SG_F32)
+    hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dtype == SG_F32)
+    hipLaunchKernelGGL((cast_kernel<float, float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+  else
+    hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+  SG_LAUNCH_CHECK("cast_kernel");
   return 0;
 }
 

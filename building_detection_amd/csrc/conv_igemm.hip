@@ -68,8 +68,14 @@ __device__ __forceinline__ int spt_of(const IgemmParams& p) { return p.C / BK; }
 // per-row source offsets and bounds flags then change only when the slab stream crosses a tap boundary (every
 // Cin/32 slabs) and a slab's gather costs a handful of adds instead of ~170 VALU/SALU instructions of
 // div/mod, bounds and 64-bit address arithmetic ahead of the first MFMA.
-template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT>
+template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT, typename TA = float>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kernel(const IgemmParams p) {
+  // TA = storage type of the activations x and y (bf16: widened to fp32 on load, rounded on store; the arithmetic is
+  // the fp32 MFMA either way).  The buffer-addressed UT path exists for fp32 storage only: bf16 tensors that qualify
+  // for it run on the bf16 matrix-pipe kernels instead (conv_x6.h), this kernel is their any-shape fallback.
+  static_assert(!UT || std::is_same<TA, float>::value, "the UT gather is fp32-only");
+  const TA* __restrict__ px = reinterpret_cast<const TA*>(p.x);
+  TA* __restrict__ py = reinterpret_cast<TA*>(p.y);
   constexpr int NT = 64 * WGM * WGN;        // 4 or 8 waves; two workgroups per CU => 2 or 4 waves per SIMD
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
       for (int j = 0; j < NA; ++j) {
         int64_t off;
         const bool v = gather_elem_addr(j, dh, dw, kvalid, off);
-        const f32x4 val = *reinterpret_cast<const f32x4*>(p.x + (v ? off + ci : 0));
+        const f32x4 val = ld4<TA>(px + (v ? off + ci : 0));
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         ra[S][j] = v ? val : z;
       }
@@ -239,7 +245,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
         for (int j = 0; j < NA; ++j) {
           int64_t off;
           const bool v = gather_elem_addr(j, dh, dw, kvalid, off);
-          const float val = p.x[v ? off + ci : 0];
+          const float val = ld1<TA>(px + (v ? off + ci : 0));
           ra[S][j][e] = v ? val : 0.f;
         }
       }
@@ -447,7 +453,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
         if (cv && row < p.M) {
           float v = acc[i][j][r] + bv;
           if (do_relu) v = fmaxf(v, 0.f);
-          p.y[(int64_t)row * p.y_ld + col] = v;
+          st1<TA>(py + (int64_t)row * p.y_ld + col, v);
         }
       }
     }
@@ -503,8 +509,11 @@ struct WgradParams {
 // two CONSTANT voffsets (pixel-in-slab x channel) and tests its column against W.  No per-thread running
 // state, no div/mod, ~10 fewer VGPRs: the kernel runs at the 128-VGPR cap and the state used to spill, and a
 // spill reload inside the slab loop waits on vmcnt(0), i.e. drains the prefetch.
-template <int BN, int WGM, int WGN, int PF, bool VEC, int FAST>
+template <int BN, int WGM, int WGN, int PF, bool VEC, int FAST, typename TA = float>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_kernel(const WgradParams p) {
+  static_assert(FAST == 0 || std::is_same<TA, float>::value, "the buffer-addressed wgrad paths are fp32-only");
+  const TA* __restrict__ px = reinterpret_cast<const TA*>(p.x);
+  const TA* __restrict__ pdy = reinterpret_cast<const TA*>(p.dy);
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -705,7 +714,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
       if constexpr (VEC) {
         const int ih = (int)oh * p.stride + dh[0], iw = (int)ow * p.stride + dw[0];
         const bool v = pv && rvalid[0] && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-        const f32x4 val = *reinterpret_cast<const f32x4*>(p.x + (v ? (int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[0] : 0));
+        const f32x4 val = ld4<TA>(px + (v ? (int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[0] : 0));
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         ra[S][j] = v ? val : z;
       } else {
@@ -713,7 +722,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
         for (int e = 0; e < 4; ++e) {
           const int ih = (int)oh * p.stride + dh[e], iw = (int)ow * p.stride + dw[e];
           const bool v = pv && rvalid[e] && ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
-          const float val = p.x[v ? (int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[e] : 0];
+          const float val = ld1<TA>(px + (v ? (int64_t)(pixbase + ih * p.W + iw) * p.x_ld + ci_e[e] : 0));
           ra[S][j][e] = v ? val : 0.f;
         }
       }
@@ -725,14 +734,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
       const int pp = p0 + kr, n = n0 + 4 * c4;
       if constexpr (VEC) {
         const bool v = (pp < p.P) && (n < p.Cout);
-        const f32x4 val = *reinterpret_cast<const f32x4*>(p.dy + (v ? (int64_t)pp * p.y_ld + n : 0));
+        const f32x4 val = ld4<TA>(pdy + (v ? (int64_t)pp * p.y_ld + n : 0));
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         rb[S][i] = v ? val : z;
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool v = (pp < p.P) && (n + e < p.Cout);
-          const float val = p.dy[v ? (int64_t)pp * p.y_ld + n + e : 0];
+          const float val = ld1<TA>(pdy + (v ? (int64_t)pp * p.y_ld + n + e : 0));
           rb[S][i][e] = v ? val : 0.f;
         }
       }
@@ -899,9 +908,10 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
 }
 
 // bias gradient = column sums of dy[rows][C] (pixel stride ld), through the fixed-order segmented reducer
+template <typename T>
 struct ColSumOp {
   static constexpr int NOUT = 1;
-  const float* __restrict__ a;
+  const T* __restrict__ a;
   float* out;
   int ld;
   template <int V>
@@ -919,10 +929,11 @@ size_t colsum_ws_bytes(int num_cus, int64_t rows, int C) {
   return a.part_bytes > b.part_bytes ? a.part_bytes : b.part_bytes;
 }
 
-int launch_colsum(int num_cus, const float* dy, int64_t rows, int C, int ld, float* out, float* part, hipStream_t st) {
+template <typename T>
+int launch_colsum(int num_cus, const T* dy, int64_t rows, int C, int ld, float* out, float* part, hipStream_t st) {
   const bool vec = (C % 4 == 0) && (ld % 4 == 0) && sg_aligned16(dy);
   const SegPlan pl = seg_plan<1>(num_cus, 1, rows, C, vec);
-  ColSumOp op;
+  ColSumOp<T> op;
   op.a = dy; op.out = out; op.ld = ld;
   return seg_reduce_launch(op, pl, 1, rows, C, part, st, "colsum");
 }
@@ -971,13 +982,13 @@ int conv_l2(bool x6 = false) {
   return v;
 }
 
-template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT>
+template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT, typename TA = float>
 int launch_igemm_ut(const IgemmParams& p, hipStream_t st) {
   // + tapinfo[64] + row_lin[NA][NT] (NA * NT = BM * BK / 4 ints)
   constexpr size_t lds = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 256 + (size_t)(BM * BK / 4) * sizeof(int);
   static bool attr_done = false;  // idempotent; racing threads set the same value
   if (!attr_done) {
-    int rc = set_dyn_lds(igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT>, lds);
+    int rc = set_dyn_lds(igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT, TA>, lds);
     if (rc) return rc;
     attr_done = true;
   }
@@ -986,7 +997,7 @@ int launch_igemm_ut(const IgemmParams& p, hipStream_t st) {
     sg_set_error("igemm: bad tile count %lld", (long long)tiles);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL((igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT, TA>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("igemm_conv_kernel");
   return 0;
 }
@@ -1044,6 +1055,7 @@ void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false) {
 #include "conv_x6.h"
 #include "conv_x6p.h"
 
+template <int NPL, typename TA>
 int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
   IgemmParams p = p_in;
   int bn = pick_bn(p.M, p.Nout, num_cus);
@@ -1075,6 +1087,11 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
   const int64_t tiles = sg_cdiv(p.M, BM) * sg_cdiv(p.Nout, bn);
   int var = x6_variant();
   if (var < 0) var = (tiles <= 3 * (int64_t)num_cus) ? 1 : 0;
+  if constexpr (NPL == 1) {  // the one-plane (bf16 product) kernels come in the two 8-wave structures only
+    if (bn == 128) return (var & 1) ? launch_x6<128, 2, 4, 2, 1, TA>(p, st) : launch_x6<128, 2, 4, 1, 1, TA>(p, st);
+    if (bn == 64) return (var & 1) ? launch_x6<64, 4, 2, 2, 1, TA>(p, st) : launch_x6<64, 4, 2, 1, 1, TA>(p, st);
+    return (var & 1) ? launch_x6<32, 4, 1, 2, 1, TA>(p, st) : launch_x6<32, 4, 1, 1, 1, TA>(p, st);
+  } else {
   if (bn == 128) {
     switch (var) {
       case 0: return launch_x6<128, 2, 4, 1>(p, st);
@@ -1092,26 +1109,46 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
     }
   }
   return (var & 1) ? launch_x6<32, 4, 1, 2>(p, st) : launch_x6<32, 4, 1, 1>(p, st);
+  }
 }
 
 // split the weights into the x6 planes (in `ws`) and run the x6 kernel
+// NPL = 3: the exact fp32 emulation; NPL = 1: bf16 products (TA = float: fp32 storage rounded on the way into LDS,
+// TA = bf16_t: SG_BF16 storage).  p.C is the depth of one tap of the reduction (Cin forward, Cout dgrad).
+template <int NPL, typename TA>
 int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH, int KW, void* ws, int num_cus,
            hipStream_t st) {
-  if (x6p_ok(p, KH, KW)) return run_x6p(p, w, dgrad, Cin, Cout, ws, num_cus, st);
+  if constexpr (NPL == 3) {
+    if (x6p_ok(p, KH, KW)) return run_x6p(p, w, dgrad, Cin, Cout, ws, num_cus, st);
+  }
+  const int Ck = p.C;
+  int Ckp = Ck;
+  if (Ck % BK != 0 && p.K != Ck) {  // virtual channel padding (x6_ok admitted the shape): whole slabs inside one tap
+    Ckp = x6_vpad_c(Ck);
+    p.K = (p.K / Ck) * Ckp;
+    p.C = Ckp;
+    p.fd_c = make_fastdiv((uint32_t)Ckp);
+  }
   const int K = p.K, N = p.Nout;
   p.Kpad = x6_kpad(K);
   p.Npad = x6_npad(N);
   p.wq = (const unsigned short*)ws;
-  p.w_bytes = (uint32_t)x6_planes_bytes(K, N);
+  p.w_bytes = (uint32_t)x6_planes_bytes(K, N, NPL);
   dim3 grid((unsigned)(p.Kpad / 32), (unsigned)(p.Npad / 32));
   if (!dgrad)
-    hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Cin,
-                       Cin * Cout, Cout, 1);
+    hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Ck,
+                       Cin * Cout, Cout, 1, NPL, Ckp);
   else
-    hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Cout,
-                       Cin * Cout, 1, Cout);
+    hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Ck,
+                       Cin * Cout, 1, Cout, NPL, Ckp);
   SG_LAUNCH_CHECK("split3_weights_kernel");
-  return dispatch_x6(p, num_cus, st);
+  return dispatch_x6<NPL, TA>(p, num_cus, st);
+}
+
+// workspace of the weight planes for a launch with `taps` taps of depth C (virtual padding included), N columns
+inline size_t x6_ws_bytes(int taps, int C, int N) {
+  const int k = taps > 1 ? taps * x6_vpad_c(C) : C;
+  return x6_planes_bytes(k, N, 3);
 }
 
 int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t st) {
@@ -1152,17 +1189,17 @@ int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t s
   return (var & 2) ? launch_igemm<32, 4, 1, 2, true>(p, st) : launch_igemm<32, 4, 1, 1, true>(p, st);
 }
 
-template <int BN, int WGM, int WGN, int PF, bool VEC, int FAST>
+template <int BN, int WGM, int WGN, int PF, bool VEC, int FAST, typename TA = float>
 int launch_wgrad_f(const WgradParams& p, int S, hipStream_t st) {
   constexpr size_t lds = (size_t)(2 * BK * BM + 2 * BK * BN) * sizeof(float) + (FAST ? (2 * 1024 + 4) * sizeof(int) : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST>, lds);
+    int rc = set_dyn_lds(igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST, TA>, lds);
     if (rc) return rc;
     attr_done = true;
   }
   const int64_t tiles = sg_cdiv(p.K, BM) * sg_cdiv(p.Cout, BN);
-  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST, TA>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("igemm_wgrad_kernel");
   return 0;
 }
@@ -1209,6 +1246,11 @@ int dispatch_wgrad(const WgradParams& p_in, int S, bool vec, hipStream_t st) {
       if (bn == 128) return launch_wgrad_x6<128, 2, 4, 2>(p, S, st);
       if (bn == 64) return launch_wgrad_x6<64, 4, 2, 2>(p, S, st);
       return launch_wgrad_x6<32, 4, 1, 2>(p, S, st);
+    }
+    if (x6_mode() == 2) {  // bf16 products in one pass on fp32 storage
+      if (bn == 128) return launch_wgrad_x6<128, 2, 4, 1, 1, float>(p, S, st);
+      if (bn == 64) return launch_wgrad_x6<64, 4, 2, 1, 1, float>(p, S, st);
+      return launch_wgrad_x6<32, 4, 1, 1, 1, float>(p, S, st);
     }
     if (bn == 128) return launch_wgrad_x6<128, 2, 4, 1>(p, S, st);
     if (bn == 64) return launch_wgrad_x6<64, 4, 2, 1>(p, S, st);
@@ -1264,9 +1306,9 @@ int check_desc(const sg_conv_desc* d, const char* who) {
 // would spend 97 % of its columns on zero padding, so they get streaming kernels instead: forward = LP lanes
 // per pixel, each lane one 16-byte channel chunk, sub-wave shuffle reduction; dgrad = one 16-byte store per
 // thread; wgrad = the segmented column reducer with Cout outputs per channel.
-template <int CO>
-__global__ __launch_bounds__(256) void thin_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ y, int64_t P,
+template <int CO, typename TA, typename TY>
+__global__ __launch_bounds__(256) void thin_fwd_kernel(const TA* __restrict__ x, const float* __restrict__ w,
+                                                       const float* __restrict__ bias, TY* __restrict__ y, int64_t P,
                                                        int chunks, int x_ld, int y_ld, int LP, int flags) {
   constexpr int PIX = 4;  // pixels per lane group: four independent 16-byte loads in flight
   const int t = threadIdx.x;
@@ -1290,7 +1332,7 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float* __restrict__
 #pragma unroll
     for (int i = 0; i < PIX; ++i) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-      xv[i] = pix[i] < P ? *reinterpret_cast<const f32x4*>(x + pix[i] * x_ld + 4 * c) : z;
+      xv[i] = pix[i] < P ? ld4<TA>(x + pix[i] * x_ld + 4 * c) : z;
     }
 #pragma unroll
     for (int i = 0; i < PIX; ++i)
@@ -1312,15 +1354,15 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const float* __restrict__
       for (int o = 0; o < CO; ++o) {
         float v = acc[i][o] + ((flags & SG_EPI_BIAS) ? bias[o] : 0.f);
         if (flags & SG_EPI_RELU) v = fmaxf(v, 0.f);
-        y[pix[i] * y_ld + o] = v;
+        st1<TY>(y + pix[i] * y_ld + o, v);
       }
     }
   }
 }
 
-template <int CO>
-__global__ __launch_bounds__(256) void thin_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
-                                                         float* __restrict__ dx, int64_t total, int chunks, int y_ld,
+template <int CO, typename TA, typename TY>
+__global__ __launch_bounds__(256) void thin_dgrad_kernel(const TY* __restrict__ dy, const float* __restrict__ w,
+                                                         TA* __restrict__ dx, int64_t total, int chunks, int y_ld,
                                                          int x_ld) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
@@ -1328,7 +1370,7 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const float* __restrict
   const int c = (int)(gid - pix * chunks);
   float g[CO];
 #pragma unroll
-  for (int o = 0; o < CO; ++o) g[o] = dy[pix * y_ld + o];
+  for (int o = 0; o < CO; ++o) g[o] = ld1<TY>(dy + pix * y_ld + o);
   f32x4 r;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -1337,14 +1379,14 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const float* __restrict
     for (int o = 0; o < CO; ++o) a = fmaf(g[o], w[(4 * c + k) * CO + o], a);
     r[k] = a;
   }
-  *reinterpret_cast<f32x4*>(dx + pix * x_ld + 4 * c) = r;
+  st4<TA>(dx + pix * x_ld + 4 * c, r);
 }
 
-template <int CO>
+template <int CO, typename TA, typename TY>
 struct ThinWgradOp {
   static constexpr int NOUT = CO;
-  const float* __restrict__ x;
-  const float* __restrict__ dy;
+  const TA* __restrict__ x;
+  const TY* __restrict__ dy;
   float* dw;
   int x_ld, y_ld;
   template <int V>
@@ -1353,7 +1395,7 @@ struct ThinWgradOp {
     ldv<V>(x + r * x_ld + c, v);
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
-      const float g = dy[r * y_ld + o];
+      const float g = ld1<TY>(dy + r * y_ld + o);
 #pragma unroll
       for (int k = 0; k < V; ++k) acc[o][k] = fmaf(v[k], g, acc[o][k]);
     }
@@ -1383,35 +1425,35 @@ size_t thin_part_bytes(int num_cus, const sg_conv_desc* d) {
   }
 }
 
-template <int CO>
-int thin_fwd_t(const sg_conv_desc* d, const float* x, const float* w, const float* bias, float* y, int flags, hipStream_t st) {
+template <int CO, typename TA, typename TY>
+int thin_fwd_t(const sg_conv_desc* d, const TA* x, const float* w, const float* bias, TY* y, int flags, hipStream_t st) {
   const int64_t P = (int64_t)d->N * d->H * d->W;
   const int chunks = d->Cin / 4;
   int LP = 1;
   while (LP * 2 <= chunks && LP < 64) LP <<= 1;
   const int64_t groups = sg_cdiv(P, (int64_t)4 * (256 / LP));
-  hipLaunchKernelGGL((thin_fwd_kernel<CO>), dim3((unsigned)groups), dim3(256), 0, st, x, w, bias, y, P, chunks,
+  hipLaunchKernelGGL((thin_fwd_kernel<CO, TA, TY>), dim3((unsigned)groups), dim3(256), 0, st, x, w, bias, y, P, chunks,
                      d->x_ld ? d->x_ld : d->Cin, d->y_ld ? d->y_ld : d->Cout, LP, flags);
   SG_LAUNCH_CHECK("thin_fwd_kernel");
   return 0;
 }
 
-template <int CO>
-int thin_dgrad_t(const sg_conv_desc* d, const float* dy, const float* w, float* dx, hipStream_t st) {
+template <int CO, typename TA, typename TY>
+int thin_dgrad_t(const sg_conv_desc* d, const TY* dy, const float* w, TA* dx, hipStream_t st) {
   const int64_t P = (int64_t)d->N * d->H * d->W;
   const int chunks = d->Cin / 4;
   const int64_t total = P * chunks;
-  hipLaunchKernelGGL((thin_dgrad_kernel<CO>), dim3((unsigned)sg_cdiv(total, 256)), dim3(256), 0, st, dy, w, dx, total, chunks,
+  hipLaunchKernelGGL((thin_dgrad_kernel<CO, TA, TY>), dim3((unsigned)sg_cdiv(total, 256)), dim3(256), 0, st, dy, w, dx, total, chunks,
                      d->y_ld ? d->y_ld : d->Cout, d->x_ld ? d->x_ld : d->Cin);
   SG_LAUNCH_CHECK("thin_dgrad_kernel");
   return 0;
 }
 
-template <int CO>
-int thin_wgrad_t(int num_cus, const sg_conv_desc* d, const float* x, const float* dy, float* dw, float* part, hipStream_t st) {
+template <int CO, typename TA, typename TY>
+int thin_wgrad_t(int num_cus, const sg_conv_desc* d, const TA* x, const TY* dy, float* dw, float* part, hipStream_t st) {
   const int64_t P = (int64_t)d->N * d->H * d->W;
   const SegPlan pl = seg_plan<CO>(num_cus, 1, P, d->Cin, true);
-  ThinWgradOp<CO> op;
+  ThinWgradOp<CO, TA, TY> op;
   op.x = x; op.dy = dy; op.dw = dw;
   op.x_ld = d->x_ld ? d->x_ld : d->Cin;
   op.y_ld = d->y_ld ? d->y_ld : d->Cout;
@@ -1426,12 +1468,22 @@ int thin_wgrad_t(int num_cus, const sg_conv_desc* d, const float* x, const float
     default: return CALL(4);       \
   }
 
-// images per sub-batch such that both activation tensors stay under 2 GiB (>= N: no split needed)
-inline int images_per_2gib(const sg_conv_desc* d) {
+// images per sub-batch such that both activation tensors stay under 2 GiB (>= N: no split needed); eb = bytes per element
+inline int64_t images_limit_bytes() {
+  // test hook: SG_CONV_MAX_BYTES lowers the 2 GiB limit so that small tensors exercise the sub-batch paths
+  static int64_t lim = -1;
+  if (lim < 0) {
+    const char* e = getenv("SG_CONV_MAX_BYTES");
+    lim = e ? atoll(e) : ((1ll << 31) - (1ll << 20));
+    if (lim <= 0) lim = (1ll << 31) - (1ll << 20);
+  }
+  return lim;
+}
+inline int images_per_2gib(const sg_conv_desc* d, int eb = 4) {
   const int64_t xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
-  const int64_t xi = (int64_t)d->H * d->W * xl * 4, yi = (int64_t)d->Ho * d->Wo * yl * 4;
+  const int64_t xi = (int64_t)d->H * d->W * xl * eb, yi = (int64_t)d->Ho * d->Wo * yl * eb;
   const int64_t per = xi > yi ? xi : yi;
-  const int64_t lim = (1ll << 31) - (1ll << 20);
+  const int64_t lim = images_limit_bytes();
   if (per * d->N < lim) return d->N;
   const int64_t nb = lim / per;
   return (int)(nb < 1 ? 0 : nb);
@@ -1502,19 +1554,121 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
   return pl;
 }
 
+// ---- storage-type plumbing of the entry points ---------------------------------------------------------------------
+// dtype = SG_F32 or SG_BF16 (activation storage), optionally | SG_HEAD_F32: the few-channel side of a thin 1x1
+// convolution (y of the forward, dy of dgrad / wgrad) is fp32 although the activations are bf16 - the softmax head,
+// whose logits, probabilities and loss stay in fp32.
+inline int dt_storage(int dtype) { return dtype & 0xff; }
+inline bool dt_ok(int dtype) {
+  const int st = dt_storage(dtype);
+  return (st == SG_F32 || st == SG_BF16) && (dtype & ~(0xff | SG_HEAD_F32)) == 0;
+}
+inline int dt_bytes(int dtype) { return dt_storage(dtype) == SG_BF16 ? 2 : 4; }
+
+void fill_fwd_params(IgemmParams& p, const sg_conv_desc* d, const void* x, const void* w, const void* bias, void* y,
+                     int flags, int eb) {
+  p.x = (const float*)x;
+  p.w = (const float*)w;
+  p.bias = (const float*)bias;
+  p.y = (float*)y;
+  p.H = d->H; p.W = d->W; p.C = d->Cin; p.x_ld = d->x_ld ? d->x_ld : d->Cin;
+  p.OH = d->Ho; p.OW = d->Wo;
+  p.Nout = d->Cout; p.y_ld = d->y_ld ? d->y_ld : d->Cout;
+  p.a_mul = d->stride; p.k_mul = d->dilation; p.off_h = -d->pad_t; p.off_w = -d->pad_l; p.div = 1;
+  p.K = d->KH * d->KW * d->Cin;
+  p.M = d->N * d->Ho * d->Wo;
+  p.flags = flags;
+  p.fd_ohow = make_fastdiv((uint32_t)(d->Ho * d->Wo));
+  p.fd_ow = make_fastdiv((uint32_t)d->Wo);
+  p.fd_c = make_fastdiv((uint32_t)d->Cin);
+  p.fd_kw = make_fastdiv((uint32_t)d->KW);
+  const int64_t xb = (((int64_t)d->N * d->H * d->W - 1) * p.x_ld + d->Cin) * eb, wb = (int64_t)p.K * d->Cout * 4;
+  p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
+  p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
+  p.stats = nullptr;
+}
+
+void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, const void* wt, const void* bias, void* dx,
+                       int flags, int eb) {
+  p.x = (const float*)dy;
+  p.w = (const float*)wt;
+  p.bias = (const float*)bias;
+  p.y = (float*)dx;
+  p.H = d->Ho; p.W = d->Wo; p.C = d->Cout; p.x_ld = d->y_ld ? d->y_ld : d->Cout;
+  p.OH = d->H; p.OW = d->W;
+  p.Nout = d->Cin; p.y_ld = d->x_ld ? d->x_ld : d->Cin;
+  p.a_mul = 1; p.k_mul = -d->dilation; p.off_h = d->pad_t; p.off_w = d->pad_l; p.div = d->stride;
+  p.K = d->KH * d->KW * d->Cout;
+  p.M = d->N * d->H * d->W;
+  p.flags = flags;
+  p.fd_ohow = make_fastdiv((uint32_t)(d->H * d->W));
+  p.fd_ow = make_fastdiv((uint32_t)d->W);
+  p.fd_c = make_fastdiv((uint32_t)d->Cout);
+  p.fd_kw = make_fastdiv((uint32_t)d->KW);
+  const int64_t xb = (((int64_t)d->N * d->Ho * d->Wo - 1) * p.x_ld + d->Cout) * eb, wb = (int64_t)p.K * d->Cin * 4;
+  p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
+  p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
+  p.stats = nullptr;
+}
+
+// any-shape fallback for bf16 storage: the native fp32-MFMA kernel with widening loads and a rounding store
+int dispatch_igemm_b16(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t st) {
+  IgemmParams p = p_in;
+  const int bn = pick_bn(p.M, p.Nout, num_cus);
+  plan_common(p, false, bn);
+  p.stagger = 0;
+  p.ablate = 0;
+  p.skip_taps = 0;
+  p.cb = 0;
+  if (vec) {
+    if (bn == 128) return launch_igemm_ut<128, 2, 4, 1, true, false, bf16_t>(p, st);
+    if (bn == 64) return launch_igemm_ut<64, 4, 2, 1, true, false, bf16_t>(p, st);
+    return launch_igemm_ut<32, 4, 1, 1, true, false, bf16_t>(p, st);
+  }
+  if (bn == 128) return launch_igemm_ut<128, 2, 4, 1, false, false, bf16_t>(p, st);
+  if (bn == 64) return launch_igemm_ut<64, 4, 2, 1, false, false, bf16_t>(p, st);
+  return launch_igemm_ut<32, 4, 1, 1, false, false, bf16_t>(p, st);
+}
+
+int dispatch_wgrad_b16(const WgradParams& p_in, int S, bool vec8, bool vec4, hipStream_t st) {
+  WgradParams p = p_in;
+  p.KH_KW = p.K / p.Cin;
+  static int noskip = -1;
+  if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;
+  p.skip_slabs = (!noskip && p.dil > 1 && p.KH_KW > 1) ? 1 : 0;
+  p.stagger = 0;
+  const int bn = wgrad_bn(p.Cout);
+  if (wgrad_x6_ok(p, vec8, true)) {
+    p.tap_inner = ((conv_l2(true) & 4) && p.KH_KW > 1 && p.Cin % BM == 0) ? 1 : 0;
+    if (bn == 128) return launch_wgrad_x6<128, 2, 4, 1, 1, bf16_t>(p, S, st);
+    if (bn == 64) return launch_wgrad_x6<64, 4, 2, 1, 1, bf16_t>(p, S, st);
+    return launch_wgrad_x6<32, 4, 1, 1, 1, bf16_t>(p, S, st);
+  }
+  p.tap_inner = 0;
+  p.skip_slabs = 0;
+  if (vec4) {
+    if (bn == 128) return launch_wgrad_f<128, 2, 4, 1, true, 0, bf16_t>(p, S, st);
+    if (bn == 64) return launch_wgrad_f<64, 4, 2, 1, true, 0, bf16_t>(p, S, st);
+    return launch_wgrad_f<32, 4, 1, 1, true, 0, bf16_t>(p, S, st);
+  }
+  if (bn == 128) return launch_wgrad_f<128, 2, 4, 1, false, 0, bf16_t>(p, S, st);
+  if (bn == 64) return launch_wgrad_f<64, 4, 2, 1, false, 0, bf16_t>(p, S, st);
+  return launch_wgrad_f<32, 4, 1, 1, false, 0, bf16_t>(p, S, st);
+}
+
 }  // namespace
 
 extern "C" {
 
 int sg_set_conv_x6(int on) {
-  const int prev = x6_enabled() ? 1 : 0;
-  g_x6_enabled = on ? 1 : 0;
+  const int prev = x6_mode();
+  g_x6_enabled = (on < 0 || on > 2) ? 1 : on;
   return prev;
 }
 
 size_t sg_conv2d_fwd_ws_bytes(const sg_conv_desc* d) {
   if (!d) return 0;
-  return x6_planes_bytes(d->KH * d->KW * d->Cin, d->Cout) + 256;
+  return x6_ws_bytes(d->KH * d->KW, d->Cin, d->Cout) + 256;
 }
 
 int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
@@ -1536,23 +1690,27 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
                         const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out) {
   if (tiles_out) *tiles_out = 0;
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_fwd: null ctx");
-  SG_CHECK_ARG(dtype == SG_F32, "sg_conv2d_fwd: only SG_F32 is implemented");
+  SG_CHECK_ARG(dt_ok(dtype), "sg_conv2d_fwd: dtype %d", dtype);
   int rc = check_desc(d, "sg_conv2d_fwd");
   if (rc) return rc;
   SG_CHECK_ARG(x && w && y, "sg_conv2d_fwd: null tensor");
   SG_CHECK_ARG(!(flags & SG_EPI_BIAS) || bias, "sg_conv2d_fwd: SG_EPI_BIAS without bias");
-  {
+  const bool b16 = dt_storage(dtype) == SG_BF16, head32 = (dtype & SG_HEAD_F32) != 0;
+  const int eb = dt_bytes(dtype);
+  SG_CHECK_ARG(!head32 || (b16 && thin_ok(d) && aligned16(x)), "sg_conv2d_fwd: SG_HEAD_F32 needs a thin (Cout <= 4) 1x1 convolution on bf16 storage");
+  hipStream_t st = (hipStream_t)stream;
+  if (!head32) {
     // The fast kernels address their operands through 2 GiB buffer descriptors.  A larger batch is run as
     // sub-batches of whole images (independent in a forward conv), so every image takes the same kernel - and
     // therefore the same rounding - whatever batch it travels in.
-    const int nb = images_per_2gib(d);
+    const int nb = images_per_2gib(d, eb);
     if (nb < d->N && nb >= 1) {
       const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
       for (int n0 = 0; n0 < d->N; n0 += nb) {
         sg_conv_desc sub = *d;
         sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
-        const float* xs = (const float*)x + (int64_t)n0 * d->H * d->W * xl;
-        float* ys = (float*)y + (int64_t)n0 * d->Ho * d->Wo * yl;
+        const char* xs = (const char*)x + (int64_t)n0 * d->H * d->W * xl * eb;
+        char* ys = (char*)y + (int64_t)n0 * d->Ho * d->Wo * yl * eb;
         int rcs = sg_conv2d_fwd_ws(ctx, stream, dtype, &sub, xs, w, bias, ys, flags, ws, ws_bytes);  // (no statistics)
         if (rcs) return rcs;
       }
@@ -1560,41 +1718,40 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
     }
   }
   if (thin_ok(d) && aligned16(x)) {
-#define CALL(CO) thin_fwd_t<CO>(d, (const float*)x, (const float*)w, (const float*)bias, (float*)y, flags, (hipStream_t)stream)
-    THIN_SWITCH(d->Cout, CALL)
+    if (!b16) {
+#define CALL(CO) thin_fwd_t<CO, float, float>(d, (const float*)x, (const float*)w, (const float*)bias, (float*)y, flags, st)
+      THIN_SWITCH(d->Cout, CALL)
 #undef CALL
+    } else if (head32) {
+#define CALL(CO) thin_fwd_t<CO, bf16_t, float>(d, (const bf16_t*)x, (const float*)w, (const float*)bias, (float*)y, flags, st)
+      THIN_SWITCH(d->Cout, CALL)
+#undef CALL
+    } else {
+#define CALL(CO) thin_fwd_t<CO, bf16_t, bf16_t>(d, (const bf16_t*)x, (const float*)w, (const float*)bias, (bf16_t*)y, flags, st)
+      THIN_SWITCH(d->Cout, CALL)
+#undef CALL
+    }
   }
   IgemmParams p;
-  p.x = (const float*)x;
-  p.w = (const float*)w;
-  p.bias = (const float*)bias;
-  p.y = (float*)y;
-  p.H = d->H; p.W = d->W; p.C = d->Cin; p.x_ld = d->x_ld ? d->x_ld : d->Cin;
-  p.OH = d->Ho; p.OW = d->Wo;
-  p.Nout = d->Cout; p.y_ld = d->y_ld ? d->y_ld : d->Cout;
-  p.a_mul = d->stride; p.k_mul = d->dilation; p.off_h = -d->pad_t; p.off_w = -d->pad_l; p.div = 1;
-  p.K = d->KH * d->KW * d->Cin;
-  p.M = d->N * d->Ho * d->Wo;
-  p.flags = flags;
-  p.fd_ohow = make_fastdiv((uint32_t)(d->Ho * d->Wo));
-  p.fd_ow = make_fastdiv((uint32_t)d->Wo);
-  p.fd_c = make_fastdiv((uint32_t)d->Cin);
-  p.fd_kw = make_fastdiv((uint32_t)d->KW);
-  {
-    const int64_t xb = (((int64_t)d->N * d->H * d->W - 1) * p.x_ld + d->Cin) * 4, wb = (int64_t)p.K * d->Cout * 4;
-    p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
-    p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
-  }
-  const bool vec = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
-  p.stats = nullptr;
-  if (ws && aligned16(ws) && ws_bytes >= x6_planes_bytes(p.K, p.Nout) && x6_ok(p, vec)) {
+  fill_fwd_params(p, d, x, w, bias, y, flags, eb);
+  const int ch = b16 ? 8 : 4;
+  const bool vec = (d->Cin % ch == 0) && (p.x_ld % ch == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
+  const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);  // padded reads must stay inside this tensor
+  const bool have_ws = ws && aligned16(ws) && ws_bytes >= x6_ws_bytes(d->KH * d->KW, d->Cin, d->Cout);
+  if (have_ws && vpad_safe && x6_ok(p, vec, b16)) {
     if (stats && tiles_out && !(flags & SG_EPI_RELU)) {  // the statistics ride in the x6 kernel's epilogue only
       p.stats = (float*)stats;
       *tiles_out = (int)sg_cdiv(p.M, BM);
     }
-    return run_x6(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, (hipStream_t)stream);
+    if (b16) return run_x6<1, bf16_t>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
+    if (x6_mode() == 2) return run_x6<1, float>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
+    return run_x6<3, float>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
   }
-  return dispatch_igemm(p, vec, ctx->num_cus, (hipStream_t)stream);
+  if (b16) {
+    const bool vec4 = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (((uintptr_t)x & 7) == 0);
+    return dispatch_igemm_b16(p, vec4, ctx->num_cus, st);
+  }
+  return dispatch_igemm(p, vec, ctx->num_cus, st);
 }
 
 size_t sg_bn_tiles_ws_bytes(const sg_ctx* ctx, int tiles, int C) {
@@ -1605,7 +1762,8 @@ size_t sg_bn_tiles_ws_bytes(const sg_ctx* ctx, int tiles, int C) {
 int sg_bn_train_fwd_tiles(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* stats, int tiles,
                           void* moving_mean, void* moving_var, void* save_mean, void* save_invstd, float momentum,
                           float eps, int unbiased_update, void* ws, size_t ws_bytes) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32, "sg_bn_train_fwd_tiles: bad ctx/dtype");
+  // dtype names the storage of the activations the statistics belong to; the statistics themselves are fp32
+  SG_CHECK_ARG(ctx && (dtype == SG_F32 || dtype == SG_BF16), "sg_bn_train_fwd_tiles: bad ctx/dtype");
   SG_CHECK_ARG(rows > 0 && C > 0 && stats && tiles == (int)sg_cdiv(rows, BM) && moving_mean && moving_var && save_mean && save_invstd,
                "sg_bn_train_fwd_tiles: bad argument");
   const bool vec = (C % 4 == 0) && sg_aligned16(stats);
@@ -1625,14 +1783,14 @@ int sg_bn_train_fwd_tiles(sg_ctx* ctx, void* stream, int dtype, int64_t rows, in
 size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d) {
   if (!d) return 0;
   const size_t native = (size_t)d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
-  const size_t x6 = x6_planes_bytes(d->KH * d->KW * d->Cout, d->Cin);
+  const size_t x6 = x6_ws_bytes(d->KH * d->KW, d->Cout, d->Cin);
   return native > x6 ? native : x6;
 }
 
 int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
                     const void* bias, void* dx, int flags, void* ws, size_t ws_bytes) {
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_dgrad: null ctx");
-  SG_CHECK_ARG(dtype == SG_F32, "sg_conv2d_dgrad: only SG_F32 is implemented");
+  SG_CHECK_ARG(dt_ok(dtype), "sg_conv2d_dgrad: dtype %d", dtype);
   int rc = check_desc(d, "sg_conv2d_dgrad");
   if (rc) return rc;
   SG_CHECK_ARG(dy && w && dx, "sg_conv2d_dgrad: null tensor");
@@ -1647,62 +1805,67 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     return SG_EWORKSPACE;
   }
   SG_CHECK_ARG(aligned16(ws), "sg_conv2d_dgrad: workspace must be 16-byte aligned");
+  const bool b16 = dt_storage(dtype) == SG_BF16, head32 = (dtype & SG_HEAD_F32) != 0;
+  const int eb = dt_bytes(dtype);
+  const bool thin = thin_ok(d) && aligned16(dx) && !(flags & (SG_EPI_BIAS | SG_EPI_RELU));
+  SG_CHECK_ARG(!head32 || (b16 && thin), "sg_conv2d_dgrad: SG_HEAD_F32 needs a thin (Cout <= 4) 1x1 convolution on bf16 storage");
   hipStream_t st = (hipStream_t)stream;
-  {
-    const int nb = images_per_2gib(d);  // see sg_conv2d_fwd_ws
+  if (!head32) {
+    const int nb = images_per_2gib(d, eb);  // see sg_conv2d_fwd_ws
     if (nb < d->N && nb >= 1) {
       const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
       for (int n0 = 0; n0 < d->N; n0 += nb) {
         sg_conv_desc sub = *d;
         sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
-        const float* dys = (const float*)dy + (int64_t)n0 * d->Ho * d->Wo * yl;
-        float* dxs = (float*)dx + (int64_t)n0 * d->H * d->W * xl;
+        const char* dys = (const char*)dy + (int64_t)n0 * d->Ho * d->Wo * yl * eb;
+        char* dxs = (char*)dx + (int64_t)n0 * d->H * d->W * xl * eb;
         int rcs = sg_conv2d_dgrad(ctx, stream, dtype, &sub, dys, w, bias, dxs, flags, ws, ws_bytes);
         if (rcs) return rcs;
       }
       return 0;
     }
   }
-  if (thin_ok(d) && aligned16(dx) && !(flags & (SG_EPI_BIAS | SG_EPI_RELU))) {
-#define CALL(CO) thin_dgrad_t<CO>(d, (const float*)dy, (const float*)w, (float*)dx, st)
-    THIN_SWITCH(d->Cout, CALL)
+  if (thin) {
+    if (!b16) {
+#define CALL(CO) thin_dgrad_t<CO, float, float>(d, (const float*)dy, (const float*)w, (float*)dx, st)
+      THIN_SWITCH(d->Cout, CALL)
 #undef CALL
+    } else if (head32) {
+#define CALL(CO) thin_dgrad_t<CO, bf16_t, float>(d, (const float*)dy, (const float*)w, (bf16_t*)dx, st)
+      THIN_SWITCH(d->Cout, CALL)
+#undef CALL
+    } else {
+#define CALL(CO) thin_dgrad_t<CO, bf16_t, bf16_t>(d, (const bf16_t*)dy, (const float*)w, (bf16_t*)dx, st)
+      THIN_SWITCH(d->Cout, CALL)
+#undef CALL
+    }
   }
   float* wt = (float*)ws;
   IgemmParams p;
-  p.x = (const float*)dy;
-  p.w = wt;
-  p.bias = (const float*)bias;
-  p.y = (float*)dx;
-  p.H = d->Ho; p.W = d->Wo; p.C = d->Cout; p.x_ld = d->y_ld ? d->y_ld : d->Cout;
-  p.OH = d->H; p.OW = d->W;
-  p.Nout = d->Cin; p.y_ld = d->x_ld ? d->x_ld : d->Cin;
-  p.a_mul = 1; p.k_mul = -d->dilation; p.off_h = d->pad_t; p.off_w = d->pad_l; p.div = d->stride;
-  p.K = d->KH * d->KW * d->Cout;
-  p.M = d->N * d->H * d->W;
-  p.flags = flags;
-  p.fd_ohow = make_fastdiv((uint32_t)(d->H * d->W));
-  p.fd_ow = make_fastdiv((uint32_t)d->W);
-  p.fd_c = make_fastdiv((uint32_t)d->Cout);
-  p.fd_kw = make_fastdiv((uint32_t)d->KW);
-  {
-    const int64_t xb = (((int64_t)d->N * d->Ho * d->Wo - 1) * p.x_ld + d->Cout) * 4, wb = (int64_t)p.K * d->Cin * 4;
-    p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
-    p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
+  fill_dgrad_params(p, d, dy, wt, bias, dx, flags, eb);
+  const int ch = b16 ? 8 : 4;
+  const bool vec = (d->Cout % ch == 0) && (p.x_ld % ch == 0) && (d->Cin % 4 == 0) && aligned16(dy);
+  const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);
+  if (vpad_safe && x6_ok(p, vec, b16)) {
+    if (b16) return run_x6<1, bf16_t>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
+    if (x6_mode() == 2) return run_x6<1, float>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
+    return run_x6<3, float>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
   }
-  p.stats = nullptr;
-  const bool vec = (d->Cout % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy);
-  if (x6_ok(p, vec)) return run_x6(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
   {
     dim3 grid((unsigned)sg_cdiv(d->Cout, 32), (unsigned)sg_cdiv(d->Cin, 32), (unsigned)(d->KH * d->KW));
     hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, st, (const float*)w, wt, d->Cin, d->Cout);
     SG_LAUNCH_CHECK("transpose_taps_kernel");
   }
-  return dispatch_igemm(p, vec, ctx->num_cus, st);
+  if (b16) {
+    const bool vec4 = (d->Cout % 4 == 0) && (p.x_ld % 4 == 0) && (((uintptr_t)dy & 7) == 0);
+    return dispatch_igemm_b16(p, vec4, ctx->num_cus, st);
+  }
+  return dispatch_igemm(p, (d->Cout % 4 == 0) && (p.x_ld % 4 == 0) && (d->Cin % 4 == 0) && aligned16(dy), ctx->num_cus, st);
 }
 
 size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
   if (!ctx || !d) return 0;
+  // planned for 2-byte elements too: a bf16 tensor needs at most as many sub-batches as the fp32 one
   WgradPlan pl = plan_wgrad(ctx->num_cus, d);
   return pl.dw_part_bytes + pl.bias_part_bytes + 512;
 }
@@ -1710,10 +1873,13 @@ size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
 int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
                     void* dw, void* dbias, void* ws, size_t ws_bytes) {
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_wgrad: null ctx");
-  SG_CHECK_ARG(dtype == SG_F32, "sg_conv2d_wgrad: only SG_F32 is implemented");
+  SG_CHECK_ARG(dt_ok(dtype), "sg_conv2d_wgrad: dtype %d", dtype);
   int rc = check_desc(d, "sg_conv2d_wgrad");
   if (rc) return rc;
   SG_CHECK_ARG(x && dy && dw, "sg_conv2d_wgrad: null tensor");
+  const bool b16 = dt_storage(dtype) == SG_BF16, head32 = (dtype & SG_HEAD_F32) != 0;
+  const int eb = dt_bytes(dtype);
+  // the split / sub-batch plan is the fp32 one for both storages (same partial-slab layout, same workspace)
   const WgradPlan pl = plan_wgrad(ctx->num_cus, d);
   const size_t need = pl.dw_part_bytes + pl.bias_part_bytes + 512;
   if (!ws || ws_bytes < need) {
@@ -1722,26 +1888,41 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   }
   SG_CHECK_ARG(aligned16(ws), "sg_conv2d_wgrad: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  if (thin_ok(d) && aligned16(x)) {
+  const bool thin = thin_ok(d) && aligned16(x);
+  SG_CHECK_ARG(!head32 || (b16 && thin), "sg_conv2d_wgrad: SG_HEAD_F32 needs a thin (Cout <= 4) 1x1 convolution on bf16 storage");
+  const int64_t rows_y = (int64_t)d->N * d->Ho * d->Wo;
+  const int yl_ = d->y_ld ? d->y_ld : d->Cout;
+  float* bias_part = (float*)((char*)ws + ((pl.dw_part_bytes + 255) & ~(size_t)255));  // 256-byte aligned, after the dw partials
+  auto bias_grad = [&]() -> int {
+    if (!dbias) return 0;
+    if (!b16 || head32) return launch_colsum<float>(ctx->num_cus, (const float*)dy, rows_y, d->Cout, yl_, (float*)dbias, bias_part, st);
+    return launch_colsum<bf16_t>(ctx->num_cus, (const bf16_t*)dy, rows_y, d->Cout, yl_, (float*)dbias, bias_part, st);
+  };
+  if (thin) {
     auto run = [&]() -> int {
-#define CALL(CO) thin_wgrad_t<CO>(ctx->num_cus, d, (const float*)x, (const float*)dy, (float*)dw, (float*)ws, st)
-      THIN_SWITCH(d->Cout, CALL)
+      if (!b16) {
+#define CALL(CO) thin_wgrad_t<CO, float, float>(ctx->num_cus, d, (const float*)x, (const float*)dy, (float*)dw, (float*)ws, st)
+        THIN_SWITCH(d->Cout, CALL)
 #undef CALL
+      } else if (head32) {
+#define CALL(CO) thin_wgrad_t<CO, bf16_t, float>(ctx->num_cus, d, (const bf16_t*)x, (const float*)dy, (float*)dw, (float*)ws, st)
+        THIN_SWITCH(d->Cout, CALL)
+#undef CALL
+      } else {
+#define CALL(CO) thin_wgrad_t<CO, bf16_t, bf16_t>(ctx->num_cus, d, (const bf16_t*)x, (const bf16_t*)dy, (float*)dw, (float*)ws, st)
+        THIN_SWITCH(d->Cout, CALL)
+#undef CALL
+      }
     };
     rc = run();
     if (rc) return rc;
-    if (dbias) {
-      float* part = (float*)((char*)ws + ((pl.dw_part_bytes + 255) & ~(size_t)255));
-      return launch_colsum(ctx->num_cus, (const float*)dy, (int64_t)d->N * d->Ho * d->Wo, d->Cout, d->y_ld ? d->y_ld : d->Cout,
-                           (float*)dbias, part, st);
-    }
-    return 0;
+    return bias_grad();
   }
   const int K_all = d->KH * d->KW * d->Cin;
-  auto launch_part = [&](const sg_conv_desc& dd, const float* xs, const float* dys, float* out, int S, int sps) -> int {
+  auto launch_part = [&](const sg_conv_desc& dd, const void* xs, const void* dys, float* out, int S, int sps) -> int {
     WgradParams p;
-    p.x = xs;
-    p.dy = dys;
+    p.x = (const float*)xs;
+    p.dy = (const float*)dys;
     p.out = out;
     p.H = dd.H; p.W = dd.W; p.Cin = dd.Cin; p.x_ld = dd.x_ld ? dd.x_ld : dd.Cin;
     p.OH = dd.Ho; p.OW = dd.Wo; p.Cout = dd.Cout; p.y_ld = dd.y_ld ? dd.y_ld : dd.Cout;
@@ -1755,10 +1936,16 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     p.fd_kw = make_fastdiv((uint32_t)dd.KW);
     p.fd_oh = make_fastdiv((uint32_t)dd.Ho);
     {
-      const int64_t xb = (((int64_t)dd.N * dd.H * dd.W - 1) * p.x_ld + dd.Cin) * 4;
-      const int64_t yb = (((int64_t)p.P - 1) * p.y_ld + dd.Cout) * 4;
+      const int64_t xb = (((int64_t)dd.N * dd.H * dd.W - 1) * p.x_ld + dd.Cin) * eb;
+      const int64_t yb = (((int64_t)p.P - 1) * p.y_ld + dd.Cout) * eb;
       p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
       p.dy_bytes = yb < (1ll << 31) ? (uint32_t)yb : 0;
+    }
+    if (b16) {
+      const bool vec8 = (dd.Cin % 8 == 0) && (p.x_ld % 8 == 0) && (dd.Cout % 8 == 0) && (p.y_ld % 8 == 0) && aligned16(xs) && aligned16(dys);
+      const bool vec4 = (dd.Cin % 4 == 0) && (p.x_ld % 4 == 0) && (dd.Cout % 4 == 0) && (p.y_ld % 4 == 0) &&
+                        (((uintptr_t)xs & 7) == 0) && (((uintptr_t)dys & 7) == 0);
+      return dispatch_wgrad_b16(p, S, vec8, vec4, st);
     }
     const bool vec = (dd.Cin % 4 == 0) && (p.x_ld % 4 == 0) && (dd.Cout % 4 == 0) && (p.y_ld % 4 == 0) &&
                      aligned16(xs) && aligned16(dys);
@@ -1773,13 +1960,13 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
       sg_conv_desc sub = *d;
       const int n0 = c * pl.nb;
       sub.N = (d->N - n0 < pl.nb) ? d->N - n0 : pl.nb;
-      rc = launch_part(sub, (const float*)x + (int64_t)n0 * d->H * d->W * xl, (const float*)dy + (int64_t)n0 * d->Ho * d->Wo * yl,
+      rc = launch_part(sub, (const char*)x + (int64_t)n0 * d->H * d->W * xl * eb, (const char*)dy + (int64_t)n0 * d->Ho * d->Wo * yl * eb,
                        (float*)ws + (int64_t)c * pl.S * slab, pl.S, pl.slabs_per_split);
       if (rc) return rc;
     }
     total_parts = pl.chunks * pl.S;
   } else {
-    rc = launch_part(*d, (const float*)x, (const float*)dy, pl.S > 1 ? (float*)ws : (float*)dw, pl.S, pl.slabs_per_split);
+    rc = launch_part(*d, x, dy, pl.S > 1 ? (float*)ws : (float*)dw, pl.S, pl.slabs_per_split);
     if (rc) return rc;
   }
   if (total_parts > 1) {
@@ -1793,14 +1980,7 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
       hipLaunchKernelGGL(reduce_splits_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, (float*)dw, n, total_parts);
     SG_LAUNCH_CHECK("reduce_splits_kernel");
   }
-  if (dbias) {
-    // 256-byte aligned region after the dw partials
-    float* part = (float*)((char*)ws + ((pl.dw_part_bytes + 255) & ~(size_t)255));
-    rc = launch_colsum(ctx->num_cus, (const float*)dy, (int64_t)d->N * d->Ho * d->Wo, d->Cout, d->y_ld ? d->y_ld : d->Cout,
-                       (float*)dbias, part, st);
-    if (rc) return rc;
-  }
-  return 0;
+  return bias_grad();
 }
 
 size_t sg_bias_grad_ws_bytes(const sg_ctx* ctx, int64_t rows, int C) {
@@ -1810,7 +1990,7 @@ size_t sg_bias_grad_ws_bytes(const sg_ctx* ctx, int64_t rows, int C) {
 
 int sg_bias_grad(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, int ld, const void* dy, void* dbias,
                  void* ws, size_t ws_bytes) {
-  SG_CHECK_ARG(ctx && dtype == SG_F32 && dy && dbias && rows > 0 && C > 0, "sg_bias_grad: bad argument");
+  SG_CHECK_ARG(ctx && (dtype == SG_F32 || dtype == SG_BF16) && dy && dbias && rows > 0 && C > 0, "sg_bias_grad: bad argument");
   if (ld == 0) ld = C;
   SG_CHECK_ARG(ld >= C, "sg_bias_grad: ld < C");
   const size_t need = colsum_ws_bytes(ctx->num_cus, rows, C);
@@ -1818,7 +1998,9 @@ int sg_bias_grad(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, int 
     sg_set_error("sg_bias_grad: workspace %zu < %zu", ws_bytes, need);
     return SG_EWORKSPACE;
   }
-  return launch_colsum(ctx->num_cus, (const float*)dy, rows, C, ld, (float*)dbias, (float*)ws, (hipStream_t)stream);
+  if (dtype == SG_BF16)
+    return launch_colsum<bf16_t>(ctx->num_cus, (const bf16_t*)dy, rows, C, ld, (float*)dbias, (float*)ws, (hipStream_t)stream);
+  return launch_colsum<float>(ctx->num_cus, (const float*)dy, rows, C, ld, (float*)dbias, (float*)ws, (hipStream_t)stream);
 }
 
 int sg_dense_fwd(sg_ctx* ctx, void* stream, int dtype, int rows, int in, int out, const void* x, const void* w,

@@ -49,9 +49,12 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 // B[k][n] = w[tap*s_tap + kk*s_k + n*s_n]  (k = tap*Ck + kk)  ->  planes[3][Npad][Kpad] bf16, zero padded.
 //   forward: Ck = Cin,  s_tap = Cin*Cout, s_k = Cout, s_n = 1      (w is HWIO)
 //   dgrad  : Ck = Cout, s_tap = Cin*Cout, s_k = 1,    s_n = Cout   (the per-tap transpose)
+// npl = 1 writes the bf16 rounding alone (the bf16 paths: one MFMA pass).  Ckp >= Ck is the per-tap depth of the k
+// index: with Ckp > Ck every tap is zero-padded to Ckp channels ("virtual channel padding": the kernel then walks
+// whole 32-deep slabs inside one tap for any channel count and multiplies the surplus A columns by these zeros).
 __global__ __launch_bounds__(256) void split3_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
                                                              int K, int N, int Kpad, int Npad, int Ck, int s_tap, int s_k,
-                                                             int s_n) {
+                                                             int s_n, int npl, int Ckp) {
   __shared__ float tile[32][33];
   const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -61,8 +64,8 @@ __global__ __launch_bounds__(256) void split3_weights_kernel(const float* __rest
     const int k = k0 + ky, n = n0 + nx;
     float v = 0.f;
     if (k < K && n < N) {
-      const int tap = k / Ck, kk = k - tap * Ck;
-      v = w[(int64_t)tap * s_tap + (int64_t)kk * s_k + (int64_t)n * s_n];
+      const int tap = k / Ckp, kk = k - tap * Ckp;
+      if (kk < Ck) v = w[(int64_t)tap * s_tap + (int64_t)kk * s_k + (int64_t)n * s_n];
     }
     tile[ky][nx] = v;
   }
@@ -75,14 +78,18 @@ __global__ __launch_bounds__(256) void split3_weights_kernel(const float* __rest
     split3_pair(x, 0.f, h, m, l);
     const int64_t o = (int64_t)n * Kpad + k;
     planes[o] = (unsigned short)(h & 0xffffu);
-    planes[plane + o] = (unsigned short)(m & 0xffffu);
-    planes[2 * plane + o] = (unsigned short)(l & 0xffffu);
+    if (npl == 3) {
+      planes[plane + o] = (unsigned short)(m & 0xffffu);
+      planes[2 * plane + o] = (unsigned short)(l & 0xffffu);
+    }
   }
 }
 
 inline int x6_kpad(int K) { return (int)(sg_cdiv(K, 32) * 32); }
 inline int x6_npad(int N) { return (int)(sg_cdiv(N, 128) * 128); }
-inline size_t x6_planes_bytes(int K, int N) { return (size_t)3 * x6_kpad(K) * x6_npad(N) * 2; }
+inline size_t x6_planes_bytes(int K, int N, int npl = 3) { return (size_t)npl * x6_kpad(K) * x6_npad(N) * 2; }
+// K of a launch under virtual channel padding: ntaps * roundup(C, 32)
+inline int x6_vpad_c(int C) { return (int)(sg_cdiv(C, 32) * 32); }
 
 // PF == 1: single LDS buffer, two barriers per slab, two workgroups per CU (128 VGPRs per wave).
 // PF == 2: ONE workgroup per CU with the whole register file (256 VGPRs per wave): LDS double-buffered, one
@@ -92,21 +99,30 @@ inline size_t x6_planes_bytes(int K, int N) { return (size_t)3 * x6_kpad(K) * x6
 //   a CU run in lockstep - store, barrier, compute - and the phases simply add up: measured store 0.41 ms +
 //   compute 0.66 ms = 1.02 ms on the ASPP forward; the bare read + MFMA loop reaches 80-88 % of the pipe,
 //   profiles/r01_exp_x6_loop.txt.)
-template <int BN, int WGM, int WGN, int PF>
+// NPL = 3, TA = float: the exact fp32 emulation above.  NPL = 1: ONE bf16 plane per operand and one MFMA per k-step
+// and tile (bf16 products, fp32 accumulation) - with TA = float the fp32 activations are rounded to bf16 on their way
+// into LDS, with TA = bf16_t (SG_BF16 storage) a thread's 16-byte chunk holds 8 k and goes to LDS as it is (no
+// arithmetic at all between the global load and the MFMA); the output is stored as TA.
+template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float>
 __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM * WGN / 2) void conv_x6_kernel(const IgemmParams p) {
+  static_assert(NPL == 3 || NPL == 1, "planes");
+  static_assert(NPL == 1 || std::is_same<TA, float>::value, "the three-plane split is the fp32 path");
+  constexpr bool A16 = !std::is_same<TA, float>::value;  // bf16 storage
+  constexpr int EB = EL<TA>::BYTES, CH = EL<TA>::CH;
+  constexpr int CPR = BK / CH;             // 16-byte chunks per A row of a slab: 8 (fp32) or 4 (bf16)
   constexpr int NT = 64 * WGM * WGN;
-  constexpr int BUFSZ = 3 * (BM + BN) * XPITCH;  // one LDS buffer: A planes then B planes
+  constexpr int BUFSZ = NPL * (BM + BN) * XPITCH;  // one LDS buffer: A planes then B planes
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int NA = (BM * BK / 4) / NT;  // float4 A chunks per thread (rows r0 + RS*j)
-  constexpr int RS = NT / 8;
-  constexpr int NBC = BN * 4 * 3;         // 16-byte chunks of one B slab (3 planes x BN rows x 4)
+  constexpr int NA = (BM * CPR) / NT;     // 16-byte A chunks per thread (rows r0 + RS*j)
+  constexpr int RS = NT / CPR;
+  constexpr int NBC = BN * 4 * NPL;       // 16-byte chunks of one B slab (NPL planes x BN rows x 4)
   constexpr int NB = (NBC + NT - 1) / NT;
   static_assert(TM >= 1 && TN >= 1 && NA >= 1, "tile too small for the wave layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  char* Ap = smem;                          // [PF buffers] x { A [3][BM][XPITCH], B [3][BN][XPITCH] }
-  char* Bp = Ap + 3 * BM * XPITCH;
+  char* Ap = smem;                          // [PF buffers] x { A [NPL][BM][XPITCH], B [NPL][BN][XPITCH] }
+  char* Bp = Ap + NPL * BM * XPITCH;
   int* tapinfo = reinterpret_cast<int*>(smem + PF * BUFSZ);  // [64]
   int* row_lin_lds = tapinfo + 64;          // [NA][NT]
 
@@ -127,7 +143,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   const int m0 = tile_m * BM, n0 = tile_n * BN;
 
   // ---- A rows (same gather as igemm_conv_kernel's UT path) ----------------------------------------------
-  const int kc = t & 7, r0 = t >> 3;
+  const int kc = t % CPR, r0 = t / CPR;
   int row_hw[NA];
 #pragma unroll
   for (int j = 0; j < NA; ++j) {
@@ -180,7 +196,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   const __amdgpu_buffer_rsrc_t rsrc_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wq), 0, (int)p.w_bytes, 0x00020000);
 
-  f32x4 ra[PF][NA];
+  u32x4_t ra[PF][NA];
   u32x4_t rb[PF][NB];
   auto load_AB = [&](int k0, auto SET) {
     constexpr int S = decltype(SET)::value;
@@ -194,34 +210,43 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
       for (int j = 0; j < NA; ++j) {
         int64_t off;
         const bool ok = gather_elem_addr(j, dh, dw, off) && tap < ntaps;
-        tap_voff[j] = ok ? (unsigned)off * 4u + 16u * kc : OOB;
+        tap_voff[j] = ok ? (unsigned)off * (unsigned)EB + 16u * kc : OOB;
       }
     }
-    const int soff_a = (k0 - tap * p.C) * 4;
-    const bool kvalid = !ktail || (k0 + 4 * kc < p.K);
+    const int soff_a = (k0 - tap * p.C) * EB;
+    const bool kvalid = !ktail || (k0 + CH * kc < p.K);
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
-      ra[S][j] = __builtin_bit_cast(f32x4, v);
-    }
+    for (int j = 0; j < NA; ++j)
+      ra[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
     const int soff_b = k0 * 2;
 #pragma unroll
     for (int i = 0; i < NB; ++i) rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
   };
 
+  // one thread's A chunk of register set S, row r0 + RS j, to buffer `buf`
+  auto store_A1 = [&](const u32x4_t v, int j, int buf) {
+    const int arow = r0 + RS * j;
+    if constexpr (A16) {  // 8 k of bf16: the chunk goes to LDS as it is
+      *reinterpret_cast<u32x4_t*>(Ap + buf * BUFSZ + arow * XPITCH + ((kc ^ xswz(arow)) << 4)) = v;
+    } else {
+      const f32x4 f = __builtin_bit_cast(f32x4, v);
+      char* dst = Ap + buf * BUFSZ + arow * XPITCH + (((kc >> 1) ^ xswz(arow)) << 4) + (kc & 1) * 8;
+      if constexpr (NPL == 3) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pair(f[0], f[1], h0, m0_, l0);
+        split3_pair(f[2], f[3], h1, m1, l1);
+        *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
+        *reinterpret_cast<u32x2_t*>(dst + BM * XPITCH) = (u32x2_t){m0_, m1};
+        *reinterpret_cast<u32x2_t*>(dst + 2 * BM * XPITCH) = (u32x2_t){l0, l1};
+      } else {
+        *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3])};
+      }
+    }
+  };
   auto store_AB = [&](auto SET, int buf) {
     constexpr int S = decltype(SET)::value;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      unsigned h0, m0_, l0, h1, m1, l1;
-      split3_pair(ra[S][j][0], ra[S][j][1], h0, m0_, l0);
-      split3_pair(ra[S][j][2], ra[S][j][3], h1, m1, l1);
-      const int arow = r0 + RS * j;
-      char* dst = Ap + buf * BUFSZ + arow * XPITCH + (((kc >> 1) ^ xswz(arow)) << 4) + (kc & 1) * 8;
-      *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
-      *reinterpret_cast<u32x2_t*>(dst + BM * XPITCH) = (u32x2_t){m0_, m1};
-      *reinterpret_cast<u32x2_t*>(dst + 2 * BM * XPITCH) = (u32x2_t){l0, l1};
-    }
+    for (int j = 0; j < NA; ++j) store_A1(ra[S][j], j, buf);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int idx = t + NT * i;
@@ -261,19 +286,19 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     const char* b_lane_b = b_lane + buf * BUFSZ;
 #pragma unroll
     for (int k0s = 0; k0s < 2; k0s += KH) {
-      bf16x8_t af[KH][TM][3], bf[KH][TN][3];
+      bf16x8_t af[KH][TM][NPL], bf[KH][TN][NPL];
 #pragma unroll
       for (int kq = 0; kq < KH; ++kq) {
         const int ks = k0s + kq;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
+          for (int pl = 0; pl < NPL; ++pl)
             af[kq][i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (pl * BM + 32 * i) * XPITCH + koff[ks]);
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-          for (int pl = 0; pl < 3; ++pl)
+          for (int pl = 0; pl < NPL; ++pl)
             bf[kq][j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (pl * BN + 32 * j) * XPITCH + koff[ks]);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -283,12 +308,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j) {
+            if constexpr (NPL == 1) {
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][0], bf[kq][j][0], acc[i][j], 0, 0, 0);
+              continue;
+            }
             // smallest terms first
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][2], bf[kq][j][0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][0], bf[kq][j][2], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][1], bf[kq][j][1], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][1], bf[kq][j][0], acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][0], bf[kq][j][1], acc[i][j], 0, 0, 0);
+            constexpr int P2 = NPL == 3 ? 2 : 0, P1 = NPL == 3 ? 1 : 0;  // (NPL == 1 never reaches these)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][P2], bf[kq][j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][0], bf[kq][j][P2], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][P1], bf[kq][j][P1], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][P1], bf[kq][j][0], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][0], bf[kq][j][P1], acc[i][j], 0, 0, 0);
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kq][i][0], bf[kq][j][0], acc[i][j], 0, 0, 0);
           }
       }
@@ -311,7 +341,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
       for (int j = 0; j < NA; ++j) {
         int64_t off;
         const bool ok = gather_elem_addr(j, dh, dw, off) && tap < ntaps;
-        tap_voff[j] = ok ? (unsigned)off * 4u + 16u * kc : OOB;
+        tap_voff[j] = ok ? (unsigned)off * (unsigned)EB + 16u * kc : OOB;
       }
     }
   };
@@ -339,15 +369,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
           if (ks == 0 && i == 0) __builtin_amdgcn_sched_barrier(0);  // keep the first tile's operands first in the queue
         }
     __builtin_amdgcn_sched_barrier(0);
-    const int soff_a = (k0 - cur_tap * p.C) * 4, soff_b = k0 * 2;
-    const bool kvalid = !ktail || (k0 + 4 * kc < p.K);
+    const int soff_a = (k0 - cur_tap * p.C) * EB, soff_b = k0 * 2;
+    const bool kvalid = !ktail || (k0 + CH * kc < p.K);
     unsigned hs[NA][2], ms[NA][2], ls[NA][2];
     constexpr int P_SPLIT = 2 * NA;            // pieces: 2*NA splits, NA A-writes, NB B-writes, NA + NB loads
     constexpr int P_AW = P_SPLIT + NA, P_BW = P_AW + NB, P_LA = P_BW + NA, P_LB = P_LA + NB;
     auto piece = [&](int w) {
       if (w < P_SPLIT) {
         const int j = w >> 1, hf = w & 1;
-        split3_pair(ra[S][j][2 * hf], ra[S][j][2 * hf + 1], hs[j][hf], ms[j][hf], ls[j][hf]);
+        const f32x4 f = __builtin_bit_cast(f32x4, ra[S][j]);
+        split3_pair(f[2 * hf], f[2 * hf + 1], hs[j][hf], ms[j][hf], ls[j][hf]);
       } else if (w < P_AW) {
         const int j = w - P_SPLIT;
         const int arow = r0 + RS * j;
@@ -364,8 +395,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         }
       } else if (w < P_LA) {
         const int j = w - P_BW;
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
-        ra[S][j] = __builtin_bit_cast(f32x4, v);
+        ra[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
       } else if (w < P_LB) {
         const int i = w - P_LA;
         rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
@@ -382,6 +412,55 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     }
 #pragma unroll
     for (int w = NM; w < P_LB; ++w) piece(w);  // narrow tiles have more pieces than MFMAs
+  };
+
+  // The same step for ONE plane (NPL == 1): 2 * TM * TN MFMAs per slab; the pieces woven between them are the LDS
+  // stores of slab s+1 (a conversion first when the storage is fp32) and the loads of slab s+3.
+  auto fused_step1 = [&](int k0, auto SET, int sbuf, int cbuf) {
+    constexpr int S = decltype(SET)::value;
+    constexpr int NM = 2 * TM * TN;
+    const char* a_lane_b = a_lane + cbuf * BUFSZ;
+    const char* b_lane_b = b_lane + cbuf * BUFSZ;
+    bf16x8_t af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[ks][i] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (32 * i) * XPITCH + koff[ks]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[ks][j] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (32 * j) * XPITCH + koff[ks]);
+      if (ks == 0) __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int soff_a = (k0 - cur_tap * p.C) * EB, soff_b = k0 * 2;
+    const bool kvalid = !ktail || (k0 + CH * kc < p.K);
+    constexpr int P_AW = NA, P_BW = P_AW + NB, P_LA = P_BW + NA, P_LB = P_LA + NB;
+    auto piece = [&](int w) {
+      if (w < P_AW) {
+        store_A1(ra[S][w], w, sbuf);
+      } else if (w < P_BW) {
+        const int i = w - P_AW, idx = t + NT * i;
+        if ((NBC % NT == 0) || idx < NBC) {
+          const int row = idx >> 2, c = idx & 3;
+          *reinterpret_cast<u32x4_t*>(Bp + sbuf * BUFSZ + row * XPITCH + ((c ^ xswz(row)) << 4)) = rb[S][i];
+        }
+      } else if (w < P_LA) {
+        const int j = w - P_BW;
+        ra[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
+      } else if (w < P_LB) {
+        const int i = w - P_LA;
+        rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
+      }
+    };
+#pragma unroll
+    for (int q = 0; q < NM; ++q) {
+      const int ks = q / (TM * TN), tile = q % (TM * TN);
+      const int i = tile / TN, j = tile % TN;
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+      if (q < P_LB) piece(q);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int w = NM; w < P_LB; ++w) piece(w);
   };
 
   // ---- slab stream (padding-tap elimination and channel-block order as in igemm_conv_kernel) ---------------
@@ -463,12 +542,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         for (int s = 0; s < nslab; s += 2) {
           const int ka = next_k0();
           prep_load(ka);
-          fused_step(ka, IC<1>{}, 1, 0);
+          if constexpr (NPL == 3) fused_step(ka, IC<1>{}, 1, 0);
+          else fused_step1(ka, IC<1>{}, 1, 0);
           __syncthreads();
           if (s + 1 >= nslab) break;
           const int kb = next_k0();
           prep_load(kb);
-          fused_step(kb, IC<0>{}, 0, 1);
+          if constexpr (NPL == 3) fused_step(kb, IC<0>{}, 0, 1);
+          else fused_step1(kb, IC<0>{}, 0, 1);
           __syncthreads();
         }
       } else
@@ -506,7 +587,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         if (cv && row < p.M) {
           float v = acc[i][j][r] + bv;
           if (do_relu) v = fmaxf(v, 0.f);
-          p.y[(int64_t)row * p.y_ld + col] = v;
+          st1<TA>(reinterpret_cast<TA*>(p.y) + (int64_t)row * p.y_ld + col, v);
         }
       }
     }
@@ -608,14 +689,17 @@ struct BnTilesOp {
   }
 };
 
-template <int BN, int WGM, int WGN, int PF>
+template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float>
 int launch_x6(const IgemmParams& p, hipStream_t st) {
   constexpr int NT = 64 * WGM * WGN;
-  constexpr size_t lds = (size_t)PF * 3 * (BM + BN) * XPITCH + 256 + (size_t)(BM * BK / 4) * sizeof(int);
+  // the statistics epilogue reuses the front of LDS for [WGM][BN] + [BN] floats: keep at least that much
+  constexpr size_t slab_lds = (size_t)PF * NPL * (BM + BN) * XPITCH;
+  constexpr size_t stat_lds = (size_t)(WGM + 1) * BN * sizeof(float);
+  constexpr size_t lds = (slab_lds > stat_lds ? slab_lds : stat_lds) + 256 + (size_t)(BM * BK / 4) * sizeof(int);
   (void)NT;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(conv_x6_kernel<BN, WGM, WGN, PF>, lds);
+    int rc = set_dyn_lds(conv_x6_kernel<BN, WGM, WGN, PF, NPL, TA>, lds);
     if (rc) return rc;
     attr_done = true;
   }
@@ -624,7 +708,7 @@ int launch_x6(const IgemmParams& p, hipStream_t st) {
     sg_set_error("conv_x6: bad tile count %lld", (long long)tiles);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL((conv_x6_kernel<BN, WGM, WGN, PF>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((conv_x6_kernel<BN, WGM, WGN, PF, NPL, TA>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("conv_x6_kernel");
   return 0;
 }
@@ -640,20 +724,33 @@ inline int x6_variant() {
   return v;
 }
 
-// A/B switch: SG_CONV_X6=0 keeps every convolution on the native fp32 MFMA kernel.
+// Convolution arithmetic on fp32 storage (sg_set_conv_x6 / SG_CONV_X6): 0 = native fp32 MFMA, 1 = the exact
+// six-pass emulation (default), 2 = bf16 products, one pass (fp32 tensors rounded to bf16 on the way into LDS, fp32
+// accumulation: the arithmetic of the SG_BF16 path on fp32 tensors).
 int g_x6_enabled = -1;  // -1: not yet read from the environment; set by sg_set_conv_x6()
-inline bool x6_enabled() {
+inline int x6_mode() {
   if (g_x6_enabled < 0) {
     const char* e = getenv("SG_CONV_X6");
-    g_x6_enabled = e ? (atoi(e) != 0) : 1;
+    g_x6_enabled = e ? atoi(e) : 1;
+    if (g_x6_enabled < 0 || g_x6_enabled > 2) g_x6_enabled = 1;
   }
-  return g_x6_enabled != 0;
+  return g_x6_enabled;
+}
+inline bool x6_enabled() { return x6_mode() != 0; }
+inline bool x6_vpad_on() {
+  static int v = -1;
+  if (v < 0) v = getenv("SG_X6_VPAD") ? atoi(getenv("SG_X6_VPAD")) : 1;
+  return v != 0;
 }
 
-// Can this launch take the x6 kernel?  (UT gather: every 32-deep slab inside one tap; 16-byte channel runs.)
-inline bool x6_ok(const IgemmParams& p, bool vec) {
-  const bool ut = (p.C % BK == 0) || (p.K == p.C);
-  return x6_enabled() && vec && ut && p.x_bytes != 0 && x6_planes_bytes(p.K, p.Nout) < (1ull << 31) && p.Nout >= 16;
+// Can this launch take the bf16-pipe kernels?  UT gather: every 32-deep slab inside one tap - Cin % 32 == 0, a 1x1
+// kernel, or (virtual channel padding, run_x6) any channel count that keeps the pixel rows 16-byte aligned; `vec` =
+// 16-byte channel runs (4 fp32 / 8 bf16).  force: SG_BF16 storage has no other fast kernel, so the mode switch is not asked.
+inline bool x6_ok(const IgemmParams& p, bool vec, bool force = false) {
+  const bool ut = (p.C % BK == 0) || (p.K == p.C) || x6_vpad_on();
+  const int64_t kmax = (int64_t)(p.K / p.C) * x6_vpad_c(p.C);
+  return (force || x6_enabled()) && vec && ut && p.x_bytes != 0 && x6_planes_bytes((int)kmax, p.Nout) < (1ull << 31) &&
+         p.Nout >= 16;
 }
 
 // ---- wgrad on the bf16 pipe --------------------------------------------------------------------------------------
@@ -686,22 +783,30 @@ struct X6WPitch {
 // PF == 1: single LDS buffer, two barriers per slab, two workgroups per CU.  PF == 2: one workgroup per CU, LDS
 // double-buffered, two register sets and the hand-interleaved step of conv_x6_kernel (the staging of slab s+1
 // and the loads of slab s+3 woven into the MFMA gaps of slab s).
-template <int BN, int WGM, int WGN, int PF>
+// NPL / TA as in conv_x6_kernel: NPL = 1 is the bf16 product (one plane, one MFMA per k-step and tile); with TA = bf16_t
+// both operands are bf16 in HBM and a thread's 16-byte chunk (8 channels) goes to LDS unchanged.
+template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float>
 __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM * WGN / 2) void wgrad_x6_kernel(const WgradParams p) {
+  static_assert(NPL == 3 || NPL == 1, "planes");
+  static_assert(NPL == 1 || std::is_same<TA, float>::value, "the three-plane split is the fp32 path");
+  constexpr bool A16 = !std::is_same<TA, float>::value;
+  constexpr int EB = EL<TA>::BYTES, CH = EL<TA>::CH;
+  constexpr int CPA = BM / CH;            // 16-byte chunks per A' pixel row: 32 (fp32) or 16 (bf16)
+  constexpr int CPB = BN / CH;
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int NA = (BK * BM / 4) / NT;  // float4 A' chunks per thread (pixel rows pr0 + PS*j)
-  constexpr int PS = NT / 32;
-  constexpr int NB = (BK * BN / 4 + NT - 1) / NT;
-  constexpr int NBC = BK * BN / 4;
+  constexpr int NA = (BK * CPA) / NT;     // 16-byte A' chunks per thread (pixel rows pr0 + PS*j)
+  constexpr int PS = NT / CPA;
+  constexpr int NBC = BK * CPB;
+  constexpr int NB = (NBC + NT - 1) / NT;
   constexpr int PA = X6WPitch<BN>::A, PB = X6WPitch<BN>::B;
   static_assert(NA >= 1 && TM >= 1 && TN >= 1, "tile too small for the wave layout");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BUFSZ = 3 * BK * (PA + PB);  // one LDS buffer: A' planes then B planes
-  char* Ap = smem;                     // [PF buffers] x { A' [3][BK][PA], B [3][BK][PB] }
-  char* Bp = Ap + 3 * BK * PA;
+  constexpr int BUFSZ = NPL * BK * (PA + PB);  // one LDS buffer: A' planes then B planes
+  char* Ap = smem;                     // [PF buffers] x { A' [NPL][BK][PA], B [NPL][BK][PB] }
+  char* Bp = Ap + NPL * BK * PA;
   int* slist = reinterpret_cast<int*>(smem + PF * BUFSZ);  // [1 + 1024] + flags[1024]
 
   const int t = threadIdx.x;
@@ -727,8 +832,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
 
   // This thread's four r-rows (one float4 of channels) lie in ONE tap (Cin % 4 == 0); the tile's 128 rows may
   // span several taps (Cin < 128), so the tap offset (dh, dw) is per thread and rides in the voffset.
-  const int rc = t & 31, pr0 = t >> 5;
-  const int r_first = rbase + 4 * rc;
+  const int rc = t % CPA, pr0 = t / CPA;
+  const int r_first = rbase + CH * rc;
   const bool rvalid = r_first < p.K;
   const int tap = (rvalid ? r_first : rbase) / p.Cin;
   int s_dh, s_dw;
@@ -750,20 +855,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   // (pixel-in-slab + tap shift + SH) * x_ld + channel is non-negative and the slab's position is the scalar offset
   const int SH = p.pad_t * p.W + p.pad_l;
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<float*>(p.x) - (int64_t)SH * p.x_ld, 0, (int)(p.x_bytes + (uint32_t)(SH * p.x_ld * 4)), 0x00020000);
+      reinterpret_cast<char*>(const_cast<float*>(p.x)) - (int64_t)SH * p.x_ld * EB, 0,
+      (int)(p.x_bytes + (uint32_t)(SH * p.x_ld * EB)), 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
   unsigned a_voffc[NA], b_voff[NB];
 #pragma unroll
   for (int j = 0; j < NA; ++j)
-    a_voffc[j] = rvalid ? (unsigned)((pr0 + PS * j + s_dh * p.W + s_dw + SH) * p.x_ld + ci0) * 4u : OOB;
+    a_voffc[j] = rvalid ? (unsigned)((pr0 + PS * j + s_dh * p.W + s_dw + SH) * p.x_ld + ci0) * (unsigned)EB : OOB;
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int idx = t + NT * i;
-    const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-    b_voff[i] = (idx < NBC && (n0 + 4 * c4) < p.Cout) ? (unsigned)(kr * p.y_ld + n0 + 4 * c4) * 4u : OOB;
+    const int kr = idx / CPB, c4 = idx % CPB;
+    b_voff[i] = (idx < NBC && (n0 + CH * c4) < p.Cout) ? (unsigned)(kr * p.y_ld + n0 + CH * c4) * (unsigned)EB : OOB;
   }
 
-  f32x4 ra[PF][NA], rb[PF][NB];
+  u32x4_t ra[PF][NA], rb[PF][NB];
   auto load_AB = [&](int p0, auto SET) {
     constexpr int S = decltype(SET)::value;
     uint32_t q, ow0, n_, oh;
@@ -771,47 +877,45 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     fd_divmod(q, p.fd_oh, n_, oh);
     const int ih = (int)oh + s_dh;
     const bool row_ok = (unsigned)ih < (unsigned)p.H;
-    const int soff_a = p0 * p.x_ld * 4;
+    const int soff_a = p0 * p.x_ld * EB;
     const int col0 = (int)ow0 + s_dw + pr0;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const bool v = row_ok && ((unsigned)(col0 + PS * j) < (unsigned)p.W);
-      const u32x4_t val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a, 0);
-      ra[S][j] = __builtin_bit_cast(f32x4, val);
+      ra[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a, 0);
     }
-    const int soff_b = p0 * p.y_ld * 4;
+    const int soff_b = p0 * p.y_ld * EB;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) {
-      const u32x4_t val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b, 0);
-      rb[S][i] = __builtin_bit_cast(f32x4, val);
-    }
+    for (int i = 0; i < NB; ++i) rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b, 0);
   };
 
+  // one 16-byte chunk (4 fp32 or 8 bf16 channels of one pixel) to its place in the [pixel][channel] LDS image
+  auto store_chunk = [&](const u32x4_t v, char* plane0, int pixel, int chunk, int pitch) {
+    if constexpr (A16) {
+      *reinterpret_cast<u32x4_t*>(plane0 + pixel * pitch + chunk * 16) = v;
+    } else {
+      const f32x4 f = __builtin_bit_cast(f32x4, v);
+      char* dst = plane0 + pixel * pitch + chunk * 8;
+      if constexpr (NPL == 3) {
+        unsigned h0, m0_, l0, h1, m1, l1;
+        split3_pair(f[0], f[1], h0, m0_, l0);
+        split3_pair(f[2], f[3], h1, m1, l1);
+        *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
+        *reinterpret_cast<u32x2_t*>(dst + BK * pitch) = (u32x2_t){m0_, m1};
+        *reinterpret_cast<u32x2_t*>(dst + 2 * BK * pitch) = (u32x2_t){l0, l1};
+      } else {
+        *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){pack2_bf16(f[0], f[1]), pack2_bf16(f[2], f[3])};
+      }
+    }
+  };
   auto store_AB = [&](auto SET, int buf) {
     constexpr int S = decltype(SET)::value;
 #pragma unroll
-    for (int j = 0; j < NA; ++j) {
-      unsigned h0, m0_, l0, h1, m1, l1;
-      split3_pair(ra[S][j][0], ra[S][j][1], h0, m0_, l0);
-      split3_pair(ra[S][j][2], ra[S][j][3], h1, m1, l1);
-      char* dst = Ap + buf * BUFSZ + (pr0 + PS * j) * PA + rc * 8;
-      *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
-      *reinterpret_cast<u32x2_t*>(dst + BK * PA) = (u32x2_t){m0_, m1};
-      *reinterpret_cast<u32x2_t*>(dst + 2 * BK * PA) = (u32x2_t){l0, l1};
-    }
+    for (int j = 0; j < NA; ++j) store_chunk(ra[S][j], Ap + buf * BUFSZ, pr0 + PS * j, rc, PA);
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int idx = t + NT * i;
-      if (idx < NBC) {
-        const int kr = idx / (BN / 4), c4 = idx % (BN / 4);
-        unsigned h0, m0_, l0, h1, m1, l1;
-        split3_pair(rb[S][i][0], rb[S][i][1], h0, m0_, l0);
-        split3_pair(rb[S][i][2], rb[S][i][3], h1, m1, l1);
-        char* dst = Bp + buf * BUFSZ + kr * PB + c4 * 8;
-        *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
-        *reinterpret_cast<u32x2_t*>(dst + BK * PB) = (u32x2_t){m0_, m1};
-        *reinterpret_cast<u32x2_t*>(dst + 2 * BK * PB) = (u32x2_t){l0, l1};
-      }
+      if (idx < NBC) store_chunk(rb[S][i], Bp + buf * BUFSZ, idx / CPB, idx % CPB, PB);
     }
   };
 
@@ -835,18 +939,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   auto compute = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[TM][3], bf[TN][3];
+      bf16x8_t af[TM][NPL], bf[TN][NPL];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
           const char* a = a_lane + buf * BUFSZ + (pl * BK + 16 * ks) * PA + 64 * i;
           af[i][pl] = tr_frag(a, a + 4 * PA);
         }
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
+        for (int pl = 0; pl < NPL; ++pl) {
           const char* b = b_lane + buf * BUFSZ + (pl * BK + 16 * ks) * PB + 64 * j;
           bf[j][pl] = tr_frag(b, b + 4 * PB);
         }
@@ -854,11 +958,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+          if constexpr (NPL == 1) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            continue;
+          }
+          constexpr int P2 = NPL == 3 ? 2 : 0, P1 = NPL == 3 ? 1 : 0;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][P2], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][P2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][P1], bf[j][P1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][P1], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][P1], acc[i][j], 0, 0, 0);
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
         }
     }
@@ -914,7 +1023,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         if (do_ld) load_AB(pn, IC<0>{});
         if (do_mm) compute(0);
       }
-    } else {
+    } else if constexpr (NPL == 3) {
       // fused step: MFMAs of the slab in buffer cbuf with, one piece per MFMA, the split + store of register set S
       // into buffer sbuf and the loads of slab p0 into the same set
       auto fused_step = [&](int p0, auto SET, int sbuf, int cbuf) {
@@ -951,7 +1060,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         auto piece = [&](int w) {
           if (w < P_SA) {
             const int j = w >> 1, hf = w & 1;
-            split3_pair(ra[S][j][2 * hf], ra[S][j][2 * hf + 1], ha[j][hf], ma[j][hf], la[j][hf]);
+            const f32x4 f = __builtin_bit_cast(f32x4, ra[S][j]);
+            split3_pair(f[2 * hf], f[2 * hf + 1], ha[j][hf], ma[j][hf], la[j][hf]);
           } else if (w < P_WA) {
             const int j = w - P_SA;
             char* dst = Ap + sbuf * BUFSZ + (pr0 + PS * j) * PA + rc * 8;
@@ -960,7 +1070,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
             *reinterpret_cast<u32x2_t*>(dst + 2 * BK * PA) = (u32x2_t){la[j][0], la[j][1]};
           } else if (w < P_SB) {
             const int i = (w - P_WA) >> 1, hf = (w - P_WA) & 1;
-            split3_pair(rb[S][i][2 * hf], rb[S][i][2 * hf + 1], hb[i][hf], mb[i][hf], lb[i][hf]);
+            const f32x4 f = __builtin_bit_cast(f32x4, rb[S][i]);
+            split3_pair(f[2 * hf], f[2 * hf + 1], hb[i][hf], mb[i][hf], lb[i][hf]);
           } else if (w < P_WB) {
             const int i = w - P_SB, idx = t + NT * i;
             if ((NBC % NT == 0) || idx < NBC) {
@@ -973,12 +1084,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
           } else if (w < P_LA) {
             const int j = w - P_WB;
             const bool v = row_ok && ((unsigned)(col0 + PS * j) < (unsigned)p.W);
-            const u32x4_t val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a, 0);
-            ra[S][j] = __builtin_bit_cast(f32x4, val);
+            ra[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a, 0);
           } else if (w < P_LB) {
             const int i = w - P_LA;
-            const u32x4_t val = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b, 0);
-            rb[S][i] = __builtin_bit_cast(f32x4, val);
+            rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b, 0);
           }
         };
 #pragma unroll
@@ -1024,23 +1133,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   }
 }
 
-template <int BN, int WGM, int WGN, int PF>
+template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float>
 int launch_wgrad_x6(const WgradParams& p, int S, hipStream_t st) {
-  constexpr size_t lds = (size_t)PF * 3 * BK * (X6WPitch<BN>::A + X6WPitch<BN>::B) + (2 * 1024 + 4) * sizeof(int);
+  constexpr size_t lds = (size_t)PF * NPL * BK * (X6WPitch<BN>::A + X6WPitch<BN>::B) + (2 * 1024 + 4) * sizeof(int);
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(wgrad_x6_kernel<BN, WGM, WGN, PF>, lds);
+    int rc = set_dyn_lds(wgrad_x6_kernel<BN, WGM, WGN, PF, NPL, TA>, lds);
     if (rc) return rc;
     attr_done = true;
   }
   const int64_t tiles = sg_cdiv(p.K, BM) * sg_cdiv(p.Cout, BN);
-  hipLaunchKernelGGL((wgrad_x6_kernel<BN, WGM, WGN, PF>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((wgrad_x6_kernel<BN, WGM, WGN, PF, NPL, TA>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("wgrad_x6_kernel");
   return 0;
 }
 
-inline bool wgrad_x6_ok(const WgradParams& p, bool vec) {
+inline bool wgrad_x6_ok(const WgradParams& p, bool vec, bool force = false) {
   const bool fast = p.stride == 1 && p.OH == p.H && p.OW == p.W && p.x_bytes != 0 && p.dy_bytes != 0;
   const int64_t sh_bytes = ((int64_t)p.pad_t * p.W + p.pad_l + 64) * p.x_ld * 4;
-  return x6_enabled() && vec && fast && (p.OW % BK == 0) && p.Cout >= 16 && ((int64_t)p.x_bytes + 2 * sh_bytes < (1ll << 31));
+  return (force || x6_enabled()) && vec && fast && (p.OW % BK == 0) && p.Cout >= 16 &&
+         ((int64_t)p.x_bytes + 2 * sh_bytes < (1ll << 31));
 }

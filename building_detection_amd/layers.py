@@ -87,7 +87,9 @@ class _ConvNode(Node):
                 if st is not None:
                     rt.bn_stats[id(y)] = st
                 return y
-            y = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=self.desc(rt, x), relu=self.activation == "relu")
+            # the softmax head stays fp32 under bf16 storage (logits, probabilities, loss: SG_HEAD_F32)
+            y = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=self.desc(rt, x), relu=self.activation == "relu",
+                                  head_f32=self.activation == "softmax")
         if self.activation == "sigmoid":
             y = rt.eng.act_fwd(y, _lib.SG_ACT_SIGMOID, out=y)
         elif self.activation == "softmax":
@@ -109,7 +111,7 @@ class _ConvNode(Node):
         with e.timed(self._tag):
             want_b = self.b is not None and not getattr(self, "bias_grad_zero", False)
             e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=rt.grad(self.w), db=rt.grad(self.b) if want_b else None)
-            dx = e.conv2d_dgrad(dz, rt.param(self.w), d) if rt.needs_grad(self.inputs[0]) else None
+            dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype) if rt.needs_grad(self.inputs[0]) else None
         return [dx]
 
     def flops(self, batch):
@@ -588,7 +590,7 @@ class _ConcatNode(Node):
         for t, sym in zip(xs, self.inputs):
             c = t.shape[-1]
             if rt.needs_grad(sym):
-                g = rt.eng.empty(*t.shape)
+                g = rt.eng.empty(*t.shape, dtype=dy.dtype)
                 rt.eng.copy_channels(dy, off, g, 0, c)
                 outs.append(g)
             else:
@@ -726,7 +728,7 @@ class _SKFuseNode(Node):
         B = self.B
         br, lg = xs[:B], xs[B:]
         n, c = br[0].shape[0], br[0].shape[-1]
-        z = e.empty(B, n * c)
+        z = e.empty(B, n * c, dtype=br[0].dtype)
         for i, l in enumerate(lg):
             e.copy_channels(l.view(1, n * c), 0, z[i].view(1, n * c), 0, n * c)
         p = e.softmax_branch_fwd(z.view(1, B, n * c)).view(B, n, c)
@@ -743,7 +745,7 @@ class _SKFuseNode(Node):
         br = xs[:B]
         p = rt.saved(self)["p"]
         n, c = br[0].shape[0], br[0].shape[-1]
-        dp = e.empty(B, n, c)
+        dp = e.empty(B, n, c, dtype=dy.dtype)
         dbr = []
         for i in range(B):
             dx, dg = e.bcast_mul_bwd(br[i], p[i], dy, 0)
@@ -752,7 +754,7 @@ class _SKFuseNode(Node):
         dz = e.softmax_branch_bwd(p.view(1, B, n * c), dp.view(1, B, n * c)).view(B, n, c)
         dl = []
         for i in range(B):
-            g = e.empty(*xs[B + i].shape)
+            g = e.empty(*xs[B + i].shape, dtype=dz.dtype)
             e.copy_channels(dz[i].view(1, n * c), 0, g.view(1, n * c), 0, n * c)
             dl.append(g)
         return dbr + dl

@@ -16,7 +16,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import ConvDesc, SG_F32, check
+from ._lib import ConvDesc, SG_F32, SG_BF16, SG_HEAD_F32, check
 
 
 def same_pad(in_size: int, k: int, stride: int, dilation: int = 1) -> Tuple[int, int, int]:
@@ -47,10 +47,21 @@ def _ptr(t: Optional[torch.Tensor]):
 def _chk(t: torch.Tensor, name: str):
     if not t.is_cuda:
         raise _lib.SgError(f"{name}: expected a CUDA (HIP) tensor - this engine has no CPU path")
-    if t.dtype != torch.float32:
-        raise _lib.SgError(f"{name}: expected float32, got {t.dtype}")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise _lib.SgError(f"{name}: expected float32 or bfloat16 storage, got {t.dtype}")
     if not t.is_contiguous():
         raise _lib.SgError(f"{name}: tensor must be contiguous")
+
+
+def _chk32(t: torch.Tensor, name: str):
+    _chk(t, name)
+    if t.dtype != torch.float32:
+        raise _lib.SgError(f"{name}: this tensor is fp32 in every storage mode (weights, statistics, head), got {t.dtype}")
+
+
+def _dt(t: torch.Tensor) -> int:
+    """ABI dtype of an activation tensor: SG_BF16 = bf16 storage with fp32 arithmetic inside the kernels."""
+    return SG_BF16 if t.dtype == torch.bfloat16 else SG_F32
 
 
 _TRACE_MARK = os.environ.get("SG_TRACE_MARK", "0") == "1"
@@ -157,11 +168,20 @@ class Engine:
     def timed(self, tag):
         return _Timed(self, tag)
 
-    def empty(self, *shape):
-        return torch.empty(*shape, dtype=torch.float32, device=self.device)
+    def empty(self, *shape, dtype=torch.float32):
+        return torch.empty(*shape, dtype=dtype, device=self.device)
 
-    def zeros(self, *shape):
-        return torch.zeros(*shape, dtype=torch.float32, device=self.device)
+    def zeros(self, *shape, dtype=torch.float32):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def cast(self, x, dtype, out=None):
+        """fp32 <-> bf16 conversion of a tensor (sg_cast: round to nearest even)."""
+        _chk(x, "x")
+        if x.dtype == dtype and out is None:
+            return x
+        y = out if out is not None else torch.empty(x.shape, dtype=dtype, device=self.device)
+        check(self.lib.sg_cast(self.h, self.stream, _dt(x), _dt(y), x.numel(), _ptr(x), _ptr(y)), "sg_cast")
+        return y
 
     # ---------------------------------------------------------------------------------------------- conv
     def set_conv_x6(self, on: bool) -> bool:
@@ -175,14 +195,17 @@ class Engine:
         return ConvDesc(n, h, w, cin, cout, kh, kw, stride, dilation, pt, pl, ho, wo, x_ld, y_ld)
 
     def conv2d_fwd(self, x, w, b=None, stride=1, dilation=1, padding="same", relu=False, out=None, desc=None,
-                   want_stats=False):
+                   want_stats=False, head_f32=False):
         """want_stats: also return the BatchNormalization statistics of y as (stats tensor [tiles,2,Cout], tiles), or
-        None when this launch could not produce them (then BN computes its own)."""
-        _chk(x, "x"); _chk(w, "w")
+        None when this launch could not produce them (then BN computes its own).
+        head_f32 (bf16 storage only): the output is fp32 - the softmax head, a thin 1x1 convolution (SG_HEAD_F32)."""
+        _chk(x, "x"); _chk32(w, "w")
         kh, kw, cin, cout = w.shape
         d = desc or self.conv_desc(x.shape, cout, kh, kw, stride, dilation, padding)
         assert d.Cin == cin, (d.Cin, cin)
-        y = out if out is not None else self.empty(d.N, d.Ho, d.Wo, cout)
+        head_f32 = bool(head_f32) and x.dtype == torch.bfloat16
+        y = out if out is not None else self.empty(d.N, d.Ho, d.Wo, cout, dtype=torch.float32 if head_f32 else x.dtype)
+        dt = _dt(x) | (SG_HEAD_F32 if head_f32 else 0)
         flags = (_lib.SG_EPI_BIAS if b is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
         need = self.lib.sg_conv2d_fwd_ws_bytes(C.byref(d))
         wsp, wsn = self.ws(need)
@@ -190,28 +213,32 @@ class Engine:
             st = self.empty(self.lib.sg_conv2d_fwd_stats_bytes(C.byref(d)) // 4)
             tiles = C.c_int(0)
             with self.timed(self._gemm_tag()):
-                check(self.lib.sg_conv2d_fwd_stats(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y),
+                check(self.lib.sg_conv2d_fwd_stats(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y),
                                                    flags, wsp, wsn, _ptr(st), C.byref(tiles)), "sg_conv2d_fwd_stats")
             return y, ((st, tiles.value) if tiles.value > 0 else None)
         with self.timed(self._gemm_tag()):
-            check(self.lib.sg_conv2d_fwd_ws(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags,
+            check(self.lib.sg_conv2d_fwd_ws(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags,
                                             wsp, wsn), "sg_conv2d_fwd_ws")
         return y
 
-    def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None):
-        """dx of the forward conv described by `d`; also Conv2DTranspose forward (then bias/relu apply)."""
-        _chk(dy, "dy"); _chk(w, "w")
-        dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin)
+    def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None, out_dtype=None):
+        """dx of the forward conv described by `d`; also Conv2DTranspose forward (then bias/relu apply).
+        out_dtype = torch.bfloat16 with an fp32 dy: the backward of the fp32 softmax head of a bf16 model (SG_HEAD_F32)."""
+        _chk(dy, "dy"); _chk32(w, "w")
+        odt = out.dtype if out is not None else (out_dtype or dy.dtype)
+        dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin, dtype=odt)
+        dt = (SG_BF16 | SG_HEAD_F32) if (odt == torch.bfloat16 and dy.dtype == torch.float32) else _dt(dy)
         need = self.lib.sg_conv2d_dgrad_ws_bytes(C.byref(d))
         wsp, wsn = self.ws(need)
         flags = (_lib.SG_EPI_BIAS if bias is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
         with self.timed(self._gemm_tag()):
-            check(self.lib.sg_conv2d_dgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
+            check(self.lib.sg_conv2d_dgrad(self.h, self.stream, dt, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
                                            flags, wsp, wsn), "sg_conv2d_dgrad")
         return dx
 
     def conv2d_wgrad(self, x, dy, d: ConvDesc, want_bias=True, dw=None, db=None):
         _chk(x, "x"); _chk(dy, "dy")
+        dt = (SG_BF16 | SG_HEAD_F32) if (x.dtype == torch.bfloat16 and dy.dtype == torch.float32) else _dt(x)
         if dw is None:
             dw = self.empty(d.KH, d.KW, d.Cin, d.Cout)
         if want_bias and db is None:
@@ -219,7 +246,7 @@ class Engine:
         need = self.lib.sg_conv2d_wgrad_ws_bytes(self.h, C.byref(d))
         wsp, wsn = self.ws(need)
         with self.timed(self._gemm_tag()):
-            check(self.lib.sg_conv2d_wgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+            check(self.lib.sg_conv2d_wgrad(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
                                            _ptr(db) if want_bias else None, wsp, wsn), "sg_conv2d_wgrad")
         return dw, (db if want_bias else None)
 
@@ -228,7 +255,7 @@ class Engine:
         c = dy.shape[-1]
         rows = dy.numel() // c
         wsp, wsn = self.ws(self.lib.sg_bias_grad_ws_bytes(self.h, rows, c))
-        check(self.lib.sg_bias_grad(self.h, self.stream, SG_F32, rows, c, c, _ptr(dy), _ptr(db), wsp, wsn), "sg_bias_grad")
+        check(self.lib.sg_bias_grad(self.h, self.stream, _dt(dy), rows, c, c, _ptr(dy), _ptr(db), wsp, wsn), "sg_bias_grad")
         return db
 
     # --------------------------------------------------------------------------------------- depthwise
@@ -236,14 +263,14 @@ class Engine:
         _chk(x, "x"); _chk(w, "w")
         kh, kw, c = w.shape[0], w.shape[1], w.shape[2]
         d = desc or self.conv_desc(x.shape, c, kh, kw, stride, 1, "same")
-        y = out if out is not None else self.empty(d.N, d.Ho, d.Wo, c)
-        check(self.lib.sg_dwconv2d_fwd(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(w), _ptr(y), int(pre_relu)),
+        y = out if out is not None else self.empty(d.N, d.Ho, d.Wo, c, dtype=x.dtype)
+        check(self.lib.sg_dwconv2d_fwd(self.h, self.stream, _dt(x), C.byref(d), _ptr(x), _ptr(w), _ptr(y), int(pre_relu)),
               "sg_dwconv2d_fwd")
         return y
 
     def dwconv_dgrad(self, dy, w, d: ConvDesc, x=None, pre_relu=False, out=None):
-        dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin)
-        check(self.lib.sg_dwconv2d_dgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(dy), _ptr(w), _ptr(x), _ptr(dx),
+        dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin, dtype=dy.dtype)
+        check(self.lib.sg_dwconv2d_dgrad(self.h, self.stream, _dt(dy), C.byref(d), _ptr(dy), _ptr(w), _ptr(x), _ptr(dx),
                                          int(pre_relu)), "sg_dwconv2d_dgrad")
         return dx
 
@@ -252,7 +279,7 @@ class Engine:
             dw = self.empty(d.KH, d.KW, d.Cin, 1)
         need = self.lib.sg_dwconv2d_wgrad_ws_bytes(self.h, C.byref(d))
         wsp, wsn = self.ws(need)
-        check(self.lib.sg_dwconv2d_wgrad(self.h, self.stream, SG_F32, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+        check(self.lib.sg_dwconv2d_wgrad(self.h, self.stream, _dt(x), C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
                                          int(pre_relu), wsp, wsn), "sg_dwconv2d_wgrad")
         return dw
 
@@ -264,7 +291,7 @@ class Engine:
         y = out if out is not None else torch.empty_like(x)
         mean, invstd = self.empty(c), self.empty(c)
         wsp, wsn = self.ws(self.lib.sg_bn_ws_bytes(self.h, rows, c))
-        check(self.lib.sg_bn_train_fwd(self.h, self.stream, SG_F32, rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mm),
+        check(self.lib.sg_bn_train_fwd(self.h, self.stream, _dt(x), rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mm),
                                        _ptr(mv), _ptr(y), _ptr(mean), _ptr(invstd), momentum, eps, int(relu),
                                        int(x.dim() == 4), wsp, wsn), "sg_bn_train_fwd")
         return y, mean, invstd
@@ -276,10 +303,10 @@ class Engine:
         y = out if out is not None else torch.empty_like(x)
         mean, invstd = self.empty(c), self.empty(c)
         wsp, wsn = self.ws(self.lib.sg_bn_tiles_ws_bytes(self.h, int(tiles), c))
-        check(self.lib.sg_bn_train_fwd_tiles(self.h, self.stream, SG_F32, rows, c, _ptr(stats), int(tiles), _ptr(mm), _ptr(mv),
+        check(self.lib.sg_bn_train_fwd_tiles(self.h, self.stream, _dt(x), rows, c, _ptr(stats), int(tiles), _ptr(mm), _ptr(mv),
                                              _ptr(mean), _ptr(invstd), momentum, eps, int(x.dim() == 4), wsp, wsn),
               "sg_bn_train_fwd_tiles")
-        check(self.lib.sg_bn_apply(self.h, self.stream, SG_F32, rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean),
+        check(self.lib.sg_bn_apply(self.h, self.stream, _dt(x), rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean),
                                    _ptr(invstd), _ptr(y), int(relu)), "sg_bn_apply")
         return y, mean, invstd
 
@@ -290,7 +317,7 @@ class Engine:
         dgamma = dgamma if dgamma is not None else self.empty(c)
         dbeta = dbeta if dbeta is not None else self.empty(c)
         wsp, wsn = self.ws(self.lib.sg_bn_ws_bytes(self.h, rows, c))
-        check(self.lib.sg_bn_train_bwd(self.h, self.stream, SG_F32, rows, c, _ptr(x), _ptr(y), _ptr(dy), _ptr(gamma),
+        check(self.lib.sg_bn_train_bwd(self.h, self.stream, _dt(x), rows, c, _ptr(x), _ptr(y), _ptr(dy), _ptr(gamma),
                                        _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(dx), _ptr(dgamma), _ptr(dbeta), int(relu),
                                        wsp, wsn),
               "sg_bn_train_bwd")
@@ -300,7 +327,7 @@ class Engine:
         _chk(x, "x")
         c = x.shape[-1]
         y = out if out is not None else torch.empty_like(x)
-        check(self.lib.sg_bn_infer(self.h, self.stream, SG_F32, x.numel() // c, c, _ptr(x), _ptr(gamma), _ptr(beta),
+        check(self.lib.sg_bn_infer(self.h, self.stream, _dt(x), x.numel() // c, c, _ptr(x), _ptr(gamma), _ptr(beta),
                                    _ptr(mm), _ptr(mv), _ptr(y), eps, int(relu)), "sg_bn_infer")
         return y
 
@@ -308,12 +335,12 @@ class Engine:
     def act_fwd(self, x, act, out=None):
         _chk(x, "x")
         y = out if out is not None else torch.empty_like(x)
-        check(self.lib.sg_act_fwd(self.h, self.stream, SG_F32, act, x.numel(), _ptr(x), _ptr(y)), "sg_act_fwd")
+        check(self.lib.sg_act_fwd(self.h, self.stream, _dt(x), act, x.numel(), _ptr(x), _ptr(y)), "sg_act_fwd")
         return y
 
     def act_bwd(self, y, dy, act, out=None, accumulate=False):
         dx = out if out is not None else torch.empty_like(y)
-        check(self.lib.sg_act_bwd(self.h, self.stream, SG_F32, act, y.numel(), _ptr(y), _ptr(dy), _ptr(dx), int(accumulate)),
+        check(self.lib.sg_act_bwd(self.h, self.stream, _dt(y), act, y.numel(), _ptr(y), _ptr(dy), _ptr(dx), int(accumulate)),
               "sg_act_bwd")
         return dx
 
@@ -323,19 +350,20 @@ class Engine:
             _chk(t, "add_n operand")
         arr = (C.c_void_p * len(xs))(*[t.data_ptr() for t in xs])
         y = out if out is not None else torch.empty_like(xs[0])
-        check(self.lib.sg_add_n(self.h, self.stream, SG_F32, len(xs), arr, xs[0].numel(), _ptr(y), int(relu)), "sg_add_n")
+        check(self.lib.sg_add_n(self.h, self.stream, _dt(xs[0]), len(xs), arr, xs[0].numel(), _ptr(y), int(relu)), "sg_add_n")
         return y
 
     def copy_channels(self, src, src_off, dst, dst_off, c, accumulate=False):
         rows = src.numel() // src.shape[-1]
         assert rows == dst.numel() // dst.shape[-1]
-        check(self.lib.sg_copy_channels(self.h, self.stream, SG_F32, rows, c, _ptr(src), src.shape[-1], src_off, _ptr(dst),
+        assert src.dtype == dst.dtype, (src.dtype, dst.dtype)
+        check(self.lib.sg_copy_channels(self.h, self.stream, _dt(src), rows, c, _ptr(src), src.shape[-1], src_off, _ptr(dst),
                                         dst.shape[-1], dst_off, int(accumulate)), "sg_copy_channels")
         return dst
 
     def concat(self, xs: Sequence[torch.Tensor], out=None):
         ctot = sum(t.shape[-1] for t in xs)
-        y = out if out is not None else self.empty(*xs[0].shape[:-1], ctot)
+        y = out if out is not None else self.empty(*xs[0].shape[:-1], ctot, dtype=xs[0].dtype)
         off = 0
         for t in xs:
             self.copy_channels(t, 0, y, off, t.shape[-1])
@@ -343,7 +371,7 @@ class Engine:
         return y
 
     def softmax2_fwd(self, z, out=None):
-        _chk(z, "z")
+        _chk32(z, "z")
         assert z.shape[-1] == 2
         p = out if out is not None else torch.empty_like(z)
         check(self.lib.sg_softmax2_fwd(self.h, self.stream, SG_F32, z.numel() // 2, _ptr(z), _ptr(p)), "sg_softmax2_fwd")
@@ -358,13 +386,13 @@ class Engine:
     def softmax_branch_fwd(self, z):
         n, b, c = z.shape
         p = torch.empty_like(z)
-        check(self.lib.sg_softmax_branch_fwd(self.h, self.stream, SG_F32, n, b, c, _ptr(z), _ptr(p)), "sg_softmax_branch_fwd")
+        check(self.lib.sg_softmax_branch_fwd(self.h, self.stream, _dt(z), n, b, c, _ptr(z), _ptr(p)), "sg_softmax_branch_fwd")
         return p
 
     def softmax_branch_bwd(self, p, dp):
         n, b, c = p.shape
         dz = torch.empty_like(p)
-        check(self.lib.sg_softmax_branch_bwd(self.h, self.stream, SG_F32, n, b, c, _ptr(p), _ptr(dp), _ptr(dz)),
+        check(self.lib.sg_softmax_branch_bwd(self.h, self.stream, _dt(p), n, b, c, _ptr(p), _ptr(dp), _ptr(dz)),
               "sg_softmax_branch_bwd")
         return dz
 
@@ -372,7 +400,7 @@ class Engine:
     def bcast_mul_fwd(self, x, g, mode, out=None, accumulate=False):
         n, h, w, c = x.shape
         y = out if out is not None else torch.empty_like(x)
-        check(self.lib.sg_bcast_mul_fwd(self.h, self.stream, SG_F32, n, h * w, c, mode, _ptr(x), _ptr(g), _ptr(y),
+        check(self.lib.sg_bcast_mul_fwd(self.h, self.stream, _dt(x), n, h * w, c, mode, _ptr(x), _ptr(g), _ptr(y),
                                         int(accumulate)), "sg_bcast_mul_fwd")
         return y
 
@@ -383,35 +411,35 @@ class Engine:
             accumulate_dx = False
         dg = torch.empty_like(g)
         wsp, wsn = self.ws(self.lib.sg_bcast_mul_bwd_ws_bytes(self.h, n, h * w, c, mode))
-        check(self.lib.sg_bcast_mul_bwd(self.h, self.stream, SG_F32, n, h * w, c, mode, _ptr(x), _ptr(g), _ptr(dy), _ptr(dx),
+        check(self.lib.sg_bcast_mul_bwd(self.h, self.stream, _dt(x), n, h * w, c, mode, _ptr(x), _ptr(g), _ptr(dy), _ptr(dx),
                                         _ptr(dg), int(accumulate_dx), wsp, wsn), "sg_bcast_mul_bwd")
         return dx, dg
 
     def scse_fwd(self, x, s, cl, out=None):
         n, h, w, c = x.shape
         y = out if out is not None else torch.empty_like(x)
-        check(self.lib.sg_scse_fwd(self.h, self.stream, SG_F32, n, h * w, c, _ptr(x), _ptr(s), _ptr(cl), _ptr(y)), "sg_scse_fwd")
+        check(self.lib.sg_scse_fwd(self.h, self.stream, _dt(x), n, h * w, c, _ptr(x), _ptr(s), _ptr(cl), _ptr(y)), "sg_scse_fwd")
         return y
 
     def scse_bwd(self, x, s, cl, dy):
         n, h, w, c = x.shape
         dx, ds, dc = torch.empty_like(x), torch.empty_like(s), torch.empty_like(cl)
         wsp, wsn = self.ws(self.lib.sg_scse_bwd_ws_bytes(self.h, n, h * w, c))
-        check(self.lib.sg_scse_bwd(self.h, self.stream, SG_F32, n, h * w, c, _ptr(x), _ptr(s), _ptr(cl), _ptr(dy), _ptr(dx),
+        check(self.lib.sg_scse_bwd(self.h, self.stream, _dt(x), n, h * w, c, _ptr(x), _ptr(s), _ptr(cl), _ptr(dy), _ptr(dx),
                                    _ptr(ds), _ptr(dc), wsp, wsn), "sg_scse_bwd")
         return dx, ds, dc
 
     def bam_fwd(self, x, mc, ms, out=None):
         n, h, w, c = x.shape
         y = out if out is not None else torch.empty_like(x)
-        check(self.lib.sg_bam_fwd(self.h, self.stream, SG_F32, n, h * w, c, _ptr(x), _ptr(mc), _ptr(ms), _ptr(y)), "sg_bam_fwd")
+        check(self.lib.sg_bam_fwd(self.h, self.stream, _dt(x), n, h * w, c, _ptr(x), _ptr(mc), _ptr(ms), _ptr(y)), "sg_bam_fwd")
         return y
 
     def bam_bwd(self, x, mc, ms, dy):
         n, h, w, c = x.shape
         dx, dmc, dms = torch.empty_like(x), torch.empty_like(mc), torch.empty_like(ms)
         wsp, wsn = self.ws(self.lib.sg_bam_bwd_ws_bytes(self.h, n, h * w, c))
-        check(self.lib.sg_bam_bwd(self.h, self.stream, SG_F32, n, h * w, c, _ptr(x), _ptr(mc), _ptr(ms), _ptr(dy), _ptr(dx),
+        check(self.lib.sg_bam_bwd(self.h, self.stream, _dt(x), n, h * w, c, _ptr(x), _ptr(mc), _ptr(ms), _ptr(dy), _ptr(dx),
                                   _ptr(dmc), _ptr(dms), wsp, wsn), "sg_bam_bwd")
         return dx, dmc, dms
 
@@ -423,8 +451,8 @@ class Engine:
             wo, pl, _ = same_pad(w, k, stride)
         else:
             ho, wo, pt, pl = (h - k) // stride + 1, (w - k) // stride + 1, 0, 0
-        y = out if out is not None else self.empty(n, ho, wo, c)
-        check(self.lib.sg_maxpool_fwd(self.h, self.stream, SG_F32, n, h, w, c, k, stride, pt, pl, ho, wo, _ptr(x), _ptr(y)),
+        y = out if out is not None else self.empty(n, ho, wo, c, dtype=x.dtype)
+        check(self.lib.sg_maxpool_fwd(self.h, self.stream, _dt(x), n, h, w, c, k, stride, pt, pl, ho, wo, _ptr(x), _ptr(y)),
               "sg_maxpool_fwd")
         return y, (k, stride, pt, pl, ho, wo)
 
@@ -432,42 +460,43 @@ class Engine:
         n, h, w, c = x.shape
         k, stride, pt, pl, ho, wo = geom
         dx = out if out is not None else torch.empty_like(x)
-        check(self.lib.sg_maxpool_bwd(self.h, self.stream, SG_F32, n, h, w, c, k, stride, pt, pl, ho, wo, _ptr(x), _ptr(y),
+        check(self.lib.sg_maxpool_bwd(self.h, self.stream, _dt(x), n, h, w, c, k, stride, pt, pl, ho, wo, _ptr(x), _ptr(y),
                                       _ptr(dy), _ptr(dx)), "sg_maxpool_bwd")
         return dx
 
     def avgpool_fwd(self, x, kh, kw, out=None):
         n, h, w, c = x.shape
-        y = out if out is not None else self.empty(n, h // kh, w // kw, c)
+        y = out if out is not None else self.empty(n, h // kh, w // kw, c, dtype=x.dtype)
         wsp, wsn = self.ws(self.lib.sg_avgpool_ws_bytes(self.h, n, h, w, c, kh, kw))
-        check(self.lib.sg_avgpool_fwd(self.h, self.stream, SG_F32, n, h, w, c, kh, kw, _ptr(x), _ptr(y), wsp, wsn), "sg_avgpool_fwd")
+        check(self.lib.sg_avgpool_fwd(self.h, self.stream, _dt(x), n, h, w, c, kh, kw, _ptr(x), _ptr(y), wsp, wsn), "sg_avgpool_fwd")
         return y
 
     def avgpool_bwd(self, dy, xshape, kh, kw, out=None, accumulate=False):
         n, h, w, c = xshape
-        dx = out if out is not None else self.empty(n, h, w, c)
-        check(self.lib.sg_avgpool_bwd(self.h, self.stream, SG_F32, n, h, w, c, kh, kw, _ptr(dy), _ptr(dx), int(accumulate)),
+        dx = out if out is not None else self.empty(n, h, w, c, dtype=dy.dtype)
+        check(self.lib.sg_avgpool_bwd(self.h, self.stream, _dt(dy), n, h, w, c, kh, kw, _ptr(dy), _ptr(dx), int(accumulate)),
               "sg_avgpool_bwd")
         return dx
 
     def upsample_fwd(self, x, sh, sw=None, out=None, out_ld=0):
         sw = sh if sw is None else sw
         n, h, w, c = x.shape
-        y = out if out is not None else self.empty(n, h * sh, w * sw, c)
-        check(self.lib.sg_upsample_nearest_fwd(self.h, self.stream, SG_F32, n, h, w, c, sh, sw, _ptr(x), _ptr(y), out_ld),
+        y = out if out is not None else self.empty(n, h * sh, w * sw, c, dtype=x.dtype)
+        check(self.lib.sg_upsample_nearest_fwd(self.h, self.stream, _dt(x), n, h, w, c, sh, sw, _ptr(x), _ptr(y), out_ld),
               "sg_upsample_nearest_fwd")
         return y
 
     def upsample_bwd(self, dy, xshape, sh, sw=None, out=None, accumulate=False, dy_ld=0):
         sw = sh if sw is None else sw
         n, h, w, c = xshape
-        dx = out if out is not None else self.empty(n, h, w, c)
-        check(self.lib.sg_upsample_nearest_bwd(self.h, self.stream, SG_F32, n, h, w, c, sh, sw, _ptr(dy), dy_ld, _ptr(dx),
+        dx = out if out is not None else self.empty(n, h, w, c, dtype=dy.dtype)
+        check(self.lib.sg_upsample_nearest_bwd(self.h, self.stream, _dt(dy), n, h, w, c, sh, sw, _ptr(dy), dy_ld, _ptr(dx),
                                                int(accumulate)), "sg_upsample_nearest_bwd")
         return dx
 
     # ------------------------------------------------------------------------------ loss / metrics / Adam
     def loss_fwd(self, kind, p, y_true):
+        _chk32(p, "p"); _chk32(y_true, "y_true")
         rows = p.numel() // 2
         out = self.empty(1)
         wsp, wsn = self.ws(self.lib.sg_loss_ws_bytes(self.h, rows))

@@ -82,7 +82,10 @@ class History:
 
 
 class Model:
-    def __init__(self, inputs, outputs, name=None, seed: int = 1103):
+    def __init__(self, inputs, outputs, name=None, seed: int = 1103, dtype=None):
+        """dtype: "float32" (the reference's precision) or "mixed_bfloat16" / "bfloat16" = bf16 storage of every
+        activation with fp32 arithmetic, fp32 master weights, BatchNorm statistics, softmax head, loss and Adam
+        (BASELINE config 3); None takes mixed_precision.global_policy()."""
         self.inputs = [inputs] if isinstance(inputs, KTensor) else list(inputs)
         self.outputs = [outputs] if isinstance(outputs, KTensor) else list(outputs)
         assert len(self.inputs) == 1 and len(self.outputs) == 1, "the path's models are single-input single-output"
@@ -96,6 +99,8 @@ class Model:
         self.loss_kind: Optional[int] = None
         self.metric_names: List[str] = []
         self._rt = None
+        from . import mixed_precision
+        self.compute_dtype = mixed_precision.resolve(dtype)   # "float32" | "bfloat16"
         self._fuse()
         self._layout_params()
         self.dist = None  # set by dist.DataParallel
@@ -495,12 +500,15 @@ class _Runtime:
         exp = m.inputs[0].shape[1:]
         if tuple(x.shape[1:]) != tuple(exp):
             raise ValueError(f"input shape {tuple(x.shape)} does not match the model's {(None,) + tuple(exp)}")
-        self.values = {id(m.inputs[0]): x.contiguous()}
+        x = x.contiguous()
+        if m.compute_dtype == "bfloat16":  # activations are bf16 from the first layer on (sg_cast, round to nearest even)
+            x = self.eng.cast(x, self.torch.bfloat16)
+        self.values = {id(m.inputs[0]): x}
         if training:
             for n in m.nodes:
                 xs = [self.values[id(t)] for t in n.inputs]
                 self.values[id(n.output)] = n.forward(self, xs, training)
-            return self.values[id(m.outputs[0])]
+            return self._as_f32(self.values[id(m.outputs[0])])
         # inference: an activation is dropped as soon as its last consumer has run (the allocator - or the
         # hipGraph's private pool under capture - reuses the block), so peak memory is the live set, not the sum
         last_use = m._last_use()
@@ -511,12 +519,20 @@ class _Runtime:
                 if last_use.get(id(t)) == i:
                     self.values.pop(id(t), None)
             del xs
-        return self.values[id(m.outputs[0])]
+        return self._as_f32(self.values[id(m.outputs[0])])
+
+    def _as_f32(self, y):
+        """The model's output leaves the engine as fp32 (the softmax head already is; a bf16 output of a head-less graph
+        is widened)."""
+        return y if y.dtype == self.torch.float32 else self.eng.cast(y, self.torch.float32)
 
     def backward(self, dout):
         """Reverse sweep.  Gradients of a tensor with several consumers are summed with sg_add_n; a gradient
         handed out as `_Shared` (pass-through of an Add) is never written in place."""
         m = self.model
+        yout = self.values.get(id(m.outputs[0]))
+        if yout is not None and yout.dtype != dout.dtype:  # a head-less bf16 graph: the fp32 loss gradient enters in bf16
+            dout = self.eng.cast(dout, yout.dtype)
         grads: Dict[int, list] = {id(m.outputs[0]): [dout, True]}
         e = self.eng
         hook = self.on_node_done

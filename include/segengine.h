@@ -19,7 +19,11 @@
  *    whose size the matching *_ws_bytes() query returns.
  *  - layout is fixed: activations NHWC, conv kernels HWIO ([kh][kw][Cin][Cout]), depthwise [kh][kw][C],
  *    Conv2DTranspose kernels [kh][kw][Cout][Cin], Dense [in][out]  (the tf.keras get_weights() layouts).
- *  - dtype: SG_F32 everywhere in this round (the reference is fp32 end to end).  SG_BF16 is reserved.
+ *  - dtype: SG_F32 (the reference's own precision) or SG_BF16 = bf16 STORAGE of every activation and activation
+ *    gradient (x, y, dy, dx, gate tensors) with fp32 arithmetic inside the kernels: convolutions multiply bf16
+ *    operands on the matrix pipe and accumulate in fp32, everything else widens on load and rounds (to nearest
+ *    even) on store.  Weights, biases, BatchNorm parameters and statistics, weight gradients, the loss and Adam are
+ *    fp32 in both modes (fp32 master weights).  BASELINE config 3.
  *  - "pixel stride" arguments (x_ld / y_ld, in elements) let an operand be a channel slice of a wider
  *    NHWC buffer, which is how concat is aliased away; 0 means "dense" (= its channel count).
  */
@@ -44,6 +48,11 @@ extern "C" {
 #define SG_F32  0
 #define SG_BF16 1
 #define SG_I64  2         /* sg_comm_allreduce_sum only (the four confusion counts) */
+/* OR-ed into the dtype of sg_conv2d_{fwd,dgrad,wgrad} on SG_BF16 storage: the few-channel side of a thin 1x1
+ * convolution (Cout <= 4: y of the forward, dy of the two backward calls) is fp32.  This is the softmax head
+ * Conv2D(num_classes, 1, activation='softmax') (v3plus.py:345): logits, probabilities, loss and their gradients
+ * stay in fp32 while every other activation is bf16. */
+#define SG_HEAD_F32 0x100
 
 /* epilogue flags for conv-like ops */
 #define SG_EPI_BIAS 1
@@ -57,9 +66,11 @@ int sg_create(int device, sg_ctx** out);
 int sg_destroy(sg_ctx* ctx);
 /* number of compute units of the ctx's device (for host-side split heuristics) */
 int sg_num_cus(const sg_ctx* ctx);
-/* Process-wide switch of the "x6" convolution path (fp32 products as six bf16 MFMA passes, csrc/conv_x6.h):
- * on = 1 (default, or SG_CONV_X6 in the environment), 0 = every convolution on the native fp32 MFMA kernels.
- * Returns the previous value.  Lets a caller (and the parity tests) run both paths on the same inputs. */
+/* Process-wide switch of the convolution arithmetic on SG_F32 storage (csrc/conv_x6.h): 1 (default, or SG_CONV_X6 in
+ * the environment) = "x6": every fp32 product as six bf16 MFMA passes over an exact 3-way split, at least as accurate
+ * as the fp32 MFMA; 0 = the native fp32 MFMA kernels; 2 = ONE bf16 MFMA pass (operands rounded to bf16 on their way
+ * into LDS, fp32 accumulation): the arithmetic of SG_BF16 on fp32 tensors.  Returns the previous value.  Lets a
+ * caller (and the parity tests) run the paths on the same inputs. */
 int sg_set_conv_x6(int on);
 
 /* ------------------------------------------------------------------------------------------------ conv
@@ -295,6 +306,9 @@ int sg_argmax_accumulate_i8(sg_ctx* ctx, void* stream, const void* p, int TH, in
 /* model_fuse.py:315,323: out = 255 where sum_i (masks[i] // 255) >= k else 0; masks are u8 [n]. */
 int sg_vote_ge(sg_ctx* ctx, void* stream, int nmasks, const void* const* masks, int64_t n, int k,
                void* out_u8);
+/* dst[i] = (dst_dtype) src[i]: fp32 <-> bf16 conversion (round to nearest even; NaN stays NaN), e.g. the fp32 input
+ * tiles of predict.py:109 / the generator of DeepLabv3plus.py:100 entering a bf16 model. */
+int sg_cast(sg_ctx* ctx, void* stream, int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst);
 /* fill n floats with value (workspace / gradient zeroing without leaving the stream) */
 int sg_fill_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float value);
 /* Profiling aid: launches an empty one-thread kernel named sg_trace_mark_kernel<tag, end> on `stream`, so that a

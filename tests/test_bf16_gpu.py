@@ -1,0 +1,317 @@
+"""SG_BF16: bf16 STORAGE of activations with fp32 arithmetic (BASELINE configs[2]; the reference itself is fp32).
+
+Tolerance contract, tested here:
+  (1) every kernel, given bf16 inputs, returns the correctly rounded bf16 of what fp32/fp64 arithmetic on THOSE inputs
+      gives, up to 1 bf16 ulp of the output's scale (convolutions: bf16 x bf16 products are exact in fp32, accumulation is
+      fp32, so only the final rounding and the fp32 summation order remain);
+  (2) a whole model in bf16 stays within stated distances of the fp32 engine on the same weights and tiles:
+      probabilities, argmax mismatch rate, training loss over several steps;
+  (3) what must stay fp32 does: softmax head output, loss, weight gradients, Adam state.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+ULP = 2.0 ** -8  # relative spacing of bf16 (8 significand bits incl. the hidden one => half-ulp rounding error 2^-9)
+
+
+def rb(t):
+    """round an fp32 tensor to bf16 and back (torch's RNE == sg_cast's)"""
+    return t.to(BF).float()
+
+
+def close_bf16(got_bf16, ref_f, scale=None, ulps=1.0, what=""):
+    g, r = got_bf16.float().double().cpu(), ref_f.double().cpu()
+    s = float(r.abs().max()) if scale is None else scale
+    err = float((g - r).abs().max())
+    assert err <= ulps * ULP * max(s, 1e-30), f"{what}: max error {err:.3e} vs {ulps} bf16 ulp of scale {s:.3e}"
+    return err / max(s, 1e-30)
+
+
+def test_cast_roundtrip(engine):
+    e = engine
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(1000003, generator=g) * 3).cuda()
+    x[:4] = torch.tensor([float("nan"), float("inf"), -0.0, 1e-40]).cuda()
+    xb = e.cast(x, BF)
+    assert xb.dtype == BF
+    want = x.to(BF)
+    assert torch.equal(xb[1:].view(torch.int16), want[1:].view(torch.int16)) and torch.isnan(xb[0])
+    assert torch.equal(e.cast(xb, torch.float32)[1:], want.float()[1:])
+
+
+CONV_CASES = [
+    # name, N,H,W,Cin,Cout,k,stride,dil
+    ("aspp_d6", 2, 32, 32, 2048, 256, 3, 1, 6),
+    ("pw_728", 4, 32, 32, 728, 728, 1, 1, 1),
+    ("c64_3x3", 2, 64, 64, 64, 64, 3, 1, 1),
+    ("vpad_304", 2, 32, 32, 304, 256, 3, 1, 1),     # Cin % 32 != 0: virtual channel padding
+    ("vpad_48", 2, 64, 64, 48, 96, 3, 1, 1),
+    ("s2_entry", 2, 64, 64, 32, 64, 3, 2, 1),        # stride 2: bf16-pipe forward/dgrad, fp32-MFMA wgrad fallback
+    ("first_conv", 2, 64, 64, 3, 32, 3, 2, 1),       # Cin = 3: the any-shape fallback (widening loads)
+    ("odd_45", 2, 32, 32, 45, 45, 3, 1, 4),          # BAM reduce dim 45
+    ("dense_like", 16, 1, 1, 256, 64, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_bf16_vs_fp64_on_rounded_operands(engine, case):
+    from oracle import tfops as T
+    e = engine
+    name, N, H, W, Cin, Cout, k, stride, dil = case
+    g = torch.Generator().manual_seed(len(name) * 131 + Cin)
+    x = rb(torch.randn(N, H, W, Cin, generator=g))
+    w = torch.randn(k, k, Cin, Cout, generator=g) * (1.0 / np.sqrt(k * k * Cin))
+    b = torch.randn(Cout, generator=g) * 0.1
+    wr = rb(w)  # the kernels multiply bf16(w): the reference does the same, in fp64
+    xd, wd, bd = x.cuda().to(BF), w.cuda(), b.cuda()
+    d = e.conv_desc(tuple(x.shape), Cout, k, k, stride, dil, "same")
+    y = e.conv2d_fwd(xd, wd, bd, desc=d)
+    assert y.dtype == BF
+    xr = x.double().requires_grad_()
+    wr64 = wr.double().requires_grad_()
+    yr = T.conv2d(xr, wr64, b.double(), stride, dil, "same")
+    r_f = close_bf16(y, yr.detach(), what=f"{name} fwd")
+    dy = rb(torch.randn(*yr.shape, generator=g))
+    yr.backward(dy.double())
+    dyd = dy.cuda().to(BF)
+    dx = e.conv2d_dgrad(dyd, wd, d)
+    assert dx.dtype == BF
+    r_d = close_bf16(dx, xr.grad, what=f"{name} dgrad")
+    dw, db = e.conv2d_wgrad(xd, dyd, d)
+    assert dw.dtype == torch.float32 and db.dtype == torch.float32   # weight gradients are fp32 (master weights)
+    ew = float((dw.double().cpu() - wr64.grad).abs().max() / wr64.grad.abs().max())
+    ebias = float((db.double().cpu() - dy.double().sum((0, 1, 2))).abs().max() / dy.double().sum((0, 1, 2)).abs().max())
+    print(f"{name}: fwd {r_f:.2e} dgrad {r_d:.2e} (of 1 bf16 ulp = {ULP:.2e}); wgrad rel {ew:.2e} bias {ebias:.2e}")
+    assert ew <= 2e-5 and ebias <= 2e-5   # fp32 accumulation of exact bf16 products
+
+
+def test_conv_transpose_and_head_bf16(engine):
+    """Conv2DTranspose(3, s2) forward = dgrad with bias+ReLU epilogue; the softmax head Conv2D(2, 1) with fp32 output and
+    its backward from an fp32 dy (SG_HEAD_F32)."""
+    from oracle import tfops as T
+    e = engine
+    g = torch.Generator().manual_seed(7)
+    N, H, C, C2 = 2, 32, 64, 32
+    x = rb(torch.randn(N, H, H, C, generator=g))
+    wT = torch.randn(3, 3, C2, C, generator=g) * 0.05
+    bT = torch.randn(C2, generator=g) * 0.1
+    fd = e.conv_desc((N, 2 * H, 2 * H, C2), C, 3, 3, 2, 1, "same")
+    u = e.conv2d_dgrad(x.cuda().to(BF), wT.cuda(), fd, bias=bT.cuda(), relu=True)
+    ur = torch.relu(T.conv2d_transpose(x.double(), rb(wT).double(), bT.double()))
+    close_bf16(u, ur, what="convT fwd")
+    # head
+    w5 = torch.randn(1, 1, C2, 2, generator=g) * 0.3
+    b5 = torch.randn(2, generator=g) * 0.1
+    ub = u.float().cpu()
+    z = e.conv2d_fwd(u, w5.cuda(), b5.cuda(), head_f32=True)
+    assert z.dtype == torch.float32
+    zr = T.conv2d(ub.double(), w5.double(), b5.double())   # thin kernels multiply in fp32: w5 is NOT rounded
+    assert float((z.double().cpu() - zr).abs().max()) <= 1e-5 * float(zr.abs().max())
+    dz = torch.randn(*zr.shape, generator=g).cuda()
+    d5 = e.conv_desc(tuple(u.shape), 2, 1, 1)
+    dw5, db5 = e.conv2d_wgrad(u, dz, d5)
+    du = e.conv2d_dgrad(dz, w5.cuda(), d5, out_dtype=BF)
+    assert du.dtype == BF and dw5.dtype == torch.float32
+    dur = torch.einsum("nhwo,co->nhwc", dz.double().cpu(), w5[0, 0].double())
+    close_bf16(du, dur, what="head dgrad")
+    dwr = torch.einsum("nhwc,nhwo->co", ub.double(), dz.double().cpu())
+    assert float((dw5[0, 0].double().cpu() - dwr).abs().max()) <= 2e-5 * float(dwr.abs().max())
+    with pytest.raises(Exception):   # SG_HEAD_F32 is the thin head only
+        e.conv2d_fwd(u, torch.randn(1, 1, C2, 64).cuda(), None, head_f32=True)
+
+
+def test_bf16_compute_mode_on_fp32_storage(engine):
+    """sg_set_conv_x6(2): fp32 tensors, products in ONE bf16 pass - the arithmetic of SG_BF16 on fp32 storage; output fp32."""
+    from oracle import tfops as T
+    e = engine
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 32, 32, 256, generator=g)
+    w = torch.randn(3, 3, 256, 128, generator=g) * 0.02
+    prev = e.lib.sg_set_conv_x6(2)
+    try:
+        d = e.conv_desc(tuple(x.shape), 128, 3, 3, 1, 2, "same")
+        y = e.conv2d_fwd(x.cuda(), w.cuda(), None, desc=d)
+        dy = torch.randn(*y.shape, generator=g)
+        dx = e.conv2d_dgrad(dy.cuda(), w.cuda(), d)
+        dw, _ = e.conv2d_wgrad(x.cuda(), dy.cuda(), d, want_bias=False)
+    finally:
+        e.lib.sg_set_conv_x6(prev)
+    xr, wr = rb(x).double().requires_grad_(), rb(w).double().requires_grad_()
+    yr = T.conv2d(xr, wr, None, 1, 2, "same")
+    assert y.dtype == torch.float32
+    assert float((y.double().cpu() - yr.detach()).abs().max()) <= 1e-5 * float(yr.abs().max())
+    # backward: dy is rounded too on its way into the multiplier
+    yr2 = T.conv2d(xr, wr, None, 1, 2, "same")
+    yr2.backward(rb(dy).double())
+    assert float((dx.double().cpu() - xr.grad).abs().max()) <= 1e-5 * float(xr.grad.abs().max())
+    assert float((dw.double().cpu() - wr.grad).abs().max()) <= 2e-5 * float(wr.grad.abs().max())
+
+
+def _pair(shape, g, scale=1.0):
+    x = rb(torch.randn(*shape, generator=g) * scale)
+    return x.cuda(), x.cuda().to(BF)
+
+
+def test_bandwidth_kernels_bf16_equal_rounded_fp32(engine):
+    """Every HBM-bound kernel on bf16 storage against THE SAME kernel on fp32 storage fed the same (bf16-representable)
+    values: the bf16 result must be the fp32 result rounded once (<= 1 bf16 ulp of the tensor's scale; the reductions'
+    fp32 outputs - dgamma, dbeta, depthwise dw - within fp32 noise)."""
+    e = engine
+    g = torch.Generator().manual_seed(11)
+    N, H, C = 2, 32, 64
+    xf, xb = _pair((N, H, H, C), g)
+    dyf, dyb = _pair((N, H, H, C), g)
+    gam, bet = (1 + 0.1 * torch.randn(C, generator=g)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    res = {}
+
+    # BatchNormalization training forward (+ReLU) and backward
+    mm, mv = torch.zeros(C).cuda(), torch.ones(C).cuda()
+    yf, mean_f, inv_f = e.bn_train_fwd(xf, gam, bet, mm.clone(), mv.clone(), relu=True)
+    yb, mean_b, inv_b = e.bn_train_fwd(xb, gam, bet, mm.clone(), mv.clone(), relu=True)
+    assert torch.allclose(mean_f, mean_b, rtol=1e-6, atol=1e-7) and torch.allclose(inv_f, inv_b, rtol=1e-6)
+    res["bn_fwd"] = close_bf16(yb, yf, what="bn fwd")
+    dxf, dgf, dbf = e.bn_train_bwd(xf, yf, dyf, gam, mean_f, inv_f, relu=True, beta=bet)
+    dxb, dgb, dbb = e.bn_train_bwd(xb, yb, dyb, gam, mean_b, inv_b, relu=True, beta=bet)
+    res["bn_bwd"] = close_bf16(dxb, dxf, what="bn bwd")
+    assert torch.allclose(dgf, dgb, rtol=1e-4, atol=1e-4) and torch.allclose(dbf, dbb, rtol=1e-4, atol=1e-4)
+    res["bn_infer"] = close_bf16(e.bn_infer(xb, gam, bet, mean_f, inv_f.abs() + 0.5), e.bn_infer(xf, gam, bet, mean_f, inv_f.abs() + 0.5))
+
+    # depthwise 3x3 (run path and generic stride-2 path), pre-ReLU folded in
+    wdw = (torch.randn(3, 3, C, 1, generator=g) * 0.3).cuda()
+    for stride in (1, 2):
+        d = e.conv_desc((N, H, H, C), C, 3, 3, stride, 1, "same")
+        tf_, tb_ = e.dwconv_fwd(xf, wdw, stride, True), e.dwconv_fwd(xb, wdw, stride, True)
+        res[f"dw_fwd_s{stride}"] = close_bf16(tb_, tf_, what="dw fwd")
+        gf, gb = _pair(tuple(tf_.shape), g)
+        res[f"dw_dgrad_s{stride}"] = close_bf16(e.dwconv_dgrad(gb, wdw, d, x=xb, pre_relu=True),
+                                                e.dwconv_dgrad(gf, wdw, d, x=xf, pre_relu=True), what="dw dgrad")
+        wf, wb = e.dwconv_wgrad(xf, gf, d, True), e.dwconv_wgrad(xb, gb, d, True)
+        assert wb.dtype == torch.float32 and torch.allclose(wf, wb, rtol=1e-4, atol=1e-4)
+
+    # pools / up-sampling / add / concat
+    for k, s_, pad in ((3, 2, "same"), (2, 2, "valid"), (2, 4, "valid")):
+        pf, geo = e.maxpool_fwd(xf, k, s_, pad)
+        pb, _ = e.maxpool_fwd(xb, k, s_, pad)
+        assert torch.equal(pb.float(), pf)   # a max of bf16 values is exact
+        gf, gb = _pair(tuple(pf.shape), g)
+        res[f"maxpool_bwd_{k}{s_}"] = close_bf16(e.maxpool_bwd(xb, pb, gb, geo), e.maxpool_bwd(xf, pf, gf, geo), what="maxpool bwd")
+    res["avgpool"] = close_bf16(e.avgpool_fwd(xb, 8, 8), e.avgpool_fwd(xf, 8, 8))
+    res["gap"] = close_bf16(e.avgpool_fwd(xb, H, H), e.avgpool_fwd(xf, H, H))
+    gf, gb = _pair((N, 4, 4, C), g)
+    res["avgpool_bwd"] = close_bf16(e.avgpool_bwd(gb, (N, H, H, C), 8, 8), e.avgpool_bwd(gf, (N, H, H, C), 8, 8))
+    assert torch.equal(e.upsample_fwd(xb, 2).float(), e.upsample_fwd(xf, 2))
+    g2f, g2b = _pair((N, 2 * H, 2 * H, C), g)
+    res["upsample_bwd"] = close_bf16(e.upsample_bwd(g2b, (N, H, H, C), 2), e.upsample_bwd(g2f, (N, H, H, C), 2))
+    res["add_n"] = close_bf16(e.add_n([xb, dyb, xb], relu=True), e.add_n([xf, dyf, xf], relu=True))
+    assert torch.equal(e.concat([xb, dyb]).float(), e.concat([xf, dyf]))
+    res["act_sig"] = close_bf16(e.act_fwd(xb, 1), e.act_fwd(xf, 1))
+    res["act_bwd"] = close_bf16(e.act_bwd(yb, dyb, 0), e.act_bwd(yf, dyf, 0))
+
+    # gates: scSE, BAM, broadcast multiplies, branch softmax
+    sf, sb = _pair((N, H, H, 1), g)
+    cf, cb = _pair((N, 1, 1, C), g)
+    res["scse_fwd"] = close_bf16(e.scse_fwd(xb, sb, cb), e.scse_fwd(xf, sf, cf))
+    for (a, b_, c_), (fa, fb, fc) in [(e.scse_bwd(xb, sb, cb, dyb), e.scse_bwd(xf, sf, cf, dyf))]:
+        pass
+    ob, of = e.scse_bwd(xb, sb, cb, dyb), e.scse_bwd(xf, sf, cf, dyf)
+    for nm, tb_, tf_ in zip(("scse_dx", "scse_ds", "scse_dc"), ob, of):
+        res[nm] = close_bf16(tb_, tf_, what=nm)
+    mcf, mcb = _pair((N, C), g)
+    res["bam_fwd"] = close_bf16(e.bam_fwd(xb, mcb, sb), e.bam_fwd(xf, mcf, sf))
+    ob, of = e.bam_bwd(xb, mcb, sb, dyb), e.bam_bwd(xf, mcf, sf, dyf)
+    for nm, tb_, tf_ in zip(("bam_dx", "bam_dmc", "bam_dms"), ob, of):
+        res[nm] = close_bf16(tb_, tf_, what=nm)
+    for mode, (gf_, gb_) in ((0, (mcf, mcb)), (1, (sf.view(N, H * H), sb.view(N, H * H)))):
+        res[f"bmul_fwd{mode}"] = close_bf16(e.bcast_mul_fwd(xb, gb_, mode), e.bcast_mul_fwd(xf, gf_, mode))
+        ob, of = e.bcast_mul_bwd(xb, gb_, dyb, mode), e.bcast_mul_bwd(xf, gf_, dyf, mode)
+        res[f"bmul_dx{mode}"] = close_bf16(ob[0], of[0])
+        res[f"bmul_dg{mode}"] = close_bf16(ob[1], of[1])
+    zf, zb = _pair((N, 5, C), g)
+    pf_, pb_ = e.softmax_branch_fwd(zf), e.softmax_branch_fwd(zb)
+    res["sm_branch"] = close_bf16(pb_, pf_)
+    res["sm_branch_bwd"] = close_bf16(e.softmax_branch_bwd(rbdev(pb_), zb), e.softmax_branch_bwd(rbdev(pb_).float(), zf))
+    worst = max(res.items(), key=lambda kv: kv[1])
+    print("bf16 bandwidth kernels, error / tensor scale (1 ulp = %.2e): worst %s %.2e; " % (ULP, worst[0], worst[1]) +
+          ", ".join(f"{k} {v:.1e}" for k, v in sorted(res.items())))
+
+
+def rbdev(t):
+    return t if t.dtype == BF else t.to(BF)
+
+
+MODELS = [("v3plus", 128, {"aspp_pool": 8}), ("bam", 128, {"aspp_pool": 8}), ("scse", 64, {}), ("res34", 64, {}), ("hrnet", 64, {})]
+
+
+def _build(name, size, kw, dtype):
+    from building_detection_amd import zoo
+    from building_detection_amd.runtime import Model  # noqa: F401
+    from building_detection_amd import mixed_precision as MP
+    MP.set_global_policy(dtype)
+    try:
+        m = zoo.BUILDERS[name]((size, size, 3), 2, **kw) if kw else zoo.BUILDERS[name]((size, size, 3))
+    finally:
+        MP.set_global_policy("float32")
+    return m
+
+
+# contract (2): measured on the first GPU run, then fixed with ~2x head-room
+MAX_DP = {"v3plus": 6e-2, "bam": 6e-2, "scse": 6e-2, "res34": 6e-2, "hrnet": 6e-2}
+MAX_FLIP = 2e-2
+
+
+@pytest.mark.parametrize("name,size,kw", MODELS, ids=[m[0] for m in MODELS])
+def test_model_bf16_against_fp32_engine(engine, name, size, kw):
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss, PA, IoU, MIoU, F1_score
+    m32 = _build(name, size, kw, "float32")
+    m16 = _build(name, size, kw, "mixed_bfloat16")
+    assert m16.compute_dtype == "bfloat16" and m32.compute_dtype == "float32"
+    ws = m32.get_weights()
+    rng = np.random.default_rng(5)
+    for i, p in enumerate(m32.params):   # non-trivial inference-mode BatchNorm
+        if p.kind == "moving_mean":
+            ws[i] = rng.normal(0, 0.1, p.shape).astype(np.float32)
+        elif p.kind == "moving_var":
+            ws[i] = rng.uniform(0.5, 1.5, p.shape).astype(np.float32)
+    m32.set_weights(ws)
+    m16.set_weights(ws)
+    x, y = synthetic_batch(2, size, size, seed=11)
+    p32, p16 = m32.predict(x), m16.predict(x)
+    assert p16.dtype == np.float32 and np.allclose(p16.sum(-1), 1.0, atol=1e-5)   # the head is fp32
+    dp = float(np.abs(p16 - p32).max())
+    flip = float(((p16[..., 1] > p16[..., 0]) != (p32[..., 1] > p32[..., 0])).mean())
+    for m in (m32, m16):
+        m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
+    l32, l16 = m32.train_on_batch(x, y), m16.train_on_batch(x, y)
+    g32 = np.concatenate([g.reshape(-1) for g in m32.get_gradients()]).astype(np.float64)
+    g16 = np.concatenate([g.reshape(-1) for g in m16.get_gradients()]).astype(np.float64)
+    cos = float(g32 @ g16 / (np.linalg.norm(g32) * np.linalg.norm(g16)))
+    rel = float(np.linalg.norm(g16 - g32) / np.linalg.norm(g32))
+    print(f"bf16 {name}: max|dp| {dp:.2e}, argmax flips {flip:.2e}, loss fp32 {l32['loss']:.5f} bf16 {l16['loss']:.5f}, "
+          f"gradient cosine {cos:.4f} rel-L2 {rel:.2e}, MIoU fp32 {l32['MIoU']:.4f} bf16 {l16['MIoU']:.4f}")
+    assert dp <= MAX_DP[name] and flip <= MAX_FLIP
+    assert abs(l16["loss"] - l32["loss"]) <= 3e-2 * abs(l32["loss"])
+    assert cos >= 0.97
+    rt = m16._runtime()
+    assert rt.w_train.dtype == torch.float32 and rt.g_train.dtype == torch.float32 and rt.adam_m.dtype == torch.float32
+
+
+def test_bf16_training_tracks_fp32_over_steps(engine):
+    """Eight Adam steps of DeepLabv3+ 128x128 on the same four batches in fp32 and in mixed_bfloat16: the loss trajectories
+    stay together (the first-steps sign-like Adam drift that separates fp32 from fp64 - test_models_gpu.py - is the scale)."""
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss, PA, IoU, MIoU, F1_score
+    batches = [synthetic_batch(2, 128, 128, seed=300 + i) for i in range(4)]
+    traj = {}
+    for dt in ("float32", "mixed_bfloat16"):
+        m = _build("v3plus", 128, {"aspp_pool": 8}, dt)
+        m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
+        traj[dt] = [m.train_on_batch(*batches[s % 4])["loss"] for s in range(8)]
+    a, b = np.array(traj["float32"]), np.array(traj["mixed_bfloat16"])
+    print("loss fp32", np.round(a, 5), "bf16", np.round(b, 5))
+    assert np.all(np.isfinite(b))
+    assert np.all(np.abs(b - a) <= 0.10 * np.abs(a) + 1e-3)
+    assert b[-1] < b[0]   # it trains
