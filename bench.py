@@ -116,6 +116,9 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="tiles per GPU (BASELINE config: 16)")
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--model", default="v3plus")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = BASELINE configs[1] (the reference's precision, default); bf16 = configs[2]: bf16 activation "
+                         "storage, one-pass bf16 MFMA products with fp32 accumulation, fp32 master weights / BN / loss / Adam")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--comm", default=os.environ.get("SG_BENCH_COMM", "sg"), choices=["sg", "torch"],
@@ -156,6 +159,9 @@ def main():
     from building_detection_amd.ops import get_engine
 
     eng = get_engine(local_rank)
+    if args.dtype == "bf16":
+        from building_detection_amd import mixed_precision
+        mixed_precision.set_global_policy("mixed_bfloat16")
     if args.model in ("v3plus", "bam"):
         model = zoo.BUILDERS[args.model]((args.size, args.size, 3), 2, aspp_pool=args.size // 16)
     else:
@@ -183,6 +189,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, _ = model.train_on_batch(xd, yd, return_device_scalars=True)
+    t_enq = time.perf_counter() - t0   # the host has queued every launch of the timed steps (the device may still be running)
     sync()
     dt = time.perf_counter() - t0
     prof = eng.profile_end()
@@ -212,15 +219,17 @@ def main():
         # fp32 operands, fp32 accumulation (csrc/conv_x6.h; accuracy >= the fp32 MFMA, profiles/r01_exp_bf16x6.txt).
         # The pipe that bounds them is therefore the bf16 one: 2500 TFLOP/s dense / 6 passes per fp32 FLOP.  With
         # SG_CONV_X6=0 they run on the fp32 MFMA (157.3 TFLOP/s) instead.
-        x6 = os.environ.get("SG_CONV_X6", "1") != "0"
-        peak = BF16_MFMA_PEAK_TFLOPS / 6.0 if x6 else FP32_MFMA_PEAK_TFLOPS
-        peak_note = ("bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMA passes per fp32 product (x6 path: fp32 in, fp32 accumulate, "
-                     "exact 3-way bf16 split); the native fp32 MFMA peak is 157.3 TFLOP/s") if x6 else "fp32 MFMA 32x32x2 dense peak"
+        b16 = args.dtype == "bf16"
+        x6 = os.environ.get("SG_CONV_X6", "1") != "0" or b16
+        peak = BF16_MFMA_PEAK_TFLOPS if b16 else (BF16_MFMA_PEAK_TFLOPS / 6.0 if x6 else FP32_MFMA_PEAK_TFLOPS)
+        peak_note = ("bf16 dense MFMA peak (one v_mfma_f32_32x32x16_bf16 pass per product, fp32 accumulation)" if b16 else
+                     ("bf16 dense MFMA peak 2500 TFLOP/s / 6 MFMA passes per fp32 product (x6 path: fp32 in, fp32 accumulate, "
+                      "exact 3-way bf16 split); the native fp32 MFMA peak is 157.3 TFLOP/s") if x6 else "fp32 MFMA 32x32x2 dense peak")
         # fabric-side bytes of the same kernel set per step, from the committed PMC passes (separate rocprofv3
         # --pmc runs of scripts/dilated_bench.py at this very configuration; scripts/pmc_traffic.py)
         traffic, traffic_note = None, "PMC passes exist for the 512x512 bs16 configuration only"
         tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-        if args.batch == 16 and args.size == 512 and os.path.exists(tj):
+        if args.batch == 16 and args.size == 512 and os.path.exists(tj) and not b16:
             with open(tj) as f:
                 tr = json.load(f)
             traffic = int(tr["set_bytes_per_step"])
@@ -245,15 +254,18 @@ def main():
             "metric": f"{args.size}x{args.size} tiles/sec fwd+bwd {LABEL.get(args.model, args.model)} (full train step: fwd+loss+bwd+Adam)",
             "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "dtype_note": "fp32 tensors, fp32 accumulation; conv products as 6 bf16 MFMA passes over an exact 3-way split" if x6 else "fp32 MFMA",
-            "config": {"workload": f"{LABEL.get(args.model, args.model)} {args.size}x{args.size} bs={args.batch}/GPU fp32, "
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if b16 else "f32", "data": "synthetic",
+            "dtype_note": ("bf16 activation storage, conv products in one bf16 MFMA pass with fp32 accumulation; fp32 master "
+                           "weights, BatchNorm statistics, softmax head, loss, weight gradients and Adam (BASELINE configs[2])") if b16
+                          else ("fp32 tensors, fp32 accumulation; conv products as 6 bf16 MFMA passes over an exact 3-way split" if x6 else "fp32 MFMA"),
+            "config": {"workload": f"{LABEL.get(args.model, args.model)} {args.size}x{args.size} bs={args.batch}/GPU {'bf16' if b16 else 'fp32'}, "
                                    f"train step, {'dp%d' % world if world > 1 else 'single GPU'}",
                        "comm": None if dist is None else ("RCCL via sg_comm_* (libsegengine C ABI)" if args.comm == "sg"
                                                           else "RCCL via torch.distributed nccl"),
                        "global_batch": world * args.batch, "model_flops_per_step_tflop": round(step_tflop, 3),
                        "step_achieved_tflops": round(step_tflop / (ms_per_step / 1e3), 2),
-                       "final_loss": float(loss.item())},
+                       "final_loss": float(loss.item()),
+                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2)},
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / peak, 4),
@@ -263,7 +275,8 @@ def main():
                          "frac_executed": None if (achieved is None or exec_ratio is None) else round(achieved * exec_ratio / peak, 4),
                          "frac_executed_note": exec_note,
                          "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": ("conv_x6_kernel / wgrad_x6_kernel" if x6 else "igemm_conv_kernel / igemm_wgrad_kernel") + " on the 6 dilated 3x3 convs (fwd+dgrad+wgrad)",
+                         "kernel": (("conv_x6_kernel<NPL=1,bf16> / wgrad_x6_kernel<NPL=1,bf16>" if b16 else "conv_x6_kernel / wgrad_x6_kernel") if x6
+                                    else "igemm_conv_kernel / igemm_wgrad_kernel") + " on the 6 dilated 3x3 convs (fwd+dgrad+wgrad)",
                          "ms_per_step": round(dil_ms, 3), "launches_per_step": prof.get("dilated_conv_launches", 0) // max(args.steps, 1)},
         }
         fam_ms = fam.get("gemm_conv", 0.0) / 2
@@ -277,6 +290,8 @@ def main():
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             try:
                 out["cpu_baseline"] = cpu_baseline(threads, 2, args.size, 2, model if args.model == "v3plus" else None)
+                if b16 and "parity" in out["cpu_baseline"]:
+                    out["cpu_baseline"]["parity"]["what"] += " (bf16 engine vs the fp32 oracle: the tolerance contract of DESIGN.md section 8, not the 1e-3 fp32 bar)"
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
         print(json.dumps(out), flush=True)

@@ -68,14 +68,14 @@ __device__ __forceinline__ int spt_of(const IgemmParams& p) { return p.C / BK; }
 // per-row source offsets and bounds flags then change only when the slab stream crosses a tap boundary (every
 // Cin/32 slabs) and a slab's gather costs a handful of adds instead of ~170 VALU/SALU instructions of
 // div/mod, bounds and 64-bit address arithmetic ahead of the first MFMA.
-template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT, typename TA = float>
+template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT, typename TA = float, typename TY = TA>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kernel(const IgemmParams p) {
   // TA = storage type of the activations x and y (bf16: widened to fp32 on load, rounded on store; the arithmetic is
   // the fp32 MFMA either way).  The buffer-addressed UT path exists for fp32 storage only: bf16 tensors that qualify
   // for it run on the bf16 matrix-pipe kernels instead (conv_x6.h), this kernel is their any-shape fallback.
   static_assert(!UT || std::is_same<TA, float>::value, "the UT gather is fp32-only");
   const TA* __restrict__ px = reinterpret_cast<const TA*>(p.x);
-  TA* __restrict__ py = reinterpret_cast<TA*>(p.y);
+  TY* __restrict__ py = reinterpret_cast<TY*>(p.y);  // TY != TA: the fp32 softmax head of a bf16 model and its backward
   constexpr int NT = 64 * WGM * WGN;        // 4 or 8 waves; two workgroups per CU => 2 or 4 waves per SIMD
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -453,7 +453,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_conv_kern
         if (cv && row < p.M) {
           float v = acc[i][j][r] + bv;
           if (do_relu) v = fmaxf(v, 0.f);
-          st1<TA>(py + (int64_t)row * p.y_ld + col, v);
+          st1<TY>(py + (int64_t)row * p.y_ld + col, v);
         }
       }
     }
@@ -509,11 +509,11 @@ struct WgradParams {
 // two CONSTANT voffsets (pixel-in-slab x channel) and tests its column against W.  No per-thread running
 // state, no div/mod, ~10 fewer VGPRs: the kernel runs at the 128-VGPR cap and the state used to spill, and a
 // spill reload inside the slab loop waits on vmcnt(0), i.e. drains the prefetch.
-template <int BN, int WGM, int WGN, int PF, bool VEC, int FAST, typename TA = float>
+template <int BN, int WGM, int WGN, int PF, bool VEC, int FAST, typename TA = float, typename TD = TA>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_kernel(const WgradParams p) {
   static_assert(FAST == 0 || std::is_same<TA, float>::value, "the buffer-addressed wgrad paths are fp32-only");
   const TA* __restrict__ px = reinterpret_cast<const TA*>(p.x);
-  const TA* __restrict__ pdy = reinterpret_cast<const TA*>(p.dy);
+  const TD* __restrict__ pdy = reinterpret_cast<const TD*>(p.dy);  // TD != TA: fp32 dy of the softmax head of a bf16 model
   constexpr int NT = 64 * WGM * WGN;
   constexpr int WM = BM / WGM, WN = BN / WGN;
   constexpr int TM = WM / 32, TN = WN / 32;
@@ -734,14 +734,14 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void igemm_wgrad_ker
       const int pp = p0 + kr, n = n0 + 4 * c4;
       if constexpr (VEC) {
         const bool v = (pp < p.P) && (n < p.Cout);
-        const f32x4 val = ld4<TA>(pdy + (v ? (int64_t)pp * p.y_ld + n : 0));
+        const f32x4 val = ld4<TD>(pdy + (v ? (int64_t)pp * p.y_ld + n : 0));
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
         rb[S][i] = v ? val : z;
       } else {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const bool v = (pp < p.P) && (n + e < p.Cout);
-          const float val = ld1<TA>(pdy + (v ? (int64_t)pp * p.y_ld + n + e : 0));
+          const float val = ld1<TD>(pdy + (v ? (int64_t)pp * p.y_ld + n + e : 0));
           rb[S][i][e] = v ? val : 0.f;
         }
       }
@@ -982,13 +982,13 @@ int conv_l2(bool x6 = false) {
   return v;
 }
 
-template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT, typename TA = float>
+template <int BN, int WGM, int WGN, int PF, bool VEC, bool UT, typename TA = float, typename TY = TA>
 int launch_igemm_ut(const IgemmParams& p, hipStream_t st) {
   // + tapinfo[64] + row_lin[NA][NT] (NA * NT = BM * BK / 4 ints)
   constexpr size_t lds = (size_t)(2 * BM * LDA + 2 * BK * BN) * sizeof(float) + 256 + (size_t)(BM * BK / 4) * sizeof(int);
   static bool attr_done = false;  // idempotent; racing threads set the same value
   if (!attr_done) {
-    int rc = set_dyn_lds(igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT, TA>, lds);
+    int rc = set_dyn_lds(igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT, TA, TY>, lds);
     if (rc) return rc;
     attr_done = true;
   }
@@ -997,7 +997,7 @@ int launch_igemm_ut(const IgemmParams& p, hipStream_t st) {
     sg_set_error("igemm: bad tile count %lld", (long long)tiles);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL((igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT, TA>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((igemm_conv_kernel<BN, WGM, WGN, PF, VEC, UT, TA, TY>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("igemm_conv_kernel");
   return 0;
 }
@@ -1189,17 +1189,17 @@ int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t s
   return (var & 2) ? launch_igemm<32, 4, 1, 2, true>(p, st) : launch_igemm<32, 4, 1, 1, true>(p, st);
 }
 
-template <int BN, int WGM, int WGN, int PF, bool VEC, int FAST, typename TA = float>
+template <int BN, int WGM, int WGN, int PF, bool VEC, int FAST, typename TA = float, typename TD = TA>
 int launch_wgrad_f(const WgradParams& p, int S, hipStream_t st) {
   constexpr size_t lds = (size_t)(2 * BK * BM + 2 * BK * BN) * sizeof(float) + (FAST ? (2 * 1024 + 4) * sizeof(int) : 0);
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST, TA>, lds);
+    int rc = set_dyn_lds(igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST, TA, TD>, lds);
     if (rc) return rc;
     attr_done = true;
   }
   const int64_t tiles = sg_cdiv(p.K, BM) * sg_cdiv(p.Cout, BN);
-  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST, TA>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((igemm_wgrad_kernel<BN, WGM, WGN, PF, VEC, FAST, TA, TD>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("igemm_wgrad_kernel");
   return 0;
 }
@@ -1611,8 +1611,11 @@ void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, co
   p.stats = nullptr;
 }
 
-// any-shape fallback for bf16 storage: the native fp32-MFMA kernel with widening loads and a rounding store
-int dispatch_igemm_b16(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t st) {
+// any-shape fallback for bf16 storage: the native fp32-MFMA kernel with widening loads (TA) and a rounding store (TY).
+// <bf16, bf16> is the plain fallback; <bf16, float> the forward of a softmax head that is not a thin 1x1 convolution
+// (Res34-UNet: Conv2D(2, 3, activation='softmax'), res34.py:156), <float, bf16> its dgrad (fp32 dy in, bf16 dx out).
+template <typename TA, typename TY>
+int dispatch_igemm_mixed(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t st) {
   IgemmParams p = p_in;
   const int bn = pick_bn(p.M, p.Nout, num_cus);
   plan_common(p, false, bn);
@@ -1621,13 +1624,34 @@ int dispatch_igemm_b16(const IgemmParams& p_in, bool vec, int num_cus, hipStream
   p.skip_taps = 0;
   p.cb = 0;
   if (vec) {
-    if (bn == 128) return launch_igemm_ut<128, 2, 4, 1, true, false, bf16_t>(p, st);
-    if (bn == 64) return launch_igemm_ut<64, 4, 2, 1, true, false, bf16_t>(p, st);
-    return launch_igemm_ut<32, 4, 1, 1, true, false, bf16_t>(p, st);
+    if (bn == 128) return launch_igemm_ut<128, 2, 4, 1, true, false, TA, TY>(p, st);
+    if (bn == 64) return launch_igemm_ut<64, 4, 2, 1, true, false, TA, TY>(p, st);
+    return launch_igemm_ut<32, 4, 1, 1, true, false, TA, TY>(p, st);
   }
-  if (bn == 128) return launch_igemm_ut<128, 2, 4, 1, false, false, bf16_t>(p, st);
-  if (bn == 64) return launch_igemm_ut<64, 4, 2, 1, false, false, bf16_t>(p, st);
-  return launch_igemm_ut<32, 4, 1, 1, false, false, bf16_t>(p, st);
+  if (bn == 128) return launch_igemm_ut<128, 2, 4, 1, false, false, TA, TY>(p, st);
+  if (bn == 64) return launch_igemm_ut<64, 4, 2, 1, false, false, TA, TY>(p, st);
+  return launch_igemm_ut<32, 4, 1, 1, false, false, TA, TY>(p, st);
+}
+int dispatch_igemm_b16(const IgemmParams& p, bool vec, int num_cus, hipStream_t st) {
+  return dispatch_igemm_mixed<bf16_t, bf16_t>(p, vec, num_cus, st);
+}
+
+// x bf16, dy fp32: the kernel gradient of a (non-thin) softmax head of a bf16 model
+int dispatch_wgrad_head32(const WgradParams& p_in, int S, bool vec4, hipStream_t st) {
+  WgradParams p = p_in;
+  p.KH_KW = p.K / p.Cin;
+  p.skip_slabs = 0;
+  p.tap_inner = 0;
+  p.stagger = 0;
+  const int bn = wgrad_bn(p.Cout);
+  if (vec4) {
+    if (bn == 128) return launch_wgrad_f<128, 2, 4, 1, true, 0, bf16_t, float>(p, S, st);
+    if (bn == 64) return launch_wgrad_f<64, 4, 2, 1, true, 0, bf16_t, float>(p, S, st);
+    return launch_wgrad_f<32, 4, 1, 1, true, 0, bf16_t, float>(p, S, st);
+  }
+  if (bn == 128) return launch_wgrad_f<128, 2, 4, 1, false, 0, bf16_t, float>(p, S, st);
+  if (bn == 64) return launch_wgrad_f<64, 4, 2, 1, false, 0, bf16_t, float>(p, S, st);
+  return launch_wgrad_f<32, 4, 1, 1, false, 0, bf16_t, float>(p, S, st);
 }
 
 int dispatch_wgrad_b16(const WgradParams& p_in, int S, bool vec8, bool vec4, hipStream_t st) {
@@ -1697,8 +1721,15 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
   SG_CHECK_ARG(!(flags & SG_EPI_BIAS) || bias, "sg_conv2d_fwd: SG_EPI_BIAS without bias");
   const bool b16 = dt_storage(dtype) == SG_BF16, head32 = (dtype & SG_HEAD_F32) != 0;
   const int eb = dt_bytes(dtype);
-  SG_CHECK_ARG(!head32 || (b16 && thin_ok(d) && aligned16(x)), "sg_conv2d_fwd: SG_HEAD_F32 needs a thin (Cout <= 4) 1x1 convolution on bf16 storage");
+  SG_CHECK_ARG(!head32 || (b16 && d->Cout <= 4), "sg_conv2d_fwd: SG_HEAD_F32 needs Cout <= 4 (a softmax head) on bf16 storage");
   hipStream_t st = (hipStream_t)stream;
+  if (head32 && !(thin_ok(d) && aligned16(x))) {  // a head that is not a 1x1 convolution: the any-shape kernel, fp32 out
+    SG_CHECK_ARG(images_per_2gib(d, 4) >= d->N, "sg_conv2d_fwd: softmax head beyond 2 GiB");
+    IgemmParams ph;
+    fill_fwd_params(ph, d, x, w, bias, y, flags, eb);
+    const bool vec4 = (d->Cin % 4 == 0) && (ph.x_ld % 4 == 0) && (((uintptr_t)x & 7) == 0);
+    return dispatch_igemm_mixed<bf16_t, float>(ph, vec4, ctx->num_cus, st);
+  }
   if (!head32) {
     // The fast kernels address their operands through 2 GiB buffer descriptors.  A larger batch is run as
     // sub-batches of whole images (independent in a forward conv), so every image takes the same kernel - and
@@ -1808,8 +1839,19 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   const bool b16 = dt_storage(dtype) == SG_BF16, head32 = (dtype & SG_HEAD_F32) != 0;
   const int eb = dt_bytes(dtype);
   const bool thin = thin_ok(d) && aligned16(dx) && !(flags & (SG_EPI_BIAS | SG_EPI_RELU));
-  SG_CHECK_ARG(!head32 || (b16 && thin), "sg_conv2d_dgrad: SG_HEAD_F32 needs a thin (Cout <= 4) 1x1 convolution on bf16 storage");
+  SG_CHECK_ARG(!head32 || (b16 && d->Cout <= 4), "sg_conv2d_dgrad: SG_HEAD_F32 needs Cout <= 4 (a softmax head) on bf16 storage");
   hipStream_t st = (hipStream_t)stream;
+  if (head32 && !thin) {  // fp32 dy in, bf16 dx out, any shape
+    SG_CHECK_ARG(images_per_2gib(d, 4) >= d->N, "sg_conv2d_dgrad: softmax head beyond 2 GiB");
+    float* wth = (float*)ws;
+    dim3 grid((unsigned)sg_cdiv(d->Cout, 32), (unsigned)sg_cdiv(d->Cin, 32), (unsigned)(d->KH * d->KW));
+    hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, st, (const float*)w, wth, d->Cin, d->Cout);
+    SG_LAUNCH_CHECK("transpose_taps_kernel");
+    IgemmParams ph;
+    fill_dgrad_params(ph, d, dy, wth, bias, dx, flags, 4);
+    const bool vec4 = (d->Cout % 4 == 0) && (ph.x_ld % 4 == 0) && aligned16(dy);
+    return dispatch_igemm_mixed<float, bf16_t>(ph, vec4, ctx->num_cus, st);
+  }
   if (!head32) {
     const int nb = images_per_2gib(d, eb);  // see sg_conv2d_fwd_ws
     if (nb < d->N && nb >= 1) {
@@ -1889,7 +1931,7 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   SG_CHECK_ARG(aligned16(ws), "sg_conv2d_wgrad: workspace must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   const bool thin = thin_ok(d) && aligned16(x);
-  SG_CHECK_ARG(!head32 || (b16 && thin), "sg_conv2d_wgrad: SG_HEAD_F32 needs a thin (Cout <= 4) 1x1 convolution on bf16 storage");
+  SG_CHECK_ARG(!head32 || (b16 && d->Cout <= 4), "sg_conv2d_wgrad: SG_HEAD_F32 needs Cout <= 4 (a softmax head) on bf16 storage");
   const int64_t rows_y = (int64_t)d->N * d->Ho * d->Wo;
   const int yl_ = d->y_ld ? d->y_ld : d->Cout;
   float* bias_part = (float*)((char*)ws + ((pl.dw_part_bytes + 255) & ~(size_t)255));  // 256-byte aligned, after the dw partials
@@ -1941,6 +1983,13 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
       p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
       p.dy_bytes = yb < (1ll << 31) ? (uint32_t)yb : 0;
     }
+    if (b16 && head32) {  // x bf16, dy fp32 (not a thin 1x1 convolution)
+      const int64_t yb32 = (((int64_t)p.P - 1) * p.y_ld + dd.Cout) * 4;
+      p.dy_bytes = yb32 < (1ll << 31) ? (uint32_t)yb32 : 0;
+      const bool vec4 = (dd.Cin % 4 == 0) && (p.x_ld % 4 == 0) && (dd.Cout % 4 == 0) && (p.y_ld % 4 == 0) &&
+                        (((uintptr_t)xs & 7) == 0) && aligned16(dys);
+      return dispatch_wgrad_head32(p, S, vec4, st);
+    }
     if (b16) {
       const bool vec8 = (dd.Cin % 8 == 0) && (p.x_ld % 8 == 0) && (dd.Cout % 8 == 0) && (p.y_ld % 8 == 0) && aligned16(xs) && aligned16(dys);
       const bool vec4 = (dd.Cin % 4 == 0) && (p.x_ld % 4 == 0) && (dd.Cout % 4 == 0) && (p.y_ld % 4 == 0) &&
@@ -1951,6 +2000,7 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
                      aligned16(xs) && aligned16(dys);
     return dispatch_wgrad(p, S, vec, st);
   };
+  SG_CHECK_ARG(!(head32 && pl.chunks > 1), "sg_conv2d_wgrad: softmax head beyond 2 GiB");
   int total_parts = pl.S;
   if (pl.chunks > 1) {
     // sub-batches of whole images, each writing its S partial slabs one after the other; one reduce over all of them

@@ -394,21 +394,13 @@ def _chain2_reference(seed):
     return t, y, {k: v.grad for k, v in p.items()}, loss.item(), margin
 
 
-def test_backward_chain_exact_multi_op(engine):
-    """VERDICT r1 next #2: ONE chain through SeparableConv2D (pre-ReLU folded into the depthwise gather, BN statistics
-    from the pointwise epilogue) -> BatchNormalization(train)+ReLU -> Add with a 1x1 projection -> scSE (sSE conv, GAP ->
-    two 1x1 convs, fused combine) -> Conv2DTranspose 3x3 s2 + ReLU -> 1x1 softmax head -> edge_focal_loss, launched op
-    by op exactly as layers.py launches it; loss and EVERY gradient (all 16 weights and the input) within 1e-5 of fp64
-    autograd, relative to the tensor's largest entry.  BN's beta and the transposed
-    convolution's bias are placed (per channel, in the widest gap of the pre-activations around 0) so that no ReLU input
-    lies within 1e-5 of zero (asserted): there is no flip noise to excuse."""
+def _chain2_engine(e, t, y, dtype=torch.float32):
+    """The chain of _chain2_reference launched op by op exactly as layers.py launches it, activations stored as `dtype`
+    (bf16: the input is rounded once, the softmax head and everything after it is fp32).  Returns (loss, gradients)."""
     from building_detection_amd import _lib
-    e = engine
-    t, y, ref, loss_ref, margin = _chain2_reference(seed=2)
-    assert margin > 1e-5, f"seed puts a ReLU pre-activation at {margin:.1e}: pick another seed"
     d = {k: v.cuda().contiguous() for k, v in t.items()}
     yd = torch.from_numpy(y).float().cuda()
-    x = d["x"]
+    x = d["x"] if dtype == torch.float32 else e.cast(d["x"], dtype)
     N, H, _, C = x.shape
     C2 = d["wT"].shape[2]
     RELU = _lib.SG_ACT_RELU
@@ -429,15 +421,15 @@ def test_backward_chain_exact_multi_op(engine):
     y2 = e.scse_fwd(s, sl, cl)
     fd = e.conv_desc((N, 2 * H, 2 * H, C2), C, 3, 3, 2, 1, "same")
     u = e.conv2d_dgrad(y2, d["wT"], fd, bias=d["bT"], relu=True)
-    prob = e.softmax2_fwd(e.conv2d_fwd(u, d["w5"], d["b5"]))
+    prob = e.softmax2_fwd(e.conv2d_fwd(u, d["w5"], d["b5"], head_f32=True))
+    assert prob.dtype == torch.float32 and u.dtype == dtype and y2.dtype == dtype and sl.dtype == dtype
     loss = float(e.loss_fwd(2, prob, yd).item())
-    assert abs(loss - loss_ref) <= 2e-6 * abs(loss_ref), (loss, loss_ref)
     # ---- backward
     got = {}
     dz = e.softmax2_bwd(prob, e.loss_bwd(2, prob, yd))
     d5 = e.conv_desc(tuple(u.shape), 2, 1, 1)
     got["w5"], got["b5"] = e.conv2d_wgrad(u, dz, d5)
-    du = e.conv2d_dgrad(dz, d["w5"], d5)
+    du = e.conv2d_dgrad(dz, d["w5"], d5, out_dtype=dtype)
     dzu = e.act_bwd(u, du, RELU)
     got["wT"], _ = e.conv2d_wgrad(dzu, y2, fd, want_bias=False)
     got["bT"] = e.bias_grad(dzu, e.empty(C2))
@@ -464,6 +456,22 @@ def test_backward_chain_exact_multi_op(engine):
     ddw = e.conv_desc(tuple(x.shape), C, 3, 3, 1, 1, "same")
     got["dw"] = e.dwconv_wgrad(x, dt, ddw, True)
     got["x"] = e.add_n([e.dwconv_dgrad(dt, d["dw"], ddw, x=x, pre_relu=True), dx_skip])
+    return loss, got
+
+
+def test_backward_chain_exact_multi_op(engine):
+    """VERDICT r1 next #2: ONE chain through SeparableConv2D (pre-ReLU folded into the depthwise gather, BN statistics
+    from the pointwise epilogue) -> BatchNormalization(train)+ReLU -> Add with a 1x1 projection -> scSE (sSE conv, GAP ->
+    two 1x1 convs, fused combine) -> Conv2DTranspose 3x3 s2 + ReLU -> 1x1 softmax head -> edge_focal_loss, launched op
+    by op exactly as layers.py launches it; loss and EVERY gradient (all 16 weights and the input) within 1e-5 of fp64
+    autograd, relative to the tensor's largest entry.  BN's beta and the transposed
+    convolution's bias are placed (per channel, in the widest gap of the pre-activations around 0) so that no ReLU input
+    lies within 1e-5 of zero (asserted): there is no flip noise to excuse."""
+    e = engine
+    t, y, ref, loss_ref, margin = _chain2_reference(seed=2)
+    assert margin > 1e-5, f"seed puts a ReLU pre-activation at {margin:.1e}: pick another seed"
+    loss, got = _chain2_engine(e, t, y)
+    assert abs(loss - loss_ref) <= 2e-6 * abs(loss_ref), (loss, loss_ref)
     worst = ("", 0.0)
     for k, r in ref.items():
         a, b = got[k].detach().cpu().double().reshape(-1), r.reshape(-1)
