@@ -24,6 +24,16 @@ class SgError(RuntimeError):
     pass
 
 
+class PlanesJob(C.Structure):
+    """Mirror of `sg_planes_job` (include/segengine.h): one weight tensor -> its prepared bf16 operand planes."""
+
+    _fields_ = [("w_off", C.c_int64), ("out_off", C.c_int64)] + [(n, C.c_int32) for n in (
+        "kind", "K", "N", "Kpad", "Npad", "Ck", "Ckp", "s_tap", "s_k", "s_n", "npl", "block0", "nblocks")]
+
+
+SG_WS_PREPARED = C.c_size_t(-1).value
+
+
 class ConvDesc(C.Structure):
     """Mirror of `sg_conv_desc` (include/segengine.h)."""
 
@@ -49,6 +59,9 @@ _SIGNATURES = {
     "sg_conv2d_fwd_ws": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "sg_conv2d_fwd_stats_bytes": (_sz, [_dp]),
     "sg_conv2d_fwd_stats": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, C.POINTER(C.c_int)]),
+    "sg_get_conv_x6": (_i, []),
+    "sg_conv2d_planes_job": (_i, [_vp, _i, _dp, _i, C.POINTER(PlanesJob), C.POINTER(C.c_size_t)]),
+    "sg_prepare_planes": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i]),
     "sg_bn_tiles_ws_bytes": (_sz, [_vp, _i, _i]),
     "sg_bn_train_fwd_tiles": (_i, [_vp, _vp, _i, _i64, _i, _vp, _i, _vp, _vp, _vp, _vp, C.c_float, C.c_float, _i, _vp, _sz]),
     "sg_bn_apply": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),

@@ -26,6 +26,7 @@
 //   Tile width and the wgrad split are chosen per launch to fill whole "waves" of 2 workgroups per CU.
 #include "sg_reduce.h"
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 
 namespace {
@@ -1117,9 +1118,10 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
 // TA = bf16_t: SG_BF16 storage).  p.C is the depth of one tap of the reduction (Cin forward, Cout dgrad).
 template <int NPL, typename TA>
 int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH, int KW, void* ws, int num_cus,
-           hipStream_t st) {
+           hipStream_t st, bool prepared = false) {
+  // prepared: `ws` already holds this launch's weight planes (sg_prepare_planes, once per optimiser step), no split here
   if constexpr (NPL == 3) {
-    if (x6p_ok(p, KH, KW)) return run_x6p(p, w, dgrad, Cin, Cout, ws, num_cus, st);
+    if (x6p_ok(p, KH, KW)) return run_x6p(p, w, dgrad, Cin, Cout, ws, num_cus, st, prepared);
   }
   const int Ck = p.C;
   int Ckp = Ck;
@@ -1134,14 +1136,16 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
   p.Npad = x6_npad(N);
   p.wq = (const unsigned short*)ws;
   p.w_bytes = (uint32_t)x6_planes_bytes(K, N, NPL);
-  dim3 grid((unsigned)(p.Kpad / 32), (unsigned)(p.Npad / 32));
-  if (!dgrad)
-    hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Ck,
-                       Cin * Cout, Cout, 1, NPL, Ckp);
-  else
-    hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Ck,
-                       Cin * Cout, 1, Cout, NPL, Ckp);
-  SG_LAUNCH_CHECK("split3_weights_kernel");
+  if (!prepared) {
+    dim3 grid((unsigned)(p.Kpad / 32), (unsigned)(p.Npad / 32));
+    if (!dgrad)
+      hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Ck,
+                         Cin * Cout, Cout, 1, NPL, Ckp);
+    else
+      hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Ck,
+                         Cin * Cout, 1, Cout, NPL, Ckp);
+    SG_LAUNCH_CHECK("split3_weights_kernel");
+  }
   return dispatch_x6<NPL, TA>(p, num_cus, st);
 }
 
@@ -1768,21 +1772,104 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
   const int ch = b16 ? 8 : 4;
   const bool vec = (d->Cin % ch == 0) && (p.x_ld % ch == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
   const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);  // padded reads must stay inside this tensor
-  const bool have_ws = ws && aligned16(ws) && ws_bytes >= x6_ws_bytes(d->KH * d->KW, d->Cin, d->Cout);
+  const bool prepared = ws_bytes == SG_WS_PREPARED;
+  const bool have_ws = ws && aligned16(ws) && (prepared || ws_bytes >= x6_ws_bytes(d->KH * d->KW, d->Cin, d->Cout));
+  if (prepared && !(have_ws && vpad_safe && x6_ok(p, vec, b16))) {
+    sg_set_error("sg_conv2d_fwd: SG_WS_PREPARED planes given, but this launch does not take a prepared-planes kernel");
+    return SG_EINVAL;
+  }
   if (have_ws && vpad_safe && x6_ok(p, vec, b16)) {
     if (stats && tiles_out && !(flags & SG_EPI_RELU)) {  // the statistics ride in the x6 kernel's epilogue only
       p.stats = (float*)stats;
       *tiles_out = (int)sg_cdiv(p.M, BM);
     }
-    if (b16) return run_x6<1, bf16_t>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
-    if (x6_mode() == 2) return run_x6<1, float>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
-    return run_x6<3, float>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
+    if (b16) return run_x6<1, bf16_t>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
+    if (x6_mode() == 2) return run_x6<1, float>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
+    return run_x6<3, float>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
   }
   if (b16) {
     const bool vec4 = (d->Cin % 4 == 0) && (p.x_ld % 4 == 0) && (((uintptr_t)x & 7) == 0);
     return dispatch_igemm_b16(p, vec4, ctx->num_cus, st);
   }
   return dispatch_igemm(p, vec, ctx->num_cus, st);
+}
+
+int sg_get_conv_x6(void) { return x6_mode(); }
+
+int sg_conv2d_planes_job(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, int dgrad, sg_planes_job* out, size_t* bytes) {
+  SG_CHECK_ARG(ctx && d && out && bytes && dt_ok(dtype), "sg_conv2d_planes_job: bad argument");
+  memset(out, 0, sizeof(*out));
+  *bytes = 0;
+  int rc = check_desc(d, "sg_conv2d_planes_job");
+  if (rc) return rc;
+  if ((dtype & SG_HEAD_F32) || thin_ok(d)) return 0;  // kind 0: streaming kernels, no planes
+  if (dgrad && d->stride != 1 && d->stride != 2) return 0;
+  const bool b16 = dt_storage(dtype) == SG_BF16;
+  const int eb = dt_bytes(dtype);
+  IgemmParams p;
+  // geometry only: the pointers are assumed 16-byte aligned and the operands dense, as the host's arenas and torch's
+  // allocator make them; a launch for which that does not hold refuses the prepared planes (SG_EINVAL)
+  static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+  if (!dgrad) fill_fwd_params(p, d, dummy, dummy, nullptr, nullptr, 0, eb);
+  else fill_dgrad_params(p, d, dummy, dummy, nullptr, nullptr, 0, eb);
+  const int ch = b16 ? 8 : 4;
+  const bool vec = !dgrad ? ((d->Cin % ch == 0) && (p.x_ld % ch == 0) && (d->Cout % 4 == 0))
+                          : ((d->Cout % ch == 0) && (p.x_ld % ch == 0) && (d->Cin % 4 == 0));
+  const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);
+  const int nb = images_per_2gib(d, eb);
+  if (nb < 1) return 0;
+  if (nb < d->N) {  // the launch will run as sub-batches: describe one of them
+    const int64_t pix = !dgrad ? (int64_t)nb * d->H * d->W : (int64_t)nb * d->Ho * d->Wo;
+    const int64_t xb = ((pix - 1) * p.x_ld + p.C) * eb;
+    p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
+  }
+  if (!(vpad_safe && x6_ok(p, vec, b16))) return 0;
+  const int npl = (b16 || x6_mode() == 2) ? 1 : 3;
+  const int Ck = p.C;
+  out->s_tap = d->Cin * d->Cout;
+  out->s_k = dgrad ? 1 : d->Cout;
+  out->s_n = dgrad ? d->Cout : 1;
+  out->N = p.Nout;
+  out->Ck = Ck;
+  if (npl == 3) {
+    p.x = (const float*)(uintptr_t)16;  // x6p_ok tests the alignment of x
+    if (x6p_ok(p, d->KH, d->KW)) {
+      out->kind = 2;
+      out->npl = 3;
+      out->K = p.K;
+      out->Ckp = Ck;
+      out->Kpad = p.K;
+      out->Npad = p.Nout;
+      const int64_t threads = (int64_t)(p.K / 16) * (p.Nout / 32) * 64;
+      out->nblocks = (int32_t)sg_cdiv(threads, 256);
+      *bytes = (size_t)3 * p.K * p.Nout * 2;
+      return 0;
+    }
+  }
+  int Ckp = Ck, K = p.K;
+  if (Ck % BK != 0 && K != Ck) {
+    Ckp = x6_vpad_c(Ck);
+    K = (K / Ck) * Ckp;
+  }
+  out->kind = 1;
+  out->npl = npl;
+  out->K = K;
+  out->Ckp = Ckp;
+  out->Kpad = x6_kpad(K);
+  out->Npad = x6_npad(p.Nout);
+  out->nblocks = (out->Kpad / 32) * (out->Npad / 32);
+  *bytes = x6_planes_bytes(K, p.Nout, npl);
+  return 0;
+}
+
+int sg_prepare_planes(sg_ctx* ctx, void* stream, const void* w_arena, void* planes_arena, const sg_planes_job* jobs_dev,
+                      int njobs, int total_blocks) {
+  SG_CHECK_ARG(ctx && w_arena && planes_arena && jobs_dev && njobs > 0 && total_blocks > 0, "sg_prepare_planes: bad argument");
+  SG_CHECK_ARG(aligned16(planes_arena), "sg_prepare_planes: planes arena must be 16-byte aligned");
+  hipLaunchKernelGGL(prepare_planes_kernel, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream, (const float*)w_arena,
+                     (char*)planes_arena, jobs_dev, njobs);
+  SG_LAUNCH_CHECK("prepare_planes_kernel");
+  return 0;
 }
 
 size_t sg_bn_tiles_ws_bytes(const sg_ctx* ctx, int tiles, int C) {
@@ -1831,7 +1918,8 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     return SG_EUNSUPPORTED;
   }
   const size_t need = sg_conv2d_dgrad_ws_bytes(d);
-  if (!ws || ws_bytes < need) {
+  const bool prepared = ws_bytes == SG_WS_PREPARED;
+  if (!ws || (!prepared && ws_bytes < need)) {
     sg_set_error("sg_conv2d_dgrad: workspace %zu < %zu", ws_bytes, need);
     return SG_EWORKSPACE;
   }
@@ -1889,9 +1977,13 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   const bool vec = (d->Cout % ch == 0) && (p.x_ld % ch == 0) && (d->Cin % 4 == 0) && aligned16(dy);
   const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);
   if (vpad_safe && x6_ok(p, vec, b16)) {
-    if (b16) return run_x6<1, bf16_t>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
-    if (x6_mode() == 2) return run_x6<1, float>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
-    return run_x6<3, float>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st);
+    if (b16) return run_x6<1, bf16_t>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
+    if (x6_mode() == 2) return run_x6<1, float>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
+    return run_x6<3, float>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
+  }
+  if (prepared) {
+    sg_set_error("sg_conv2d_dgrad: SG_WS_PREPARED planes given, but this launch does not take a prepared-planes kernel");
+    return SG_EINVAL;
   }
   {
     dim3 grid((unsigned)sg_cdiv(d->Cout, 32), (unsigned)sg_cdiv(d->Cin, 32), (unsigned)(d->KH * d->KW));

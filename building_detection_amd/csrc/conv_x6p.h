@@ -61,6 +61,76 @@ __global__ __launch_bounds__(256) void split3_weights_frag_kernel(const float* _
   o[128] = (u32x4_t){l[0], l[1], l[2], l[3]};
 }
 
+// ---- every weight of a model in ONE launch (sg_prepare_planes): block b finds its job by binary search over the jobs'
+// first-block numbers and does that job's tile exactly as split3_weights_kernel / split3_weights_frag_kernel would
+__global__ __launch_bounds__(256) void prepare_planes_kernel(const float* __restrict__ w_arena, char* __restrict__ planes_arena,
+                                                              const sg_planes_job* __restrict__ jobs, int njobs) {
+  __shared__ float tile[32][33];
+  int lo = 0, hi = njobs - 1;
+  const int b = (int)blockIdx.x;
+  while (lo < hi) {  // last job with block0 <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].block0 <= b) lo = mid; else hi = mid - 1;
+  }
+  const sg_planes_job j = jobs[lo];
+  const int lb = b - j.block0;
+  if (lb >= j.nblocks) return;
+  const float* __restrict__ w = w_arena + j.w_off;
+  unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(planes_arena + j.out_off);
+  if (j.kind == 1) {  // row planes [npl][Npad][Kpad]
+    const int gx = j.Kpad / 32;
+    const int k0 = (lb % gx) * 32, n0 = (lb / gx) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+      const int ky = (j.s_n == 1) ? i : tx, nx = (j.s_n == 1) ? tx : i;
+      const int k = k0 + ky, n = n0 + nx;
+      float v = 0.f;
+      if (k < j.K && n < j.N) {
+        const int tap = k / j.Ckp, kk = k - tap * j.Ckp;
+        if (kk < j.Ck) v = w[(int64_t)tap * j.s_tap + (int64_t)kk * j.s_k + (int64_t)n * j.s_n];
+      }
+      tile[ky][nx] = v;
+    }
+    __syncthreads();
+    const int64_t plane = (int64_t)j.Npad * j.Kpad;
+    for (int i = ty; i < 32; i += 8) {
+      const int n = n0 + i, k = k0 + tx;
+      unsigned h, m, l;
+      split3_pair(tile[tx][i], 0.f, h, m, l);
+      const int64_t o = (int64_t)n * j.Kpad + k;
+      out[o] = (unsigned short)(h & 0xffffu);
+      if (j.npl == 3) {
+        out[plane + o] = (unsigned short)(m & 0xffffu);
+        out[2 * plane + o] = (unsigned short)(l & 0xffffu);
+      }
+    }
+  } else {  // fragment-major planes of the patch kernel
+    const int64_t gid = (int64_t)lb * 256 + threadIdx.x;
+    const int lane = (int)(gid & 63);
+    const int64_t f = gid >> 6;
+    const int NB32 = j.N / 32;
+    if (f >= (int64_t)(j.K / 16) * NB32) return;
+    const int ks = (int)(f / NB32), nb = (int)(f - (int64_t)ks * NB32);
+    const int n = nb * 32 + (lane & 31), k0 = ks * 16 + (lane >> 5) * 8;
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int k = k0 + 2 * e + u;
+        const int tap = k / j.Ck, kk = k - tap * j.Ck;
+        v[u] = w[(int64_t)tap * j.s_tap + (int64_t)kk * j.s_k + (int64_t)n * j.s_n];
+      }
+      split3_pair(v[0], v[1], h[e], m[e], l[e]);
+    }
+    u32x4_t* o = reinterpret_cast<u32x4_t*>(out + (f * 3) * 512 + lane * 8);
+    o[0] = (u32x4_t){h[0], h[1], h[2], h[3]};
+    o[64] = (u32x4_t){m[0], m[1], m[2], m[3]};
+    o[128] = (u32x4_t){l[0], l[1], l[2], l[3]};
+  }
+}
+
 // Persistent: gridDim.x = (workgroups that fit one CU) x CUs; workgroup g walks tiles g, g + gridDim.x, ...
 // The timing-only ablations add up (512x512 64->64: 0.46 ms without the K loop + 1.42 ms without the patch loads =
 // the 1.87 ms of the whole), which looked like the workgroups of a CU marching in lockstep.  `delay` (100 MHz ticks,
@@ -426,7 +496,8 @@ int launch_x6p(const IgemmParams& p, int num_cus, hipStream_t st) {
 }
 
 // split the weights fragment-major (in `ws`, x6_planes_bytes() is enough) and run the patch kernel
-int run_x6p(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void* ws, int num_cus, hipStream_t st) {
+int run_x6p(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void* ws, int num_cus, hipStream_t st,
+            bool prepared = false) {
   const int K = p.K, N = p.Nout;
   {
     static int abl = -1;  // SG_X6P_ABLATE (timing only, results wrong): 1 = no K loop, 2 = no patch loads, 4 = phase clocks into y, 8 = no y stores
@@ -434,13 +505,15 @@ int run_x6p(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void*
     p.ablate = abl;
   }
   p.wq = (const unsigned short*)ws;
-  const int64_t threads = (int64_t)(K / 16) * (N / 32) * 64;
-  const dim3 grid((unsigned)sg_cdiv(threads, 256));
-  if (!dgrad)
-    hipLaunchKernelGGL(split3_weights_frag_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, Cin, Cin * Cout, Cout, 1);
-  else
-    hipLaunchKernelGGL(split3_weights_frag_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, Cout, Cin * Cout, 1, Cout);
-  SG_LAUNCH_CHECK("split3_weights_frag_kernel");
+  if (!prepared) {
+    const int64_t threads = (int64_t)(K / 16) * (N / 32) * 64;
+    const dim3 grid((unsigned)sg_cdiv(threads, 256));
+    if (!dgrad)
+      hipLaunchKernelGGL(split3_weights_frag_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, Cin, Cin * Cout, Cout, 1);
+    else
+      hipLaunchKernelGGL(split3_weights_frag_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, Cout, Cin * Cout, 1, Cout);
+    SG_LAUNCH_CHECK("split3_weights_frag_kernel");
+  }
   const int bn = N >= 128 ? 128 : N;
   if (p.C == 32) {
     if (bn == 32) return launch_x6p<32, 32>(p, num_cus, st);

@@ -194,6 +194,7 @@ class DataParallel:
         # identical replicas: broadcast rank-0 weights and BN statistics once
         self.tp.broadcast(rt.w_train, src=0)
         self.tp.broadcast(rt.w_frozen, src=0)
+        rt.weights_changed()
         self.buckets = plan_buckets(param_ranges(model), rt.g_train.numel(), self.bucket_elems)
         self.reducer = BucketReducer(rt.g_train, self.buckets, self.tp)
         rt.on_node_done = self.reducer.node_done

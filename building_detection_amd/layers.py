@@ -73,6 +73,17 @@ class _ConvNode(Node):
     def desc(self, rt, x):
         return rt.eng.conv_desc(tuple(x.shape), self.filters, self.k, self.k, self.stride, self.dilation, self.padding)
 
+    def plane_sites(self, rt, batch):
+        """(tag, weight, forward-conv descriptor, dgrad?, phase) of every launch of this layer that reads its kernel through
+        the matrix-pipe weight planes: runtime._Runtime.ensure_planes prepares them once per optimiser step."""
+        d = rt.eng.conv_desc((batch,) + tuple(self.inputs[0].shape[1:]), self.filters, self.k, self.k, self.stride,
+                             self.dilation, self.padding)
+        head = self.activation == "softmax"
+        sites = [("f", self.w, d, 0, "fwd", head)]
+        if rt.needs_grad(self.inputs[0]):
+            sites.append(("d", self.w, d, 1, "bwd", head))
+        return sites
+
     @property
     def _tag(self):  # the north_star target kernels: ASPP / SK dilated 3x3 (rates 6, 12, 18)
         return "dilated_conv" if (self.k == 3 and self.dilation >= 6) else None
@@ -83,13 +94,14 @@ class _ConvNode(Node):
         with rt.eng.timed(self._tag):
             if training and getattr(self, "emit_bn_stats", False):
                 # the following BatchNormalization takes its statistics from this conv's epilogue
-                y, st = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=self.desc(rt, x), want_stats=True)
+                y, st = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=self.desc(rt, x), want_stats=True,
+                                          planes=rt.planes(self, "f"))
                 if st is not None:
                     rt.bn_stats[id(y)] = st
                 return y
             # the softmax head stays fp32 under bf16 storage (logits, probabilities, loss: SG_HEAD_F32)
             y = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=self.desc(rt, x), relu=self.activation == "relu",
-                                  head_f32=self.activation == "softmax")
+                                  head_f32=self.activation == "softmax", planes=rt.planes(self, "f"))
         if self.activation == "sigmoid":
             y = rt.eng.act_fwd(y, _lib.SG_ACT_SIGMOID, out=y)
         elif self.activation == "softmax":
@@ -111,7 +123,8 @@ class _ConvNode(Node):
         with e.timed(self._tag):
             want_b = self.b is not None and not getattr(self, "bias_grad_zero", False)
             e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=rt.grad(self.w), db=rt.grad(self.b) if want_b else None)
-            dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype) if rt.needs_grad(self.inputs[0]) else None
+            dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype, planes=rt.planes(self, "d")) \
+                if rt.needs_grad(self.inputs[0]) else None
         return [dx]
 
     def flops(self, batch):
@@ -147,6 +160,11 @@ class _SepConvNode(Node):
         self.b = self.add_param("bias", (self.filters,), "zeros", kind="bias")
         return self.connect([x], (None, ho, wo, self.filters))
 
+    def plane_sites(self, rt, batch):
+        _, ho, wo, _ = self.output.shape
+        d = rt.eng.conv_desc((batch, ho, wo, self.inputs[0].shape[-1]), self.filters, 1, 1)
+        return [("f", self.pw, d, 0, "fwd", False), ("d", self.pw, d, 1, "bwd", False)]
+
     def forward(self, rt, xs, training):
         (x,) = xs
         e = rt.eng
@@ -154,11 +172,11 @@ class _SepConvNode(Node):
         if training:
             rt.save(self, t=t)
             if getattr(self, "emit_bn_stats", False):
-                y, st = e.conv2d_fwd(t, rt.param(self.pw), rt.param(self.b), want_stats=True)
+                y, st = e.conv2d_fwd(t, rt.param(self.pw), rt.param(self.b), want_stats=True, planes=rt.planes(self, "f"))
                 if st is not None:
                     rt.bn_stats[id(y)] = st
                 return y
-        return e.conv2d_fwd(t, rt.param(self.pw), rt.param(self.b), relu=self.activation == "relu")
+        return e.conv2d_fwd(t, rt.param(self.pw), rt.param(self.b), relu=self.activation == "relu", planes=rt.planes(self, "f"))
 
     def backward(self, rt, xs, y, dy):
         (x,) = xs
@@ -168,7 +186,7 @@ class _SepConvNode(Node):
         dpw = e.conv_desc(tuple(t.shape), self.filters, 1, 1)
         want_b = not getattr(self, "bias_grad_zero", False)
         e.conv2d_wgrad(t, dz, dpw, want_b, dw=rt.grad(self.pw), db=rt.grad(self.b) if want_b else None)
-        dt = e.conv2d_dgrad(dz, rt.param(self.pw), dpw)
+        dt = e.conv2d_dgrad(dz, rt.param(self.pw), dpw, planes=rt.planes(self, "d"))
         ddw = e.conv_desc(tuple(x.shape), x.shape[-1], 3, 3, self.stride, 1, "same")
         e.dwconv_wgrad(x, dt, ddw, self.pre_relu, dw=rt.grad(self.dw))
         dx = e.dwconv_dgrad(dt, rt.param(self.dw), ddw, x=x, pre_relu=self.pre_relu) if rt.needs_grad(self.inputs[0]) else None
@@ -210,10 +228,18 @@ class _ConvTNode(Node):
         n, h, w, cin = x.shape
         return rt.eng.conv_desc((n, 2 * h, 2 * w, self.filters), cin, self.k, self.k, 2, 1, "same")
 
+    def plane_sites(self, rt, batch):
+        _, h, w, cin = self.inputs[0].shape
+        d = rt.eng.conv_desc((batch, 2 * h, 2 * w, self.filters), cin, self.k, self.k, 2, 1, "same")
+        sites = [("d", self.w, d, 1, "fwd", False)]            # the layer's forward is the dgrad of F
+        if rt.needs_grad(self.inputs[0]):
+            sites.append(("f", self.w, d, 0, "bwd", False))    # its input gradient is F's forward
+        return sites
+
     def forward(self, rt, xs, training):
         (x,) = xs
         return rt.eng.conv2d_dgrad(x, rt.param(self.w), self.fdesc(rt, x), bias=rt.param(self.b),
-                                   relu=self.activation == "relu")
+                                   relu=self.activation == "relu", planes=rt.planes(self, "d"))
 
     def backward(self, rt, xs, y, dy):
         (x,) = xs
@@ -223,7 +249,7 @@ class _ConvTNode(Node):
         # dw_F = wgrad_F(x_F = dz, dy_F = x); the bias gradient is the column sum of dz
         e.conv2d_wgrad(dz, x, d, want_bias=False, dw=rt.grad(self.w))
         e.bias_grad(dz, rt.grad(self.b))
-        dx = e.conv2d_fwd(dz, rt.param(self.w), None, desc=d) if rt.needs_grad(self.inputs[0]) else None
+        dx = e.conv2d_fwd(dz, rt.param(self.w), None, desc=d, planes=rt.planes(self, "f")) if rt.needs_grad(self.inputs[0]) else None
         return [dx]
 
     def flops(self, batch):

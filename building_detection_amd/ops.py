@@ -195,7 +195,7 @@ class Engine:
         return ConvDesc(n, h, w, cin, cout, kh, kw, stride, dilation, pt, pl, ho, wo, x_ld, y_ld)
 
     def conv2d_fwd(self, x, w, b=None, stride=1, dilation=1, padding="same", relu=False, out=None, desc=None,
-                   want_stats=False, head_f32=False):
+                   want_stats=False, head_f32=False, planes=None):
         """want_stats: also return the BatchNormalization statistics of y as (stats tensor [tiles,2,Cout], tiles), or
         None when this launch could not produce them (then BN computes its own).
         head_f32 (bf16 storage only): the output is fp32 - the softmax head, a thin 1x1 convolution (SG_HEAD_F32)."""
@@ -207,8 +207,10 @@ class Engine:
         y = out if out is not None else self.empty(d.N, d.Ho, d.Wo, cout, dtype=torch.float32 if head_f32 else x.dtype)
         dt = _dt(x) | (SG_HEAD_F32 if head_f32 else 0)
         flags = (_lib.SG_EPI_BIAS if b is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
-        need = self.lib.sg_conv2d_fwd_ws_bytes(C.byref(d))
-        wsp, wsn = self.ws(need)
+        if planes is not None:  # this layer's weight planes, prepared once per step (runtime._Runtime.ensure_planes)
+            wsp, wsn = C.c_void_p(planes), C.c_size_t(_lib.SG_WS_PREPARED)
+        else:
+            wsp, wsn = self.ws(self.lib.sg_conv2d_fwd_ws_bytes(C.byref(d)))
         if want_stats:
             st = self.empty(self.lib.sg_conv2d_fwd_stats_bytes(C.byref(d)) // 4)
             tiles = C.c_int(0)
@@ -221,15 +223,17 @@ class Engine:
                                             wsp, wsn), "sg_conv2d_fwd_ws")
         return y
 
-    def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None, out_dtype=None):
+    def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None, out_dtype=None, planes=None):
         """dx of the forward conv described by `d`; also Conv2DTranspose forward (then bias/relu apply).
         out_dtype = torch.bfloat16 with an fp32 dy: the backward of the fp32 softmax head of a bf16 model (SG_HEAD_F32)."""
         _chk(dy, "dy"); _chk32(w, "w")
         odt = out.dtype if out is not None else (out_dtype or dy.dtype)
         dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin, dtype=odt)
         dt = (SG_BF16 | SG_HEAD_F32) if (odt == torch.bfloat16 and dy.dtype == torch.float32) else _dt(dy)
-        need = self.lib.sg_conv2d_dgrad_ws_bytes(C.byref(d))
-        wsp, wsn = self.ws(need)
+        if planes is not None:
+            wsp, wsn = C.c_void_p(planes), C.c_size_t(_lib.SG_WS_PREPARED)
+        else:
+            wsp, wsn = self.ws(self.lib.sg_conv2d_dgrad_ws_bytes(C.byref(d)))
         flags = (_lib.SG_EPI_BIAS if bias is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
         with self.timed(self._gemm_tag()):
             check(self.lib.sg_conv2d_dgrad(self.h, self.stream, dt, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),

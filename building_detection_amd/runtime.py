@@ -200,6 +200,7 @@ class Model:
             if tuple(w.shape) != p.shape:
                 raise ValueError(f"set_weights: {p.name} expects {p.shape}, got {w.shape}")
             rt.param(p).copy_(torch.from_numpy(np.ascontiguousarray(w)))
+        rt.weights_changed()
 
     def get_gradients(self) -> List[np.ndarray]:
         """Trainable-weight gradients of the last train step / backward, in trainable_weights order."""
@@ -303,6 +304,7 @@ class Model:
             lr_t = float(opt.lr) * math.sqrt(1.0 - opt.beta_2 ** t) / (1.0 - opt.beta_1 ** t)
             rt.eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, lr_t, opt.beta_1, opt.beta_2, opt.epsilon,
                              grad_scale)
+            rt.weights_changed()
             rt.release()
         if return_device_scalars:
             return loss, counts
@@ -419,6 +421,8 @@ class GraphedPredict:
         """Replays the graph on x_dev.  The returned tensor is the graph's static output buffer: consume (or clone) it
         before the next call."""
         with self.rt.eng.lock:
+            if self.rt._planes_dirty:  # weights were replaced after the capture: the graph reads the same planes arena
+                self.rt.ensure_planes(self.x.shape[0], False)
             self.x.copy_(x_dev, non_blocking=True)
             self.graph.replay()
         return self.y
@@ -454,6 +458,14 @@ class _Runtime:
         self._saved: Dict[int, dict] = {}
         self.bn_stats: Dict[int, tuple] = {}  # id(conv output tensor) -> (per-tile statistics, tiles)
         self.on_node_done = None
+        # weight planes of the matrix-pipe convolutions, prepared once per optimiser step (ensure_planes)
+        self._planes_key = None
+        self._planes_ptr: Dict[tuple, int] = {}
+        self._planes_arena = None
+        self._planes_jobs = None
+        self._planes_launch = (0, 0)
+        self._planes_dirty = True
+        self._use_planes = os.environ.get("SG_PREPARED_PLANES", "1") != "0"
 
     # -- parameters ---------------------------------------------------------------------------------------
     def param(self, p: ParamSpec):
@@ -476,6 +488,64 @@ class _Runtime:
         if isinstance(a, torch.Tensor):
             return a if a.is_cuda and a.dtype == torch.float32 else a.to(self.eng.device, torch.float32)
         return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(self.eng.device)
+
+    # -- prepared weight planes -----------------------------------------------------------------------------
+    def weights_changed(self):
+        """Call after writing the weight arena (Adam, set_weights, broadcast): the bf16 operand planes the convolution
+        kernels read are re-derived from it before the next forward."""
+        self._planes_dirty = True
+
+    def planes(self, node, tag):
+        """Device address of the prepared planes of `node`'s launch `tag` ("f" / "d"), or None (the launch then converts its
+        kernel itself, in the workspace)."""
+        return self._planes_ptr.get((id(node), tag))
+
+    def ensure_planes(self, batch: int, training: bool):
+        """(Re)build the job table when the batch, the storage dtype or the arithmetic mode changed; convert every kernel of
+        the model in ONE launch when the weights changed since the last conversion (sg_prepare_planes)."""
+        if not self._use_planes:
+            return
+        import ctypes as C
+        e, m, torch = self.eng, self.model, self.torch
+        bwd = training or m.optimizer is not None
+        key = (int(batch), m.compute_dtype, e.lib.sg_get_conv_x6(), bwd)
+        if key != self._planes_key:
+            dt = _lib.SG_BF16 if m.compute_dtype == "bfloat16" else _lib.SG_F32
+            jobs, ptr_of, off, blocks = [], {}, 0, 0
+            for n in m.nodes:
+                sites = getattr(n, "plane_sites", None)
+                if sites is None:
+                    continue
+                for tag, wspec, d, dgrad, phase, head in sites(self, int(batch)):
+                    if (phase == "bwd" and not bwd) or not wspec.trainable:
+                        continue
+                    job, nbytes = _lib.PlanesJob(), C.c_size_t(0)
+                    _lib.check(e.lib.sg_conv2d_planes_job(e.h, dt | (_lib.SG_HEAD_F32 if (head and dt == _lib.SG_BF16) else 0),
+                                                          C.byref(d), dgrad, C.byref(job), C.byref(nbytes)), "sg_conv2d_planes_job")
+                    if job.kind == 0:
+                        continue
+                    job.w_off, job.out_off, job.block0 = wspec.offset, off, blocks
+                    ptr_of[(id(n), tag)] = off
+                    off += (nbytes.value + 255) // 256 * 256
+                    blocks += job.nblocks
+                    jobs.append(job)
+            self._planes_key = key
+            self._planes_ptr = {}
+            self._planes_arena = self._planes_jobs = None
+            self._planes_launch = (len(jobs), blocks)
+            if jobs:
+                self._planes_arena = torch.empty(off, dtype=torch.uint8, device=e.device)
+                arr = (_lib.PlanesJob * len(jobs))(*jobs)
+                host = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                self._planes_jobs = host.to(e.device)
+                base = self._planes_arena.data_ptr()
+                self._planes_ptr = {k: base + o for k, o in ptr_of.items()}
+            self._planes_dirty = True
+        if self._planes_dirty and self._planes_launch[0]:
+            _lib.check(e.lib.sg_prepare_planes(e.h, e.stream, C.c_void_p(self.w_train.data_ptr()),
+                                               C.c_void_p(self._planes_arena.data_ptr()), C.c_void_p(self._planes_jobs.data_ptr()),
+                                               self._planes_launch[0], self._planes_launch[1]), "sg_prepare_planes")
+        self._planes_dirty = False
 
     # -- tape ---------------------------------------------------------------------------------------------
     def save(self, node, **kw):
@@ -501,6 +571,7 @@ class _Runtime:
         if tuple(x.shape[1:]) != tuple(exp):
             raise ValueError(f"input shape {tuple(x.shape)} does not match the model's {(None,) + tuple(exp)}")
         x = x.contiguous()
+        self.ensure_planes(x.shape[0], training)
         if m.compute_dtype == "bfloat16":  # activations are bf16 from the first layer on (sg_cast, round to nearest even)
             x = self.eng.cast(x, self.torch.bfloat16)
         self.values = {id(m.inputs[0]): x}

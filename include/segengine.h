@@ -161,6 +161,32 @@ int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
 int sg_dense_fwd(sg_ctx* ctx, void* stream, int dtype, int rows, int in, int out, const void* x,
                  const void* w, const void* bias, void* y, int flags);
 
+/* Weight operands prepared ONCE per optimiser step instead of once per launch.  The matrix-pipe convolution kernels
+ * read their weights as bf16 planes ([n][k] rows, or fragment-major for the low-channel patch kernel); without this,
+ * every forward / dgrad launch first converts its kernel into the workspace (about 200 small launches per DeepLabv3+
+ * step).  With it the host keeps one planes arena per model:
+ *   sg_conv2d_planes_job   geometry of the planes of one convolution (dgrad = 0: forward / Conv2DTranspose backward-dx,
+ *                          1: dgrad / Conv2DTranspose forward) into *out, their size into *bytes; out->kind == 0 means
+ *                          this convolution does not take a prepared-planes kernel (thin, odd shapes).  The caller
+ *                          fills w_off (element offset of the fp32 kernel inside the weight arena), out_off (16-byte
+ *                          aligned byte offset inside the planes arena) and block0 (running sum of nblocks), copies
+ *                          the job table to the device, and
+ *   sg_prepare_planes      converts every job of the table in ONE launch (after Adam, after set_weights);
+ *   then passes `planes_arena + out_off` as `ws` with `ws_bytes = SG_WS_PREPARED` to sg_conv2d_fwd_ws / _stats /
+ *   sg_conv2d_dgrad.  A launch whose operands turn out not to qualify (unaligned, strided) returns SG_EINVAL.
+ * The planes depend on the arithmetic mode (sg_get_conv_x6) and the storage dtype: prepare again after changing either. */
+#define SG_WS_PREPARED ((size_t)-1)
+typedef struct sg_planes_job {
+  int64_t w_off, out_off;
+  int32_t kind; /* 0 none, 1 row planes [npl][Npad][Kpad], 2 fragment-major (patch kernel) */
+  int32_t K, N, Kpad, Npad, Ck, Ckp, s_tap, s_k, s_n, npl;
+  int32_t block0, nblocks;
+} sg_planes_job;
+int sg_get_conv_x6(void);
+int sg_conv2d_planes_job(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, int dgrad, sg_planes_job* out, size_t* bytes);
+int sg_prepare_planes(sg_ctx* ctx, void* stream, const void* w_arena, void* planes_arena, const sg_planes_job* jobs_dev,
+                      int njobs, int total_blocks);
+
 /* ------------------------------------------------------------------------------------- normalisation
  * BatchNormalization, Keras defaults (momentum .99, eps 1e-3): v3plus.py:174 ... (92 sites), 2-D after
  * Dense in bam.py / res34.py:95,99.  rows = N*H*W (or N for 2-D), C channels innermost.

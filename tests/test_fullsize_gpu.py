@@ -79,6 +79,7 @@ def test_full_size_512_bs16(engine, name, oracle_fn):
 
     def step():
         rt.w_train.copy_(w0)
+        rt.weights_changed()
         rt.w_frozen.copy_(f0)
         rt.adam_m.zero_()
         rt.adam_v.zero_()
@@ -101,6 +102,7 @@ def test_full_size_512_bs16(engine, name, oracle_fn):
 
     def loss_at(w):
         rt.w_train.copy_(w)
+        rt.weights_changed()
         rt.w_frozen.copy_(f0)
         pr = rt.forward(xd, training=True)
         val = float(rt.eng.loss_fwd(model.loss_kind, pr, yd).item())
@@ -114,6 +116,7 @@ def test_full_size_512_bs16(engine, name, oracle_fn):
     hs = (4e-4, 1e-4, 2.5e-5)
     fds = [(loss_at(w0 + h * d) - loss_at(w0 - h * d)) / (2 * h) for h in hs]
     rt.w_train.copy_(w0)
+    rt.weights_changed()
     rt.w_frozen.copy_(f0)
     fd0 = fds[2] + (fds[2] - fds[1]) * hs[2] / (hs[1] - hs[2])
     print(f"{name} 512x512 bs16: loss {l1:.6f}; directional derivative fd(h=4e-4, 1e-4, 2.5e-5) = "

@@ -485,3 +485,44 @@ def test_backward_chain_exact_multi_op(engine):
         assert rel <= 1e-5, (k, rel)
     print(f"multi-op chain: loss gpu {loss:.7f} fp64 {loss_ref:.7f}; worst gradient {worst[0]} rel {worst[1]:.2e}; "
           f"smallest |ReLU pre-activation| {margin:.2e}")
+
+
+@pytest.mark.parametrize("policy", ["float32", "mixed_bfloat16"])
+def test_prepared_weight_planes_equal_per_launch_conversion(engine, policy):
+    """The bf16 operand planes prepared once per step by ONE batched launch (sg_prepare_planes) against the per-launch
+    conversion into the workspace: the same bits in, so predict(), the loss, the gradients and the weights after two Adam
+    steps must be bit-identical; the planes follow set_weights and a change of the arithmetic mode."""
+    from building_detection_amd import mixed_precision as MP, zoo
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss
+    MP.set_global_policy(policy)
+    try:
+        ma = zoo.Xception_DeepLabV3_Plus((128, 128, 3), 2, aspp_pool=8)
+        mb = zoo.Xception_DeepLabV3_Plus((128, 128, 3), 2, aspp_pool=8)
+    finally:
+        MP.set_global_policy("float32")
+    mb._runtime()._use_planes = False
+    mb.set_weights(ma.get_weights())
+    x, y = synthetic_batch(2, 128, 128, seed=31)
+    assert np.array_equal(ma.predict(x), mb.predict(x))
+    assert ma._runtime()._planes_launch[0] > 50 and mb._runtime()._planes_launch[0] == 0
+    for m in (ma, mb):
+        m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
+    for _ in range(2):
+        la, lb = ma.train_on_batch(x, y), mb.train_on_batch(x, y)
+        assert la["loss"] == lb["loss"]
+        for ga, gb in zip(ma.get_gradients(), mb.get_gradients()):
+            assert np.array_equal(ga, gb)
+    for wa, wb in zip(ma.get_weights(), mb.get_weights()):
+        assert np.array_equal(wa, wb)
+    # new weights -> new planes; another arithmetic mode -> another job table
+    ws = [w * 0.5 if w.ndim == 4 else w for w in ma.get_weights()]
+    ma.set_weights(ws); mb.set_weights(ws)
+    assert np.array_equal(ma.predict(x), mb.predict(x))
+    if policy == "float32":
+        prev = engine.lib.sg_set_conv_x6(2)
+        try:
+            assert np.array_equal(ma.predict(x), mb.predict(x))
+        finally:
+            engine.lib.sg_set_conv_x6(prev)
+        assert np.array_equal(ma.predict(x), mb.predict(x))
