@@ -112,6 +112,10 @@ _SIGNATURES = {
     "sg_edge_labels": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "sg_argmax_accumulate_i8": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i]),
     "sg_vote_ge": (_i, [_vp, _vp, _i, _pp, _i64, _i, _vp]),
+    "sg_mask_objects_ws_bytes": (_sz, [_i, _i]),
+    "sg_mask_objects": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _i, _vp, _vp]),
+    "sg_mask_split_words": (_i64, [_i, _i, _i, _i, _i, _i]),
+    "sg_mask_split": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "sg_cast": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),
     "sg_fill_f32": (_i, [_vp, _vp, _vp, _i64, _f]),
     "sg_trace_mark": (_i, [_vp, _vp, _i, _i]),

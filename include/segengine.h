@@ -335,6 +335,26 @@ int sg_vote_ge(sg_ctx* ctx, void* stream, int nmasks, const void* const* masks, 
 /* dst[i] = (dst_dtype) src[i]: fp32 <-> bf16 conversion (round to nearest even; NaN stays NaN), e.g. the fp32 input
  * tiles of predict.py:109 / the generator of DeepLabv3plus.py:100 entering a bf16 model. */
 int sg_cast(sg_ctx* ctx, void* stream, int src_dtype, int dst_dtype, int64_t n, const void* src, void* dst);
+/* Mask clean-up around the vote (model_fuse.py:9-218, 271-350) on label maps instead of OpenCV contours; what each
+ * OpenCV call means at mask level is restated in oracle/cleanup.py.
+ *   sg_mask_objects   fill_and_delete (model_fuse.py:9-32) of a u8 mask [H][W] (non-zero = building): holes filled (4-connected
+ *                     background not reaching the image border), 8-connected objects numbered, per object the bounding
+ *                     box and 2 x cv.contourArea (2*N4 + N3 over the 2x2 pixel quads) into table[k][8] = {root pixel,
+ *                     area2, x0, y0, x1, y1, kept, 0}, kept = area2 > min_area2 (2000 for the reference's "area <= 1000"),
+ *                     labels[H][W] = object number or -1, *count = number of objects (may exceed max_objs: enlarge and
+ *                     repeat), kept_mask (optional) = the reference's gray_label.  ws: sg_mask_objects_ws_bytes(H, W).
+ *   sg_mask_split     eroede_dilate_process (model_fuse.py:65-115, 173-218) for the listed objects, one workgroup each:
+ *                     1x5 and 5x1 erosions (5 iterations), pieces of contourArea <= piece_area2 / 2 dropped (1000 for the
+ *                     reference's 500), every kept piece dilated and filled on its own; the object is kept, replaced by
+ *                     its pieces or dropped exactly as the reference's if-chain decides; 255 is written into out (which
+ *                     the caller zeroes).  offsets[i] = first 32-bit word of object i's scratch inside ws, each object
+ *                     needing sg_mask_split_words(H, W, its box) words. */
+size_t sg_mask_objects_ws_bytes(int H, int W);
+int sg_mask_objects(sg_ctx* ctx, void* stream, int H, int W, const void* mask_u8, int min_area2, void* ws, size_t ws_bytes,
+                    void* labels_i32, void* table_i32, int max_objs, void* count_i32, void* kept_mask_u8);
+int64_t sg_mask_split_words(int H, int W, int x0, int y0, int x1, int y1);
+int sg_mask_split(sg_ctx* ctx, void* stream, int H, int W, const void* labels_i32, const void* table_i32, const void* objs_i32,
+                  const void* offsets_i64, int nobj, int piece_area2, void* ws, void* out_u8);
 /* fill n floats with value (workspace / gradient zeroing without leaving the stream) */
 int sg_fill_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float value);
 /* Profiling aid: launches an empty one-thread kernel named sg_trace_mark_kernel<tag, end> on `stream`, so that a
