@@ -8,8 +8,8 @@ What changes against the reference: tiles of one image are predicted in batches 
 `model.predict` per tile (BatchNorm runs on moving statistics in inference, so per-tile results do not depend
 on the batching), the argmax / int8 accumulation / vote run as HIP kernels (sg_argmax_accumulate_i8,
 sg_vote_ge), and images may be passed as arrays (OpenCV is not available here; PNG I/O uses Pillow).  The
-contour clean-up around the vote (model_fuse.py:9-218) and polygonisation (edge_3.py) are CPU OpenCV geometry
-and out of scope.
+contour clean-up around the vote (model_fuse.py:9-218) runs on the GPU as label-map kernels (cleanup.py, csrc/morph.hip:
+`model_confuse` below); polygonisation (edge_3.py) is CPU OpenCV geometry and out of scope.
 
 `reference_jloop=True` keeps the reference's column loop `for j in range(0, new_h-152, 360)` (predict.py:106
 iterates the HEIGHT for columns): for landscape images the right-hand columns beyond new_h are never
@@ -86,6 +86,29 @@ def vote(masks: Sequence[np.ndarray], k: int = 3) -> np.ndarray:
     eng = get_engine(0)
     dev = [torch.from_numpy(np.ascontiguousarray(m, dtype=np.uint8)).to(eng.device) for m in masks]
     return eng.vote_ge(dev, k).cpu().numpy()
+
+
+def model_confuse(path, name: str = ""):
+    """model_fuse.py:271-350: the five `*.png` masks in `path` (what run_model wrote) -> clean each, 3-of-5 vote, clean
+    again -> `<path>/<name>_result.png`; returns the uint8 mask.  Also accepts a list of five arrays (then nothing is
+    written).  Fewer / more than five images: prints 'no five images' and returns None, like the reference."""
+    import glob
+    from . import cleanup
+    if isinstance(path, (str, os.PathLike)):
+        files = sorted(glob.glob(os.path.join(str(path), "*.png")))
+        files = [f for f in files if not f.endswith("_result.png")]
+        if len(files) != 5:
+            print("no five images")
+            return None
+        from PIL import Image
+        masks = [np.asarray(Image.open(f).convert("L")) for f in files]
+        out = cleanup.model_confuse(masks)
+        Image.fromarray(out).save(os.path.join(str(path), f"{name}_result.png"), compress_level=0)
+        return out
+    if len(path) != 5:
+        print("no five images")
+        return None
+    return cleanup.model_confuse(list(path))
 
 
 def load_model(weight_dir: str = ".", shape=(512, 512, 3)):

@@ -61,6 +61,33 @@ def test_clean_matches_oracle(engine, seed, h, w):
     assert diff == 0
 
 
+def test_many_separate_buildings(engine):
+    """A town: ~300 separate rectangles / L-shapes / dumbbells of 20-90 px on a 1400x1500 canvas - hundreds of object windows,
+    many of them split, next to each other."""
+    from building_detection_amd import cleanup as GC
+    rng = np.random.default_rng(42)
+    g = np.zeros((1400, 1500), np.uint8)
+    for gy in range(0, 1400, 100):
+        for gx in range(0, 1500, 100):
+            y, x = gy + rng.integers(2, 12), gx + rng.integers(2, 12)
+            hh, ww = rng.integers(20, 86), rng.integers(20, 86)
+            g[y:y + hh, x:x + ww] = 255
+            kind = rng.integers(0, 4)
+            if kind == 0:    # L-shape
+                g[y:y + hh // 2, x + ww // 2:x + ww] = 0
+            elif kind == 1:  # dumbbell: a neck cut into the middle
+                n0 = rng.integers(3, 12)
+                g[y + hh // 2 - 4:y + hh // 2 + 4, x:x + ww // 2 - n0 // 2] = 0
+                g[y + hh // 2 - 4:y + hh // 2 + 4, x + ww // 2 + n0 // 2:x + ww] = 0
+            elif kind == 2:  # courtyard
+                g[y + hh // 3:y + 2 * hh // 3, x + ww // 3:x + 2 * ww // 3] = 0
+    got, ref = GC.clean(g, engine), CL.clean(g)
+    n_in = ndi.label(g > 0, structure=np.ones((3, 3)))[1]
+    n_out = ndi.label(ref > 0, structure=np.ones((3, 3)))[1]
+    print(f"town: {n_in} objects in, {n_out} out, {int((got != ref).sum())} pixels differ")
+    assert np.array_equal(got, ref) and n_out > 50
+
+
 def test_split_drop_and_keep_rules_on_the_gpu(engine):
     """The hand-made cases of tests/test_cleanup_cpu.py::test_split_rules, placed in ONE image: corridor cut (list), narrow
     object (empty list -> vanishes), all pieces small (False -> dropped), compact (kept), an object in the image corner."""
@@ -98,3 +125,6 @@ def test_model_confuse_matches_oracle(engine):
     assert isinstance(got_dev, torch.Tensor) and np.array_equal(got_dev.cpu().numpy(), ref)
     with pytest.raises(ValueError):
         GC.model_confuse(masks[:4], engine)
+    from building_detection_amd import pipeline as PL
+    assert PL.model_confuse(masks[:4]) is None                  # 'no five images', as the reference prints
+    assert np.array_equal(PL.model_confuse(masks), ref)
