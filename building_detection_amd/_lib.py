@@ -116,6 +116,7 @@ _SIGNATURES = {
     "sg_mask_objects": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _sz, _vp, _vp, _i, _vp, _vp]),
     "sg_mask_split_words": (_i64, [_i, _i, _i, _i, _i, _i]),
     "sg_mask_split": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "sg_u8_to_f32": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _f]),
     "sg_cast": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),
     "sg_fill_f32": (_i, [_vp, _vp, _vp, _i64, _f]),
     "sg_trace_mark": (_i, [_vp, _vp, _i, _i]),

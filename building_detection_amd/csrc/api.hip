@@ -29,6 +29,13 @@ __global__ void cast_kernel(const TS* __restrict__ src, TD* __restrict__ dst, in
   if (blockIdx.x == 0 && i < n) st1<TD>(dst + i, ld1<TS>(src + i));
 }
 
+// dst = (float)src / div - sub: the pixel normalisations of decode_img / decode_lbel (DeepLabv3plus.py:36-37, 48)
+__global__ void u8_to_f32_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int64_t n, float div, float sub) {
+  int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) dst[i] = (float)src[i] / div - sub;  // IEEE division, then one rounding: numpy's float32 result
+}
+
 __global__ void scale_f32_kernel(float* __restrict__ p, int64_t n, float a) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -104,6 +111,17 @@ int sg_cast(sg_ctx* ctx, void* stream, int src_dtype, int dst_dtype, int64_t n, 
   else
     hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
   SG_LAUNCH_CHECK("cast_kernel");
+  return 0;
+}
+
+int sg_u8_to_f32(sg_ctx* ctx, void* stream, int64_t n, const void* src_u8, void* dst_f32, float div, float sub) {
+  SG_CHECK_ARG(ctx && (src_u8 || n == 0) && (dst_f32 || n == 0) && n >= 0 && div != 0.f, "sg_u8_to_f32: bad argument");
+  if (n == 0) return 0;
+  int64_t blocks = sg_cdiv(n, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src_u8,
+                     (float*)dst_f32, n, div, sub);
+  SG_LAUNCH_CHECK("u8_to_f32_kernel");
   return 0;
 }
 

@@ -20,6 +20,8 @@ What is exact and what is not (OpenCV is absent here, so nothing below could be 
 from __future__ import annotations
 
 import itertools
+import queue
+import threading
 
 import numpy as np
 
@@ -132,3 +134,109 @@ def train_data_gen(img_path, lab_path, BATCH_SIZE, label_smooth=False, loss="edg
 def val_data_gen(img_path, lab_path, BATCH_SIZE, label_smooth=False, loss="edge_focal_loss", engine=None):
     """`DeepLabv3plus.py:110-153`: the same generator over the validation lists."""
     return _gen(img_path, lab_path, BATCH_SIZE, label_smooth, loss, engine)
+
+
+# ---- not in the reference: a non-blocking feed for the GPU -------------------------------------------------------------------
+class Prefetcher:
+    """Runs any generator (train_data_gen, val_data_gen, ...) in a background thread, `depth` batches ahead, so that file
+    decoding overlaps the training step instead of sitting between two steps as in the reference's synchronous loop
+    (DeepLabv3plus.py:844: fit_generator pulls `next(generator)` on the training thread).  Iteration order and values are
+    the generator's own; an exception in the generator is re-raised by `next()`; `close()` stops the thread."""
+
+    _END = object()
+
+    def __init__(self, generator, depth: int = 2):
+        self._gen = generator
+        self._q: "queue.Queue" = queue.Queue(maxsize=max(1, int(depth)))
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        try:
+            for item in self._gen:
+                while not self._stop.is_set():
+                    try:
+                        self._q.put(item, timeout=0.1)
+                        break
+                    except queue.Full:
+                        continue
+                if self._stop.is_set():
+                    return
+            self._q.put(self._END)
+        except BaseException as e:  # hand the failure to the consumer
+            self._q.put(e)
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        item = self._q.get()
+        if item is self._END:
+            self._q.put(self._END)
+            raise StopIteration
+        if isinstance(item, BaseException):
+            self._q.put(item)
+            raise item
+        return item
+
+    def close(self):
+        self._stop.set()
+        while True:
+            try:
+                self._q.get_nowait()
+            except queue.Empty:
+                break
+        self._thread.join(timeout=5)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _decode_u8(img, seg):
+    """The file-side half of decode_img / decode_lbel: uint8 RGB [512,512,3] and uint8 grey [512,512] (resize included)."""
+    rgb = _resize_bilinear_u8(_imread_bgr_order_free(img))
+    lab = _imread_bgr_order_free(seg).astype(np.int32)
+    gray = ((lab[..., 0] * 4899 + lab[..., 1] * 9617 + lab[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
+    return rgb, _resize_bilinear_u8(gray)
+
+
+def device_data_gen(img_path, lab_path, BATCH_SIZE, engine, depth: int = 2, workers: int = 4):
+    """train_data_gen for the GPU (loss="edge_focal_loss"): the same sorted, cycled (image, label) pairs, but
+      * files are decoded by `workers` threads, `depth` batches ahead of the consumer (Prefetcher),
+      * the batch crosses PCIe as uint8 pixels (a quarter of the fp32 bytes), from pinned memory,
+      * normalisation (`/ 127.5 - 1`, `/ 255`: sg_u8_to_f32) and the four label channels (sg_edge_labels) run on the device.
+    Yields DEVICE tensors (x float32 [N,512,512,3], y float32 [N,512,512,4]) that `fit_generator` / `train_on_batch` take as
+    they are; values are bit-identical to train_data_gen's (tests/test_pipeline_gpu.py).  y is float32 where the reference
+    yields float64: Keras casts y_true to y_pred's float32 before the loss anyway."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    images, label = img_path, lab_path
+    images.sort()
+    label.sort()
+
+    def host_batches():
+        zipped = itertools.cycle(zip(images, label))
+        with ThreadPoolExecutor(max_workers=max(1, int(workers))) as pool:
+            while True:
+                pairs = [next(zipped) for _ in range(BATCH_SIZE)]
+                dec = list(pool.map(lambda p: _decode_u8(*p), pairs))
+                xb = torch.from_numpy(np.stack([d[0] for d in dec]))
+                lb = torch.from_numpy(np.stack([d[1] for d in dec]))
+                if torch.cuda.is_available():
+                    xb, lb = xb.pin_memory(), lb.pin_memory()
+                yield xb, lb
+
+    feed = Prefetcher(host_batches(), depth)
+    try:
+        for xb, lb in feed:
+            xd = xb.to(engine.device, non_blocking=True)
+            ld = lb.to(engine.device, non_blocking=True)
+            x = engine.u8_to_f32(xd, 127.5, 1.0)
+            y = engine.edge_labels(engine.u8_to_f32(ld, 255.0, 0.0))
+            yield x, y
+    finally:
+        feed.close()

@@ -553,6 +553,13 @@ class Engine:
         return t
 
 
+    def u8_to_f32(self, src, div, sub=0.0):
+        """float32(src) / div - sub of a uint8 device tensor (decode_img / decode_lbel's normalisation)."""
+        assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
+        dst = torch.empty(src.shape, dtype=torch.float32, device=self.device)
+        check(self.lib.sg_u8_to_f32(self.h, self.stream, src.numel(), _ptr(src), _ptr(dst), float(div), float(sub)), "sg_u8_to_f32")
+        return dst
+
     def scale(self, t, a):
         check(self.lib.sg_scale_f32(self.h, self.stream, _ptr(t), t.numel(), float(a)), "sg_scale_f32")
         return t

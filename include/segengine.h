@@ -355,6 +355,10 @@ int sg_mask_objects(sg_ctx* ctx, void* stream, int H, int W, const void* mask_u8
 int64_t sg_mask_split_words(int H, int W, int x0, int y0, int x1, int y1);
 int sg_mask_split(sg_ctx* ctx, void* stream, int H, int W, const void* labels_i32, const void* table_i32, const void* objs_i32,
                   const void* offsets_i64, int nobj, int piece_area2, void* ws, void* out_u8);
+/* dst[i] = (float)src[i] / div - sub: decode_img's `np.array(img, np.float32) / 127.5 - 1` and decode_lbel's `/ 255`
+ * (train_model/DeepLabv3plus.py:36-37, 48) on the GPU, so the input pipeline ships uint8 pixels over PCIe (a quarter of
+ * the fp32 bytes) and converts on the device; bit-identical to the numpy float32 arithmetic. */
+int sg_u8_to_f32(sg_ctx* ctx, void* stream, int64_t n, const void* src_u8, void* dst_f32, float div, float sub);
 /* fill n floats with value (workspace / gradient zeroing without leaving the stream) */
 int sg_fill_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float value);
 /* Profiling aid: launches an empty one-thread kernel named sg_trace_mark_kernel<tag, end> on `stream`, so that a

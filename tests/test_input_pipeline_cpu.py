@@ -89,3 +89,34 @@ def test_generator_protocol_and_labels(tmp_path, gen):
     assert y2.shape == (1, 512, 512, 2) and y2.dtype == np.float32
     with pytest.raises(NameError):
         next(gen(imgs, labs, 1, label_smooth=True))
+
+
+def test_prefetcher_keeps_order_propagates_errors_and_stops():
+    import time
+    from building_detection_amd.input_pipeline import Prefetcher
+
+    def gen(n, fail_at=None):
+        for i in range(n):
+            if i == fail_at:
+                raise ValueError("boom")
+            time.sleep(0.001)
+            yield i, i * i
+
+    assert list(Prefetcher(gen(25), depth=3)) == [(i, i * i) for i in range(25)]
+    p = Prefetcher(gen(10, fail_at=4), depth=2)
+    got = []
+    with pytest.raises(ValueError, match="boom"):
+        for item in p:
+            got.append(item)
+    assert got == [(i, i * i) for i in range(4)]
+
+    def forever():
+        i = 0
+        while True:
+            yield i
+            i += 1
+
+    p = Prefetcher(forever(), depth=2)
+    assert [next(p) for _ in range(5)] == [0, 1, 2, 3, 4]
+    p.close()
+    assert not p._thread.is_alive()

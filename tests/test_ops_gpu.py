@@ -550,3 +550,50 @@ def test_conv_epilogue_bn_statistics(engine, shape):
     yr = T.conv2d(x.cpu().double(), wt.cpu().double(), b.cpu().double(), 1, 1, "same")
     zr, _, _ = T.batch_norm(yr, gam.cpu().double(), bet.cpu().double(), torch.zeros(cout).double(), torch.ones(cout).double(), True)
     close(z2, torch.relu(zr), rtol=2e-5, what="conv -> BN -> ReLU vs fp64 oracle")
+
+
+def test_sub_batch_paths_of_oversized_tensors(engine):
+    """activations beyond 2 GiB run as sub-batches of whole images (forward, dgrad) / as chunks with one reduce
+    (wgrad).  SG_CONV_MAX_BYTES (read once per process) lowers that limit, so a child process runs a 5-image convolution
+    with a 2-image limit - uneven last chunk - against the unlimited result of this process: bit-identical forward / dgrad
+    (every image takes the same kernel), wgrad within fp32 summation-order noise (the split differs)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from building_detection_amd.ops import get_engine
+e = get_engine(0)
+g = torch.Generator().manual_seed(5)
+out = {}
+for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    x = (torch.randn(5, 32, 32, 64, generator=g)).cuda().to(dt)
+    w = (torch.randn(3, 3, 64, 96, generator=g) * 0.05).cuda()
+    b = torch.randn(96, generator=g).cuda()
+    d = e.conv_desc(tuple(x.shape), 96, 3, 3, 1, 2, "same")
+    y = e.conv2d_fwd(x, w, b, desc=d)
+    dy = torch.randn(*y.shape, generator=g).cuda().to(dt)
+    dx = e.conv2d_dgrad(dy, w, d)
+    dw, db = e.conv2d_wgrad(x, dy, d)
+    for k, v in (("y", y), ("dx", dx), ("dw", dw), ("db", db)):
+        out[f"{tag}_{k}"] = v.float().cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, limit in (("whole", None), ("chunked", str(2 * 32 * 32 * 96 * 4 + 1000))):   # two fp32 output images fit
+            env = dict(os.environ)
+            if limit:
+                env["SG_CONV_MAX_BYTES"] = limit
+            path = os.path.join(td, name + ".npz")
+            subprocess.run([sys.executable, "-c", code, root, path], check=True, env=env, timeout=300)
+            res[name] = dict(np.load(path))
+    for tag in ("f32", "bf16"):
+        assert np.array_equal(res["whole"][f"{tag}_y"], res["chunked"][f"{tag}_y"])
+        assert np.array_equal(res["whole"][f"{tag}_dx"], res["chunked"][f"{tag}_dx"])
+        for k in ("dw", "db"):
+            a, b = res["whole"][f"{tag}_{k}"], res["chunked"][f"{tag}_{k}"]
+            assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max(), (tag, k)

@@ -187,3 +187,36 @@ def test_predict_is_serialised_across_threads(engine):
     for t in ts:
         t.join()
     assert not errs, errs[:5]
+
+
+def test_device_data_gen_is_bit_identical_to_the_host_generator(engine, tmp_path):
+    """SURVEY 8f-1, the non-synchronous feed: files decoded by worker threads ahead of the consumer, uint8 pixels over PCIe,
+    normalisation and label channels on the device - same values as train_data_gen (DeepLabv3plus.py:53-107), bit for bit,
+    in the same (sorted, cycled) order, and fit_generator consumes the device tensors directly."""
+    from PIL import Image
+    from building_detection_amd import input_pipeline as IP, zoo
+    from building_detection_amd.losses import edge_focal_loss, PA, IoU, MIoU, F1_score
+    rng = np.random.default_rng(8)
+    imgs, labs = [], []
+    for i in range(3):
+        lab = np.zeros((512, 512), np.uint8)
+        lab[40 + 90 * i:180 + 90 * i, 60:260 + 40 * i] = 255
+        lab[500:, :30] = 255
+        lab[100, 400] = 128          # a grey value that is NOT building (to_categorical truncation)
+        pi, pl = tmp_path / f"i{i}.png", tmp_path / f"l{i}.png"
+        Image.fromarray(rng.integers(0, 256, size=(512, 512, 3), dtype=np.uint8)).save(pi)
+        Image.fromarray(lab).save(pl)
+        imgs.append(str(pi)); labs.append(str(pl))
+    host = IP.train_data_gen(list(imgs), list(labs), 2)
+    dev = IP.device_data_gen(list(imgs), list(labs), 2, engine, depth=2, workers=3)
+    for _ in range(4):   # more than one cycle of the three files
+        xh, yh = next(host)
+        xd, yd = next(dev)
+        assert xd.is_cuda and xd.dtype == torch.float32 and yd.dtype == torch.float32
+        assert np.array_equal(xd.cpu().numpy(), xh)
+        assert np.array_equal(yd.cpu().numpy().astype(np.float64), yh)
+    model = zoo.HRNet((512, 512, 3))
+    model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
+    hist = model.fit_generator(dev, steps_per_epoch=2, epochs=1, verbose=0)
+    assert np.isfinite(hist.history["loss"][-1])
+    dev.close()
