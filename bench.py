@@ -65,6 +65,42 @@ def cpu_baseline(threads, batch, size, steps, model=None):
     out = {"value": round(batch / best, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
            "sample": f"CPU oracle (restated TF2 semantics, torch CPU ops) DeepLabv3+ {size}x{size} bs={batch}, "
                      f"min of {steps} full steps (fwd+loss+bwd+Adam), {best:.2f} s/step"}
+    # BASELINE.md section 3 extras, bounded: (a) the same step on ONE thread (one 256x256 tile: 1/8 of the bs-2 512x512
+    # sample's work), (b) BASELINE configs[0]: Res34-UNet 256x256 bs 2 on all threads
+    def one_step(fn, xs, ys, threads_, reps):
+        torch.set_num_threads(threads_)
+        Pq = M.Params(seed=1103)
+        best_ = None
+        mq = vq = None
+        for it in range(reps + 1):
+            t0 = time.time()
+            pq = fn(Pq, xs, training=True)
+            lq = M.loss_fn("edge_focal_loss", ys, pq)
+            trq = Pq.trainable_tensors()
+            for t in trq:
+                t.grad = None
+            lq.backward()
+            if mq is None:
+                mq, vq = [torch.zeros_like(t) for t in trq], [torch.zeros_like(t) for t in trq]
+            M.adam_step(trq, [t.grad for t in trq], mq, vq, t=it + 1, lr=1e-3)
+            if it > 0:
+                dt_ = time.time() - t0
+                best_ = dt_ if best_ is None else min(best_, dt_)
+        torch.set_num_threads(threads)
+        return best_
+    try:
+        xs1, ys1 = synthetic_batch(1, 256, 256, seed=1103)
+        t1 = one_step(lambda Pq, x_, training: M.deeplab_v3plus(Pq, x_, training=training, aspp_pool=16), torch.from_numpy(xs1),
+                      torch.from_numpy(ys1), 1, 1)
+        out["one_thread"] = {"value": round(0.25 / t1, 4), "unit": "512x512-tile equivalents/s", "cores": 1,
+                             "sample": f"DeepLabv3+ one 256x256 tile (a quarter of a 512x512 tile's work), full step, {t1:.2f} s"}
+        xs2, ys2 = synthetic_batch(2, 256, 256, seed=1103)
+        t2 = one_step(lambda Pq, x_, training: M.res34_unet(Pq, x_, training=training), torch.from_numpy(xs2), torch.from_numpy(ys2),
+                      threads, 2)
+        out["config1_res34_256_bs2"] = {"value": round(2 / t2, 4), "unit": "256x256 tiles/s", "cores": threads,
+                                        "sample": f"BASELINE configs[0]: Res34-UNet 256x256 bs=2 full step, min of 2, {t2:.2f} s/step"}
+    except Exception as e:  # extras never take the main figure down
+        out["extras_error"] = repr(e)
     if model is not None:
         import numpy as np
         with torch.no_grad():
