@@ -1034,7 +1034,7 @@ int pick_bn(int64_t M, int N, int num_cus) {
 }
 
 // fields shared by the fp32 and the x6 kernel: padding-tap elimination, tile order, K order
-void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false) {
+void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false, int eb = 4) {
   static int noskip = -1;
   if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;  // A/B switch for the padding-tap elimination
   const int ntaps = p.K / p.C, spt = p.C / BK;
@@ -1047,7 +1047,7 @@ void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false) {
   const bool ut = vec && (p.C % BK == 0) && p.x_bytes != 0 && p.w_bytes != 0;
   // decided from ONE image's footprint, never from the batch: the K order fixes the rounding order, and
   // inference must not depend on how many tiles travel together (tests/test_fullsize_gpu.py)
-  const int64_t img_bytes = (int64_t)p.H * p.W * p.x_ld * 4;
+  const int64_t img_bytes = (int64_t)p.H * p.W * p.x_ld * eb;
   static int cbv = -1;  // experiment switch SG_CONV_CB: slabs per channel block of the K order (default 4)
   if (cbv < 0) cbv = getenv("SG_CONV_CB") ? atoi(getenv("SG_CONV_CB")) : 4;
   p.cb = ((conv_l2(x6) & 2) && ut && ntaps > 1 && spt > cbv && spt % cbv == 0 && img_bytes > (2ll << 20)) ? cbv : 0;
@@ -1055,6 +1055,7 @@ void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false) {
 
 #include "conv_x6.h"
 #include "conv_x6p.h"
+#include "conv_b16.h"
 
 template <int NPL, typename TA>
 int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
@@ -1065,7 +1066,7 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
     static const bool bn64 = getenv("SG_X6_BN64") != nullptr;
     if (bn64 && bn == 128 && sg_cdiv(p.M, BM) * sg_cdiv(p.Nout, 128) <= (int64_t)num_cus) bn = 64;
   }
-  plan_common(p, true, bn, true);
+  plan_common(p, true, bn, true, EL<TA>::BYTES);
   {
     static int il = -1;  // SG_X6_INTERLEAVE=0: staggered halves instead of the hand-interleaved step (A/B switch)
     if (il < 0) il = getenv("SG_X6_INTERLEAVE") ? atoi(getenv("SG_X6_INTERLEAVE")) : 1;
@@ -1145,6 +1146,10 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
       hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Ck,
                          Cin * Cout, 1, Cout, NPL, Ckp);
     SG_LAUNCH_CHECK("split3_weights_kernel");
+  }
+  if constexpr (NPL == 1 && !std::is_same<TA, float>::value) {
+    static const bool deep = !(getenv("SG_B16_DEEP") && atoi(getenv("SG_B16_DEEP")) == 0);  // A/B switch
+    if (deep) return dispatch_b16(p, num_cus, st);
   }
   return dispatch_x6<NPL, TA>(p, num_cus, st);
 }
@@ -1505,7 +1510,7 @@ struct WgradPlan {
 // Split of the pixel reduction over S workgroups per tile.  Modelled time = MFMA work / (fraction of the
 // 2*CUs workgroup slots kept busy over whole waves) + the traffic of writing and re-adding S partial slabs;
 // the S with the smallest modelled time wins (e.g. ASPP: 288 tiles -> S = 7: 2016 workgroups = 3.94 waves).
-WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
+WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d, bool b16 = false) {
   WgradPlan pl;
   const int64_t K = (int64_t)d->KH * d->KW * d->Cin;
   const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
@@ -1514,7 +1519,7 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
     if (nb >= 1 && nb < d->N && !thin_ok(d)) {
       sg_conv_desc sub = *d;
       sub.N = nb;
-      pl = plan_wgrad(num_cus, &sub);
+      pl = plan_wgrad(num_cus, &sub, b16);
       pl.nb = nb;
       pl.chunks = (int)sg_cdiv(d->N, nb);
       pl.dw_part_bytes = (size_t)pl.chunks * pl.S * K * d->Cout * 4;  // every chunk writes partial slabs
@@ -1537,7 +1542,9 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d) {
   // sustained rate of the kernel that will run: the x6 wgrad (geometry test as in wgrad_x6_ok) or the fp32 MFMA one
   static const double rate_x6 = getenv("SG_WGRAD_PLAN_RATE") ? atof(getenv("SG_WGRAD_PLAN_RATE")) * 1e12 : 110e12;
   const bool x6_geom = d->stride == 1 && d->Ho == d->H && d->Wo == d->W && d->W % 32 == 0 && d->Cout >= 16 && d->Cin % 4 == 0;
-  const double rate = x6_geom ? rate_x6 : 110e12;
+  // the one-pass bf16 kernel multiplies ~4x faster than the six-pass one: the split's partial-slab traffic weighs more
+  static const double rate_b16 = getenv("SG_WGRAD_PLAN_RATE_B16") ? atof(getenv("SG_WGRAD_PLAN_RATE_B16")) * 1e12 : 110e12;  // measured 110 / 250 / 450 / 900: no gain from a higher rate (profiles/r02_b16_deep_ab.txt)
+  const double rate = x6_geom ? (b16 ? rate_b16 : rate_x6) : 110e12;
   int64_t maxS = nslab / 8;  // at least 8 slabs per split
   if (maxS < 1) maxS = 1;
   if (maxS > 512) maxS = 512;
@@ -1999,9 +2006,10 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
 
 size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
   if (!ctx || !d) return 0;
-  // planned for 2-byte elements too: a bf16 tensor needs at most as many sub-batches as the fp32 one
-  WgradPlan pl = plan_wgrad(ctx->num_cus, d);
-  return pl.dw_part_bytes + pl.bias_part_bytes + 512;
+  // the query does not know the storage type: the larger of the fp32 and the bf16 plan
+  const WgradPlan pl = plan_wgrad(ctx->num_cus, d, false), pb = plan_wgrad(ctx->num_cus, d, true);
+  const size_t a = pl.dw_part_bytes + pl.bias_part_bytes, b = pb.dw_part_bytes + pb.bias_part_bytes;
+  return (a > b ? a : b) + 512;
 }
 
 int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
@@ -2013,8 +2021,7 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   SG_CHECK_ARG(x && dy && dw, "sg_conv2d_wgrad: null tensor");
   const bool b16 = dt_storage(dtype) == SG_BF16, head32 = (dtype & SG_HEAD_F32) != 0;
   const int eb = dt_bytes(dtype);
-  // the split / sub-batch plan is the fp32 one for both storages (same partial-slab layout, same workspace)
-  const WgradPlan pl = plan_wgrad(ctx->num_cus, d);
+  const WgradPlan pl = plan_wgrad(ctx->num_cus, d, b16);
   const size_t need = pl.dw_part_bytes + pl.bias_part_bytes + 512;
   if (!ws || ws_bytes < need) {
     sg_set_error("sg_conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);

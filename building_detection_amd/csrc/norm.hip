@@ -175,9 +175,13 @@ inline unsigned ew_blocks(int64_t total) {
 template <typename T>
 int launch_bn_apply(hipStream_t st, bool vec, const T* x, const float* mean, const float* invstd, const float* gamma,
                     const float* beta, T* y, int64_t rows, int C, int relu, float eps, int infer) {
-  const int V = vec ? 4 : 1;
+  const bool wide = vec && sizeof(T) == 2 && C % 8 == 0;  // bf16: 8 channels = one 16-byte access
+  const int V = wide ? 8 : (vec ? 4 : 1);
   const unsigned blocks = ew_blocks(rows * (C / V));
-  if (vec)
+  if (wide)
+    hipLaunchKernelGGL((bn_apply_kernel<8, T>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, y, rows, C, relu, eps,
+                       infer, make_fastdiv((uint32_t)(C / V)));
+  else if (vec)
     hipLaunchKernelGGL((bn_apply_kernel<4, T>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, y, rows, C, relu, eps,
                        infer, make_fastdiv((uint32_t)(C / V)));
   else
@@ -196,7 +200,10 @@ size_t sg_bn_ws_bytes(const sg_ctx* ctx, int64_t rows, int C) {
   SegPlan pl = seg_plan<2>(ctx->num_cus, 1, rows, C, true);
   // scalar plan can only be smaller or equal in part_bytes (same formula, S differs): take the max of both
   SegPlan pls = seg_plan<2>(ctx->num_cus, 1, rows, C, false);
-  return (pl.part_bytes > pls.part_bytes ? pl.part_bytes : pls.part_bytes) + 256;
+  SegPlan plw = seg_plan<2>(ctx->num_cus, 1, rows, C, true, true);
+  size_t m = pl.part_bytes > pls.part_bytes ? pl.part_bytes : pls.part_bytes;
+  if (plw.part_bytes > m) m = plw.part_bytes;
+  return m + 256;
 }
 
 int sg_bn_train_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* gamma,
@@ -208,7 +215,7 @@ int sg_bn_train_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
                "sg_bn_train_fwd: bad argument");
   SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_train_fwd: tensor exceeds 2^31 elements");
   const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
-  const SegPlan pl = seg_plan<2>(ctx->num_cus, 1, rows, C, vec);
+  const SegPlan pl = seg_plan<2>(ctx->num_cus, 1, rows, C, vec, dtype == SG_BF16);
   if (!ws || ws_bytes < pl.part_bytes) {
     sg_set_error("sg_bn_train_fwd: workspace %zu < %zu", ws_bytes, pl.part_bytes);
     return SG_EWORKSPACE;
@@ -237,7 +244,7 @@ int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
   SG_CHECK_ARG(!relu || y || beta, "sg_bn_train_bwd: relu set but neither y nor beta given");
   SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_train_bwd: tensor exceeds 2^31 elements");
   const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy) && sg_aligned16(dx) && (!relu || sg_aligned16(y));
-  const SegPlan pl = seg_plan<2>(ctx->num_cus, 1, rows, C, vec);
+  const SegPlan pl = seg_plan<2>(ctx->num_cus, 1, rows, C, vec, dtype == SG_BF16);
   if (!ws || ws_bytes < pl.part_bytes) {
     sg_set_error("sg_bn_train_bwd: workspace %zu < %zu", ws_bytes, pl.part_bytes);
     return SG_EWORKSPACE;
@@ -251,9 +258,14 @@ int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
     op.dgamma = (float*)dgamma; op.dbeta = (float*)dbeta; op.C = C; op.relu = relu;
     int rc = seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_bwd_reduce");
     if (rc) return rc;
-    const int V = vec ? 4 : 1;
+    const bool wide = vec && sizeof(T) == 2 && C % 8 == 0;
+    const int V = wide ? 8 : (vec ? 4 : 1);
     const unsigned blocks = ew_blocks(rows * (C / V));
-    if (vec)
+    if (wide)
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<8, T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
+                         (const float*)save_mean, (const float*)save_invstd, (const float*)gamma, (const float*)beta,
+                         (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));
+    else if (vec)
       hipLaunchKernelGGL((bn_bwd_apply_kernel<4, T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
                          (const float*)save_mean, (const float*)save_invstd, (const float*)gamma, (const float*)beta,
                          (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));

@@ -488,7 +488,10 @@ int sg_act_bwd(sg_ctx* ctx, void* stream, int dtype, int act, int64_t n, const v
   if (n == 0) return 0;
   hipStream_t st = (hipStream_t)stream;
   SG_DTYPE_SWITCH(dtype, "sg_act_bwd", {
-    if (n % 4 == 0 && sg_aligned16(y) && sg_aligned16(dy) && sg_aligned16(dx))
+    if (sizeof(T) == 2 && n % 8 == 0 && sg_aligned16(y) && sg_aligned16(dy) && sg_aligned16(dx))
+      hipLaunchKernelGGL((act_bwd_kernel<8, T>), dim3(ew_blocks(n / 8)), dim3(256), 0, st, (const T*)y, (const T*)dy, (T*)dx, n,
+                         act, accumulate);
+    else if (n % 4 == 0 && sg_aligned16(y) && sg_aligned16(dy) && sg_aligned16(dx))
       hipLaunchKernelGGL((act_bwd_kernel<4, T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, (const T*)y, (const T*)dy, (T*)dx, n,
                          act, accumulate);
     else
@@ -515,7 +518,9 @@ int sg_add_n(sg_ctx* ctx, void* stream, int dtype, int k, const void* const* xs,
   a.k = k;
   hipStream_t st = (hipStream_t)stream;
   SG_DTYPE_SWITCH(dtype, "sg_add_n", {
-    if (vec)
+    if (vec && sizeof(T) == 2 && n % 8 == 0)
+      hipLaunchKernelGGL((add_n_kernel<8, T>), dim3(ew_blocks(n / 8)), dim3(256), 0, st, a, (T*)y, n, relu);
+    else if (vec)
       hipLaunchKernelGGL((add_n_kernel<4, T>), dim3(ew_blocks(n / 4)), dim3(256), 0, st, a, (T*)y, n, relu);
     else
       hipLaunchKernelGGL((add_n_kernel<1, T>), dim3(ew_blocks(n)), dim3(256), 0, st, a, (T*)y, n, relu);
@@ -535,7 +540,10 @@ int sg_copy_channels(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, 
                    sg_aligned16(src) && sg_aligned16(dst);
   hipStream_t st = (hipStream_t)stream;
   SG_DTYPE_SWITCH(dtype, "sg_copy_channels", {
-    if (vec)
+    if (vec && sizeof(T) == 2 && (C % 8 == 0) && (src_ld % 8 == 0) && (dst_ld % 8 == 0) && (src_off % 8 == 0) && (dst_off % 8 == 0))
+      hipLaunchKernelGGL((copy_channels_kernel<8, T>), dim3(ew_blocks(rows * (C / 8))), dim3(256), 0, st, (const T*)src, src_ld,
+                         src_off, (T*)dst, dst_ld, dst_off, rows, C, accumulate, make_fastdiv((uint32_t)(C / 8)));
+    else if (vec)
       hipLaunchKernelGGL((copy_channels_kernel<4, T>), dim3(ew_blocks(rows * (C / 4))), dim3(256), 0, st, (const T*)src, src_ld,
                          src_off, (T*)dst, dst_ld, dst_off, rows, C, accumulate, make_fastdiv((uint32_t)(C / 4)));
     else

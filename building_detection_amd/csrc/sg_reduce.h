@@ -93,10 +93,12 @@ struct SegPlan {
   size_t part_bytes;
 };
 
+// wide8: the reduced tensor is bf16 and C % 8 == 0: a lane takes 8 channels (one 16-byte access) instead of 4 (8 bytes)
 template <int NOUT>
-static inline SegPlan seg_plan(int num_cus, int nseg, int64_t rows, int C, bool vec_ok) {
+static inline SegPlan seg_plan(int num_cus, int nseg, int64_t rows, int C, bool vec_ok, bool wide8 = false) {
   SegPlan pl;
   pl.V = (vec_ok && C % 4 == 0) ? 4 : 1;
+  if (pl.V == 4 && wide8 && C % 8 == 0 && NOUT <= 2) pl.V = 8;
   const int chunks = C / pl.V;
   // 16 lanes x 16 B = one 256-byte run per row; narrow blocks keep gx (and so the block count) high without
   // a large row split S, which the second stage would have to add up again
@@ -126,7 +128,9 @@ static inline int seg_reduce_launch(const Op& op, const SegPlan& pl, int nseg, i
   if (nseg <= 0 || rows <= 0 || C <= 0) return 0;
   const size_t lds = (size_t)256 * Op::NOUT * pl.V * sizeof(float);
   dim3 grid((unsigned)pl.gx, (unsigned)nseg, (unsigned)pl.S), block((unsigned)pl.TX, (unsigned)pl.TY);
-  if (pl.V == 4)
+  if (pl.V == 8) {
+    if constexpr (Op::NOUT <= 2) hipLaunchKernelGGL((seg_reduce_kernel<Op, 8>), grid, block, lds, st, op, rows, C, pl.S, part);
+  } else if (pl.V == 4)
     hipLaunchKernelGGL((seg_reduce_kernel<Op, 4>), grid, block, lds, st, op, rows, C, pl.S, part);
   else
     hipLaunchKernelGGL((seg_reduce_kernel<Op, 1>), grid, block, lds, st, op, rows, C, pl.S, part);
@@ -137,10 +141,13 @@ static inline int seg_reduce_launch(const Op& op, const SegPlan& pl, int nseg, i
   return 0;
 }
 
-// vector load/store helpers (V = 4: 16-byte access; V = 1: scalar)
+// vector load/store helpers (V = 4: 16-byte access; V = 1: scalar; V = 8: two 16-byte accesses)
 template <int V>
 __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&o)[V]) {
-  if constexpr (V == 4) {
+  if constexpr (V == 8) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  } else if constexpr (V == 4) {
     const f32x4 t = *reinterpret_cast<const f32x4*>(p);
     o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
   } else {
@@ -149,7 +156,11 @@ __device__ __forceinline__ void ldv(const float* __restrict__ p, float (&o)[V]) 
 }
 template <int V>
 __device__ __forceinline__ void stv(float* __restrict__ p, const float (&o)[V]) {
-  if constexpr (V == 4) {
+  if constexpr (V == 8) {
+    const f32x4 a = {o[0], o[1], o[2], o[3]}, b = {o[4], o[5], o[6], o[7]};
+    *reinterpret_cast<f32x4*>(p) = a;
+    *reinterpret_cast<f32x4*>(p + 4) = b;
+  } else if constexpr (V == 4) {
     f32x4 t = {o[0], o[1], o[2], o[3]};
     *reinterpret_cast<f32x4*>(p) = t;
   } else {
@@ -160,7 +171,11 @@ __device__ __forceinline__ void stv(float* __restrict__ p, const float (&o)[V]) 
 // bf16 storage: V = 4 is one 8-byte access, V = 1 a 2-byte one; values widen to fp32 in registers
 template <int V>
 __device__ __forceinline__ void ldv(const bf16_t* __restrict__ p, float (&o)[V]) {
-  if constexpr (V == 4) {
+  if constexpr (V == 8) {
+    f32x4 a, b;
+    ld8_bf16(p, a, b);
+    o[0] = a[0]; o[1] = a[1]; o[2] = a[2]; o[3] = a[3]; o[4] = b[0]; o[5] = b[1]; o[6] = b[2]; o[7] = b[3];
+  } else if constexpr (V == 4) {
     const f32x4 t = ld4<bf16_t>(p);
     o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; o[3] = t[3];
   } else {
@@ -169,7 +184,10 @@ __device__ __forceinline__ void ldv(const bf16_t* __restrict__ p, float (&o)[V])
 }
 template <int V>
 __device__ __forceinline__ void stv(bf16_t* __restrict__ p, const float (&o)[V]) {
-  if constexpr (V == 4) {
+  if constexpr (V == 8) {
+    const f32x4 a = {o[0], o[1], o[2], o[3]}, b = {o[4], o[5], o[6], o[7]};
+    st8_bf16(p, a, b);
+  } else if constexpr (V == 4) {
     const f32x4 t = {o[0], o[1], o[2], o[3]};
     st4<bf16_t>(p, t);
   } else {
