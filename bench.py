@@ -205,7 +205,8 @@ def main():
     model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
     if dist is not None:
         from building_detection_amd.dist import DataParallel
-        DataParallel(model, comm=args.comm)
+        dp = DataParallel(model, comm="sg_or_torch" if args.comm == "sg" else "torch")
+        args.comm = dp.tp.name   # what actually carries the gradients ("sg" may have fallen back to "torch")
 
     # rank r takes tiles [16 r, 16 r + 16) of the global synthetic batch (weak scaling)
     x, y = synthetic_batch(args.batch, args.size, args.size, seed=1103 + rank)
@@ -240,7 +241,7 @@ def main():
         fam = eng.profile_end()
     sync()
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.comm == "torch" else "cpu")
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     ms_per_step = dt / args.steps * 1e3

@@ -189,7 +189,29 @@ class DataParallel:
         rt = model._runtime()
         if comm == "auto":
             comm = "torch" if dist.get_backend(group) == "nccl" else "sg"
-        self.tp = SgTransport(rt.eng.device, group) if comm == "sg" else TorchTransport(group)
+        if comm in ("sg", "sg_or_torch"):
+            self.tp, err = None, None
+            try:
+                self.tp = SgTransport(rt.eng.device, group)
+            except Exception as e:  # e.g. no usable librccl for dlopen: every rank must take the same way out
+                err = e
+            if comm == "sg_or_torch":
+                import torch
+                flag = torch.tensor([0 if self.tp is not None else 1], dtype=torch.int32)
+                if dist.get_backend(group) == "nccl":
+                    flag = flag.to(rt.eng.device)
+                dist.all_reduce(flag, group=group)
+                if int(flag.item()) > 0:  # somebody failed: all fall back to torch.distributed's RCCL
+                    import sys
+                    print(f"[dist] sg_comm transport unavailable ({err!r}); falling back to torch.distributed nccl", file=sys.stderr)
+                    if self.tp is not None:
+                        self.tp.close()
+                    g2 = group if dist.get_backend(group) == "nccl" else dist.new_group(backend="nccl")
+                    self.tp = TorchTransport(g2)
+            elif self.tp is None:
+                raise err
+        else:
+            self.tp = TorchTransport(group)
         self.world, self.rank = self.tp.world, self.tp.rank
         # identical replicas: broadcast rank-0 weights and BN statistics once
         self.tp.broadcast(rt.w_train, src=0)
