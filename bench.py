@@ -265,7 +265,7 @@ def main():
         # fabric-side bytes of the same kernel set per step, from the committed PMC passes (separate rocprofv3
         # --pmc runs of scripts/dilated_bench.py at this very configuration; scripts/pmc_traffic.py)
         traffic, traffic_note = None, "PMC passes exist for the 512x512 bs16 configuration only"
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
         if args.batch == 16 and args.size == 512 and os.path.exists(tj) and not b16:
             with open(tj) as f:
                 tr = json.load(f)

@@ -11,6 +11,12 @@ import json
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
+# round 2: in the training step the weight planes are prepared ONCE per step for the whole model (sg_prepare_planes), the
+# per-launch split3_weights_kernel of this micro-benchmark no longer runs there.  --prepared leaves its bytes out of the
+# helpers and adds the six layers' share of the batched preparation instead (4 B read + 12 B written per weight: three bf16
+# planes for the forward and three for the dgrad orientation).
+PREPARED = "--prepared" in sys.argv
+N_WEIGHTS = 3 * 9 * 2048 * 256 + 3 * 9 * 256 * 256
 names = ["aspp_d6", "aspp_d12", "aspp_d18", "sk_d6", "sk_d12", "sk_d18"]
 out = {}
 for kind, mul in (("fetch", 2 * 1024), ("write", 1024)):
@@ -18,7 +24,7 @@ for kind, mul in (("fetch", 2 * 1024), ("write", 1024)):
     rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Dispatch_Id"]))
     ci = wi = 0
     per = {"fwd": {}, "dgrad": {}, "wgrad": {}}
-    helpers = 0.0
+    helpers = split = 0.0
     for r in rows:
         k, v = r["Kernel_Name"], float(r["Counter_Value"]) * mul
         if "igemm_conv_kernel" in k or "conv_x6_kernel" in k:  # per case: 3 forward launches (1 + warm-up + 1 timed), then 2 dgrad
@@ -27,12 +33,19 @@ for kind, mul in (("fetch", 2 * 1024), ("write", 1024)):
         elif "igemm_wgrad_kernel" in k or "wgrad_x6_kernel" in k:
             per["wgrad"].setdefault(wi // 2, []).append(v)
             wi += 1
+        elif PREPARED and "split3_weights" in k:
+            split += v
         elif "copyBuffer" not in k:
             helpers += v  # kernel transpose, split reduce, bias column sum: each runs twice
     o = {t: [sum(x) / len(x) for _, x in sorted(per[t].items())] for t in per}
     o["helpers_per_step"] = helpers / 2
+    if PREPARED:
+        o["per_launch_split_not_in_the_step"] = split / 2
+        o["prepare_share_per_step"] = N_WEIGHTS * (4 if kind == "fetch" else 12)
     out[kind] = o
 tot = sum(sum(out[k][t]) for k in out for t in ("fwd", "dgrad", "wgrad")) + out["fetch"]["helpers_per_step"] + out["write"]["helpers_per_step"]
+if PREPARED:
+    tot += out["fetch"]["prepare_share_per_step"] + out["write"]["prepare_share_per_step"]
 MiB = 2 ** 20
 alg = (3 * 3 * (128 + 18 + 16) + 3 * 3 * (16 + 2.25 + 16)) * MiB
 json.dump({"source": f"{src}/pmc_fetch + pmc_write: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 scripts/dilated_bench.py (ONLY_DILATED=1 ITERS=1)",
