@@ -1056,6 +1056,7 @@ void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false, int eb = 4) 
 #include "conv_x6.h"
 #include "conv_x6p.h"
 #include "conv_b16.h"
+#include "conv_x6wp.h"
 
 template <int NPL, typename TA>
 int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
@@ -1505,6 +1506,7 @@ struct WgradPlan {
   size_t bias_part_bytes;
   int chunks = 1;  // > 1: activations beyond 2 GiB are reduced as sub-batches of nb whole images, each with S splits
   int nb = 0;
+  int patch = 0;   // the patch form (conv_x6wp.h): S = its workgroup count, every workgroup writes one partial slab
 };
 
 // Split of the pixel reduction over S workgroups per tile.  Modelled time = MFMA work / (fraction of the
@@ -1531,6 +1533,15 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d, bool b16 = false) {
     pl.S = 1;
     pl.slabs_per_split = 0;
     pl.dw_part_bytes = thin_part_bytes(num_cus, d);
+    pl.bias_part_bytes = colsum_ws_bytes(num_cus, P, d->Cout);
+    return pl;
+  }
+  if (x6wp_geom(d) && (b16 || x6_enabled()) && (d->x_ld ? d->x_ld : d->Cin) % (b16 ? 8 : 4) == 0 &&
+      (d->y_ld ? d->y_ld : d->Cout) % (b16 ? 8 : 4) == 0) {
+    pl.patch = 1;
+    pl.S = x6wp_grid(num_cus, d);
+    pl.slabs_per_split = (int)sg_cdiv(sg_cdiv(P, BK), pl.S);  // for the slab kernels, should the launch fall back to them
+    pl.dw_part_bytes = pl.S > 1 ? (size_t)pl.S * K * d->Cout * 4 : 0;
     pl.bias_part_bytes = colsum_ws_bytes(num_cus, P, d->Cout);
     return pl;
   }
@@ -2060,7 +2071,10 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     return bias_grad();
   }
   const int K_all = d->KH * d->KW * d->Cin;
-  auto launch_part = [&](const sg_conv_desc& dd, const void* xs, const void* dys, float* out, int S, int sps) -> int {
+  // parts: in = the plan's S, out = the partial slabs actually written (a patch plan that has to fall back to the slab
+  // kernels - unaligned pointers - writes cdiv(slabs, slabs_per_split) <= S of them)
+  auto launch_part = [&](const sg_conv_desc& dd, const void* xs, const void* dys, float* out, int& parts, int sps) -> int {
+    int S = parts;
     WgradParams p;
     p.x = (const float*)xs;
     p.dy = (const float*)dys;
@@ -2081,6 +2095,21 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
       const int64_t yb = (((int64_t)p.P - 1) * p.y_ld + dd.Cout) * eb;
       p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
       p.dy_bytes = yb < (1ll << 31) ? (uint32_t)yb : 0;
+    }
+    if (pl.patch) {
+      const bool al = aligned16(xs) && aligned16(dys) && p.x_bytes != 0 && p.dy_bytes != 0 && !head32;
+      if (al) {
+        const int grid = x6wp_grid(ctx->num_cus, &dd);  // a last, smaller sub-batch may have fewer tiles than slots
+        parts = grid;
+        p.out = out;
+        if (b16) return launch_x6wp<1, bf16_t>(p, grid, st);
+        return x6_mode() == 2 ? launch_x6wp<1, float>(p, grid, st) : launch_x6wp<3, float>(p, grid, st);
+      }
+      const int nslab = (int)sg_cdiv((int64_t)p.P, BK);
+      sps = (int)sg_cdiv(nslab, S);
+      p.slabs_per_split = sps;
+      S = (int)sg_cdiv(nslab, sps);
+      parts = S;
     }
     if (b16 && head32) {  // x bf16, dy fp32 (not a thin 1x1 convolution)
       const int64_t yb32 = (((int64_t)p.P - 1) * p.y_ld + dd.Cout) * 4;
@@ -2105,18 +2134,22 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     // sub-batches of whole images, each writing its S partial slabs one after the other; one reduce over all of them
     const int64_t xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
     const int64_t slab = (int64_t)K_all * d->Cout;
+    total_parts = 0;
     for (int c = 0; c < pl.chunks; ++c) {
       sg_conv_desc sub = *d;
       const int n0 = c * pl.nb;
       sub.N = (d->N - n0 < pl.nb) ? d->N - n0 : pl.nb;
+      int parts = pl.S;
       rc = launch_part(sub, (const char*)x + (int64_t)n0 * d->H * d->W * xl * eb, (const char*)dy + (int64_t)n0 * d->Ho * d->Wo * yl * eb,
-                       (float*)ws + (int64_t)c * pl.S * slab, pl.S, pl.slabs_per_split);
+                       (float*)ws + (int64_t)total_parts * slab, parts, pl.slabs_per_split);
       if (rc) return rc;
+      total_parts += parts;
     }
-    total_parts = pl.chunks * pl.S;
   } else {
-    rc = launch_part(*d, x, dy, pl.S > 1 ? (float*)ws : (float*)dw, pl.S, pl.slabs_per_split);
+    int parts = pl.S;
+    rc = launch_part(*d, x, dy, pl.S > 1 ? (float*)ws : (float*)dw, parts, pl.slabs_per_split);
     if (rc) return rc;
+    total_parts = parts;
   }
   if (total_parts > 1) {
     const int64_t n = (int64_t)K_all * d->Cout;

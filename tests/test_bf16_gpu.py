@@ -47,6 +47,9 @@ CONV_CASES = [
     ("aspp_d6", 2, 32, 32, 2048, 256, 3, 1, 6),
     ("pw_728", 4, 32, 32, 728, 728, 1, 1, 1),
     ("c64_3x3", 2, 64, 64, 64, 64, 3, 1, 1),
+    ("c64_c32_3x3", 3, 96, 128, 64, 32, 3, 1, 1),     # patch-form wgrad, more tiles than workgroups
+    ("c32_c32_3x3", 2, 20, 48, 32, 32, 3, 1, 1),
+    ("c32_c64_3x3", 5, 12, 16, 32, 64, 3, 1, 1),
     ("vpad_304", 2, 32, 32, 304, 256, 3, 1, 1),     # Cin % 32 != 0: virtual channel padding
     ("vpad_48", 2, 64, 64, 48, 96, 3, 1, 1),
     ("s2_entry", 2, 64, 64, 32, 64, 3, 2, 1),        # stride 2: bf16-pipe forward/dgrad, fp32-MFMA wgrad fallback

@@ -66,6 +66,13 @@ CONV_CASES = [
     (3, 8, 16, 32, 64, 3, 1, 1, "patch_c32_n64_one_tile"),
     (1, 8, 32, 64, 128, 3, 1, 1, "patch_c64_n128"),
     (2, 16, 16, 32, 256, 3, 1, 1, "patch_c32_n256"),
+    # patch-form wgrad (conv_x6wp.h: 3x3 s1 d1, Cin and Cout in {32, 64}, H % 4 == 0, W % 16 == 0; the cases above with
+    # such shapes take it too): more tiles than workgroups (576 > 512: the persistent walk and its prefetch), H % 8 != 0
+    # (forward on the im2col kernel, wgrad on the patch one), every k-class split
+    (3, 96, 128, 64, 32, 3, 1, 1, "wpatch_c64_n32_576_tiles"),
+    (2, 20, 48, 32, 32, 3, 1, 1, "wpatch_c32_n32_h20"),
+    (5, 12, 16, 32, 64, 3, 1, 1, "wpatch_c32_n64"),
+    (1, 44, 80, 64, 64, 3, 1, 1, "wpatch_c64_n64"),
 ]
 
 
@@ -119,6 +126,11 @@ def test_conv2d_into_concat_slice(engine, hw):
     engine.conv2d_dgrad(buf.view(-1)[64:], wt.cuda(), d, out=dxb.view(-1)[16:])
     close(dxb[..., 16:48], xr.grad, what="slice dgrad")
     assert dxb[..., :16].abs().max().item() == 0 and dxb[..., 48:].abs().max().item() == 0
+    # wgrad from the same two slices (x_ld = 64, y_ld = 160; (16, 32): the patch-form kernel)
+    wr = wt.clone().requires_grad_()
+    T.conv2d(xs, wr, None, 1, 1, "same").backward(dy)
+    dw, _ = engine.conv2d_wgrad(xd.view(-1)[16:], buf.view(-1)[64:], d, want_bias=False)
+    close(dw, wr.grad, what="slice wgrad")
 
 
 @pytest.mark.parametrize("k,tag", [(3, "convT3"), (2, "convT2")])
