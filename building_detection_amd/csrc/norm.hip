@@ -45,7 +45,15 @@ struct BnStatsOp {
   }
 };
 
-template <typename T>
+// MODE: 0 = no fused ReLU, 1 = ReLU mask read from y, 2 = ReLU mask recomputed from x (gamma, beta given).  Compile-time,
+// and the per-channel parameters are loaded once per thread (BnCtx): the row loop is two loads (three in mode 1) and
+// arithmetic, four rows in flight.
+template <int V>
+struct BnCtx {
+  float mv[V], iv[V], gm[V], bt[V];
+};
+
+template <typename T, int MODE>
 struct BnBwdOp {
   static constexpr int NOUT = 2;  // sum dy, sum dy * xhat
   const T* __restrict__ x;
@@ -58,33 +66,36 @@ struct BnBwdOp {
   float* dgamma;
   float* dbeta;
   int C;
-  int relu;
 
   template <int V>
-  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[2][V]) const {
-    float xv[V], gv[V], mv[V], iv[V];
+  __device__ __forceinline__ BnCtx<V> begin(int, int c) const {
+    BnCtx<V> k;
+    ldv<V>(mean + c, k.mv);
+    ldv<V>(invstd + c, k.iv);
+    if constexpr (MODE == 2) {
+      ldv<V>(gamma + c, k.gm);
+      ldv<V>(beta + c, k.bt);
+    }
+    return k;
+  }
+  template <int V>
+  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[2][V], const BnCtx<V>& k) const {
+    float xv[V], gv[V];
     ldv<V>(x + r * C + c, xv);
     ldv<V>(dy + r * C + c, gv);
-    ldv<V>(mean + c, mv);
-    ldv<V>(invstd + c, iv);
-    if (relu) {
-      if (beta) {
-        float gm[V], bt[V];
-        ldv<V>(gamma + c, gm);
-        ldv<V>(beta + c, bt);
+    if constexpr (MODE == 2) {
 #pragma unroll
-        for (int i = 0; i < V; ++i) gv[i] = fmaf((xv[i] - mv[i]) * iv[i], gm[i], bt[i]) > 0.f ? gv[i] : 0.f;
-      } else {
-        float yv[V];
-        ldv<V>(y + r * C + c, yv);
+      for (int i = 0; i < V; ++i) gv[i] = fmaf((xv[i] - k.mv[i]) * k.iv[i], k.gm[i], k.bt[i]) > 0.f ? gv[i] : 0.f;
+    } else if constexpr (MODE == 1) {
+      float yv[V];
+      ldv<V>(y + r * C + c, yv);
 #pragma unroll
-        for (int i = 0; i < V; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
-      }
+      for (int i = 0; i < V; ++i) gv[i] = yv[i] > 0.f ? gv[i] : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       acc[0][i] += gv[i];
-      acc[1][i] = fmaf(gv[i], (xv[i] - mv[i]) * iv[i], acc[1][i]);
+      acc[1][i] = fmaf(gv[i], (xv[i] - k.mv[i]) * k.iv[i], acc[1][i]);
     }
   }
   __device__ __forceinline__ void finalize(int, int c, const double (&s)[2]) const {
@@ -121,12 +132,13 @@ __global__ void bn_apply_kernel(const T* __restrict__ x, const float* __restrict
   }
 }
 
-template <int V, typename T>
+// MODE as in BnBwdOp (compile-time: no load behind a branch)
+template <int V, typename T, int MODE>
 __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict__ y,
                                     const T* __restrict__ dy, const float* __restrict__ mean,
                                     const float* __restrict__ invstd, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ dgamma,
-                                    const float* __restrict__ dbeta, T* __restrict__ dx, int64_t rows, int C, int relu,
+                                    const float* __restrict__ dbeta, T* __restrict__ dx, int64_t rows, int C,
                                     FastDiv fd_cv) {
   const uint32_t cv = C / V;
   const uint32_t total = (uint32_t)(rows * cv);
@@ -143,18 +155,16 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
     ldv<V>(gamma + c, gam);
     ldv<V>(dgamma + c, dg);
     ldv<V>(dbeta + c, db);
-    if (relu) {
-      if (beta) {
-        float bt[V];
-        ldv<V>(beta + c, bt);
+    if constexpr (MODE == 2) {
+      float bt[V];
+      ldv<V>(beta + c, bt);
 #pragma unroll
-        for (int k = 0; k < V; ++k) gv[k] = fmaf((xv[k] - mv[k]) * iv[k], gam[k], bt[k]) > 0.f ? gv[k] : 0.f;
-      } else {
-        float yv[V];
-        ldv<V>(y + r * C + c, yv);
+      for (int k = 0; k < V; ++k) gv[k] = fmaf((xv[k] - mv[k]) * iv[k], gam[k], bt[k]) > 0.f ? gv[k] : 0.f;
+    } else if constexpr (MODE == 1) {
+      float yv[V];
+      ldv<V>(y + r * C + c, yv);
 #pragma unroll
-        for (int k = 0; k < V; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
-      }
+      for (int k = 0; k < V; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
     }
 #pragma unroll
     for (int k = 0; k < V; ++k) {
@@ -251,28 +261,33 @@ int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
   }
   hipStream_t st = (hipStream_t)stream;
   SG_DTYPE_SWITCH(dtype, "sg_bn_train_bwd", {
-    BnBwdOp<T> op;
-    op.x = (const T*)x; op.y = (const T*)y; op.dy = (const T*)dy;
-    op.mean = (const float*)save_mean; op.invstd = (const float*)save_invstd;
-    op.gamma = (const float*)gamma; op.beta = (const float*)beta;
-    op.dgamma = (float*)dgamma; op.dbeta = (float*)dbeta; op.C = C; op.relu = relu;
-    int rc = seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_bwd_reduce");
+    auto reduce = [&](auto op) -> int {
+      op.x = (const T*)x; op.y = (const T*)y; op.dy = (const T*)dy;
+      op.mean = (const float*)save_mean; op.invstd = (const float*)save_invstd;
+      op.gamma = (const float*)gamma; op.beta = (const float*)beta;
+      op.dgamma = (float*)dgamma; op.dbeta = (float*)dbeta; op.C = C;
+      return seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_bwd_reduce");
+    };
+    int rc = !relu ? reduce(BnBwdOp<T, 0>{}) : (beta ? reduce(BnBwdOp<T, 2>{}) : reduce(BnBwdOp<T, 1>{}));
     if (rc) return rc;
     const bool wide = vec && sizeof(T) == 2 && C % 8 == 0;
     const int V = wide ? 8 : (vec ? 4 : 1);
     const unsigned blocks = ew_blocks(rows * (C / V));
-    if (wide)
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<8, T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
+    const int mode = !relu ? 0 : (beta ? 2 : 1);
+    auto apply = [&](auto vt, auto mt) {
+      constexpr int V_ = decltype(vt)::value, M_ = decltype(mt)::value;
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, T, M_>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
                          (const float*)save_mean, (const float*)save_invstd, (const float*)gamma, (const float*)beta,
-                         (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));
-    else if (vec)
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<4, T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
-                         (const float*)save_mean, (const float*)save_invstd, (const float*)gamma, (const float*)beta,
-                         (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));
-    else
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<1, T>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
-                         (const float*)save_mean, (const float*)save_invstd, (const float*)gamma, (const float*)beta,
-                         (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, relu, make_fastdiv((uint32_t)(C / V)));
+                         (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, make_fastdiv((uint32_t)(C / V)));
+    };
+    auto apply_v = [&](auto vt) {
+      if (mode == 0) apply(vt, std::integral_constant<int, 0>{});
+      else if (mode == 1) apply(vt, std::integral_constant<int, 1>{});
+      else apply(vt, std::integral_constant<int, 2>{});
+    };
+    if (wide) apply_v(std::integral_constant<int, 8>{});
+    else if (vec) apply_v(std::integral_constant<int, 4>{});
+    else apply_v(std::integral_constant<int, 1>{});
     SG_LAUNCH_CHECK("bn_bwd_apply_kernel");
   });
   return 0;

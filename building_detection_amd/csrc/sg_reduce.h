@@ -10,7 +10,17 @@
 // (grid.z) the S partial rows are added in fixed order (in fp64) by the finalize kernel.  Results are
 // therefore bit-reproducible run to run (no float atomics).
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "sg_common.h"
+
+// An Op may carry per-thread constants through the row loop (per-channel parameters loaded once instead of once per
+// row): it then declares  template <int V> CtxType begin(int seg, int c) const  and takes the context as accum's last
+// argument.
+template <class Op, int V, class = void>
+struct seg_has_ctx : std::false_type {};
+template <class Op, int V>
+struct seg_has_ctx<Op, V, std::void_t<decltype(std::declval<const Op&>().template begin<V>(0, 0))>> : std::true_type {};
 
 template <class Op, int V>
 __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int64_t rows, const int C, const int S,
@@ -32,9 +42,19 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
     const int64_t rb = (int64_t)z * per;
     int64_t re = rb + per;
     if (re > rows) re = rows;
-    // four rows per trip so four independent 16-byte loads per operand are in flight per thread
-#pragma unroll 4
-    for (int64_t r = rb + ty; r < re; r += TY) op.template accum<V>(seg, r, c, acc);
+    // four rows per trip so four independent 16-byte loads per operand are in flight per thread (the accum bodies are
+    // branch-free for that reason: a run-time `if` around a load puts it in its own basic block behind a full wait)
+    // (Ops whose single row already keeps a few dozen loads in flight - the depthwise filter gradient - set NOUT >= 9 and
+    // are not unrolled: four interleaved rows would need 300 registers)
+    constexpr int UNR = NO >= 9 ? 1 : 4;
+    if constexpr (seg_has_ctx<Op, V>::value) {
+      const auto ctx = op.template begin<V>(seg, c);
+#pragma unroll UNR
+      for (int64_t r = rb + ty; r < re; r += TY) op.template accum<V>(seg, r, c, acc, ctx);
+    } else {
+#pragma unroll UNR
+      for (int64_t r = rb + ty; r < re; r += TY) op.template accum<V>(seg, r, c, acc);
+    }
   }
   float* mine = red + ((size_t)(ty * TX + tx)) * (NO * V);
 #pragma unroll

@@ -116,12 +116,15 @@ struct DwWgradOp {
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int iw = (int)ow * stride - pad_l + kw * dil;
-        if ((unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W) {
-          float xv[V];
-          ldv<V>(x + ((int64_t)(n * H + ih) * W + iw) * x_ld + c, xv);
+        // branch-free: a tap outside the image loads pixel (0, 0) of the image and is dropped by a select (nine loads in flight)
+        const bool ok = (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W;
+        float xv[V];
+        ldv<V>(x + ((int64_t)(n * H + (ok ? ih : 0)) * W + (ok ? iw : 0)) * x_ld + c, xv);
 #pragma unroll
-          for (int k = 0; k < V; ++k)
-            acc[kh * 3 + kw][k] = fmaf(pre_relu ? fmaxf(xv[k], 0.f) : xv[k], gv[k], acc[kh * 3 + kw][k]);
+        for (int k = 0; k < V; ++k) {
+          const float xr = pre_relu ? fmaxf(xv[k], 0.f) : xv[k];
+          const float a = fmaf(xr, gv[k], acc[kh * 3 + kw][k]);
+          acc[kh * 3 + kw][k] = ok ? a : acc[kh * 3 + kw][k];
         }
       }
     }
@@ -149,9 +152,12 @@ struct DwRunParams {
 };
 
 // RR output rows per run: the (RR + 2) x 6 input window is loaded once for RR x 4 outputs - 4.5 loads per output
-// at RR = 1, 2.25 at RR = 4 (fd_h divides by H / RR then)
-template <int RR, typename T>
-__global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams<T> p) {
+// at RR = 1, 2.25 at RR = 4 (fd_h divides by H / RR then).
+// RELU / MASK are compile-time and the window is branch-free (rows and columns outside the image load a valid address
+// and are zeroed by a select): with the run-time `if (relu_in)` and the `continue` on the row test every load sat in its
+// own basic block behind an s_waitcnt vmcnt(0) - 18..36 serialised memory latencies per run.
+template <int RR, typename T, bool RELU, bool MASK>
+__global__ __launch_bounds__(256, 3) void dw_s1_run_kernel(const DwRunParams<T> p) {
   // p.lc lanes (a power of two <= 64) cover the channel chunks of one run; with few channels (C = 64: 16 chunks)
   // a wave takes several runs instead of idling three quarters of its lanes
   const int lc = p.lc, rpb = 256 / lc;
@@ -166,6 +172,7 @@ __global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams<T> p) 
     fd_divmod((uint32_t)run, p.fd_rpr, rowi, q);
     fd_divmod(rowi, p.fd_h, n, ohb);
     const int ow0 = (int)q * 4, oh0 = (int)ohb * RR;
+    const bool lok = ow0 > 0, rok = ow0 + 4 < p.W;   // the window's first / last column lies inside the image
     f32x4 acc[RR][4];
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr)
@@ -174,16 +181,16 @@ __global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams<T> p) 
 #pragma unroll
     for (int a = 0; a < RR + 2; ++a) {
       const int ih = oh0 - 1 + a;
-      if ((unsigned)ih >= (unsigned)p.H) continue;
-      const T* rowp = p.in + ((int64_t)(n * p.H + ih) * p.W) * p.in_ld + c;
+      const bool rowok = (a >= 1 && a <= RR) || (unsigned)ih < (unsigned)p.H;  // the RR middle rows always are
+      const T* rowp = p.in + ((int64_t)(n * p.H + (rowok ? ih : oh0)) * p.W + ow0) * p.in_ld + c;
       f32x4 v[6];
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        const int iw = ow0 - 1 + b;
-        const bool ok = (unsigned)iw < (unsigned)p.W;
-        const f32x4 t = ld4<T>(rowp + (int64_t)(ok ? iw : 0) * p.in_ld);
+        const bool ok = rowok && (b == 0 ? lok : (b == 5 ? rok : true));
+        const int db = (b == 0 && !lok) ? 0 : ((b == 5 && !rok) ? 3 : b - 1);   // a valid column when masked
+        const f32x4 t = ld4<T>(rowp + (int64_t)db * p.in_ld);
         v[b] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (p.relu_in) {
+        if constexpr (RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[b][e] = fmaxf(v[b][e], 0.f);
         }
@@ -202,13 +209,17 @@ __global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams<T> p) 
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
       const int64_t opix = ((int64_t)(n * p.H + oh0 + rr) * p.W + ow0);
+      f32x4 m[4];
+      if constexpr (MASK) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) m[k] = ld4<T>(p.mask + (opix + k) * p.mask_ld + c);
+      }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         f32x4 o = acc[rr][k];
-        if (p.mask) {
-          const f32x4 m = ld4<T>(p.mask + (opix + k) * p.mask_ld + c);
+        if constexpr (MASK) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = m[e] > 0.f ? o[e] : 0.f;
+          for (int e = 0; e < 4; ++e) o[e] = m[k][e] > 0.f ? o[e] : 0.f;
         }
         st4<T>(p.out + (opix + k) * p.out_ld + c, o);
       }
@@ -216,14 +227,16 @@ __global__ __launch_bounds__(256) void dw_s1_run_kernel(const DwRunParams<T> p) 
   }
 }
 
-// wgrad, same window: a "row" of the segmented reducer is a run of RR rows x 4 output pixels
-template <int RR, typename T>
+// wgrad, same window: a "row" of the segmented reducer is a run of RR rows x 4 output pixels.  Branch-free like the
+// stencil above (PRE compile-time, rows / columns outside the image masked by a select): 22 loads of a run in flight
+// together instead of one at a time.
+template <int RR, typename T, bool PRE>
 struct DwWgradRunOp {
   static constexpr int NOUT = 9;
   const T* __restrict__ x;
   const T* __restrict__ dy;
   float* dw;
-  int H, W, C, x_ld, y_ld, pre_relu;
+  int H, W, C, x_ld, y_ld;
   FastDiv fd_rpr, fd_h;
   template <int V>
   __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[9][V]) const {
@@ -234,6 +247,7 @@ struct DwWgradRunOp {
     fd_divmod((uint32_t)r, fd_rpr, rowi, q);
     fd_divmod(rowi, fd_h, n, ohb);
     const int ow0 = (int)q * 4, oh0 = (int)ohb * RR;
+    const bool lok = ow0 > 0, rok = ow0 + 4 < W;
     f32x4 g[RR][4];
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
@@ -244,16 +258,16 @@ struct DwWgradRunOp {
 #pragma unroll
     for (int a = 0; a < RR + 2; ++a) {
       const int ih = oh0 - 1 + a;
-      if ((unsigned)ih >= (unsigned)H) continue;
-      const T* rowp = x + ((int64_t)(n * H + ih) * W) * x_ld + c;
+      const bool rowok = (a >= 1 && a <= RR) || (unsigned)ih < (unsigned)H;
+      const T* rowp = x + ((int64_t)(n * H + (rowok ? ih : oh0)) * W + ow0) * x_ld + c;
       f32x4 v[6];
 #pragma unroll
       for (int b = 0; b < 6; ++b) {
-        const int iw = ow0 - 1 + b;
-        const bool ok = (unsigned)iw < (unsigned)W;
-        const f32x4 t = ld4<T>(rowp + (int64_t)(ok ? iw : 0) * x_ld);
+        const bool ok = rowok && (b == 0 ? lok : (b == 5 ? rok : true));
+        const int db = (b == 0 && !lok) ? 0 : ((b == 5 && !rok) ? 3 : b - 1);
+        const f32x4 t = ld4<T>(rowp + (int64_t)db * x_ld);
         v[b] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (pre_relu) {
+        if constexpr (PRE) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[b][e] = fmaxf(v[b][e], 0.f);
         }
@@ -308,9 +322,21 @@ int launch_dw_run(const DwRunParams<T>& p_in, hipStream_t st) {
   const int64_t cap = sg_cdiv(16384, gx);
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
-  if (rr == 4) hipLaunchKernelGGL((dw_s1_run_kernel<4, T>), dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
-  else if (rr == 2) hipLaunchKernelGGL((dw_s1_run_kernel<2, T>), dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL((dw_s1_run_kernel<1, T>), dim3(gx, (unsigned)gy), dim3(256), 0, st, p);
+  const dim3 grid(gx, (unsigned)gy);
+#define SG_DW_RUN(RR_)                                                                                                  \
+  do {                                                                                                                  \
+    if (p.mask) hipLaunchKernelGGL((dw_s1_run_kernel<RR_, T, false, true>), grid, dim3(256), 0, st, p);                 \
+    else if (p.relu_in) hipLaunchKernelGGL((dw_s1_run_kernel<RR_, T, true, false>), grid, dim3(256), 0, st, p);         \
+    else hipLaunchKernelGGL((dw_s1_run_kernel<RR_, T, false, false>), grid, dim3(256), 0, st, p);                       \
+  } while (0)
+  if (p.mask && p.relu_in) {
+    sg_set_error("dw_s1_run: mask and relu_in together");
+    return SG_EINVAL;
+  }
+  if (rr == 4) SG_DW_RUN(4);
+  else if (rr == 2) SG_DW_RUN(2);
+  else SG_DW_RUN(1);
+#undef SG_DW_RUN
   SG_LAUNCH_CHECK("dw_s1_run_kernel");
   return 0;
 }
@@ -637,13 +663,18 @@ int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
       }
       auto run = [&](auto ro) -> int {
         ro.x = (const T*)x; ro.dy = (const T*)dy; ro.dw = (float*)dw; ro.H = d->H; ro.W = d->W; ro.C = op.C;
-        ro.x_ld = op.x_ld; ro.y_ld = op.y_ld; ro.pre_relu = pre_relu;
+        ro.x_ld = op.x_ld; ro.y_ld = op.y_ld;
         ro.fd_rpr = make_fastdiv((uint32_t)(d->W / 4)); ro.fd_h = make_fastdiv((uint32_t)(d->H / rr));
         return seg_reduce_launch(ro, rp, 1, nruns, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad_run");
       };
-      if (rr == 4) return run(DwWgradRunOp<4, T>{});
-      if (rr == 2) return run(DwWgradRunOp<2, T>{});
-      return run(DwWgradRunOp<1, T>{});
+      if (pre_relu) {
+        if (rr == 4) return run(DwWgradRunOp<4, T, true>{});
+        if (rr == 2) return run(DwWgradRunOp<2, T, true>{});
+        return run(DwWgradRunOp<1, T, true>{});
+      }
+      if (rr == 4) return run(DwWgradRunOp<4, T, false>{});
+      if (rr == 2) return run(DwWgradRunOp<2, T, false>{});
+      return run(DwWgradRunOp<1, T, false>{});
     }
     const SegPlan pl = seg_plan<9>(ctx->num_cus, 1, rows, op.C, vec);
     if (!ws || ws_bytes < pl.part_bytes) {
