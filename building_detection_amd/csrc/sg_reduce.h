@@ -10,6 +10,8 @@
 // (grid.z) the S partial rows are added in fixed order (in fp64) by the finalize kernel.  Results are
 // therefore bit-reproducible run to run (no float atomics).
 #pragma once
+#include <cstdlib>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 #include "sg_common.h"
@@ -22,9 +24,16 @@ struct seg_has_ctx : std::false_type {};
 template <class Op, int V>
 struct seg_has_ctx<Op, V, std::void_t<decltype(std::declval<const Op&>().template begin<V>(0, 0))>> : std::true_type {};
 
+// `fuse`: the LAST workgroup of a (segment, column block) to finish - found with one agent-scope counter per column
+// block, cnt[seg * gridDim.x + blockIdx.x], zero before the launch and reset by that workgroup - also does the second
+// stage for its channels (same lanes, same order of additions as seg_finalize_kernel: bit-identical), so that the
+// few-microsecond finalize launch behind every reduction disappears.  The partial rows travel between workgroups (and
+// XCDs, whose L2s are not coherent) by release / acquire at agent scope: __threadfence() before the counter increment
+// writes this workgroup's partials back, __threadfence() after it invalidates the reader's caches.  With S == 1 there is
+// nothing to wait for and no counter.
 template <class Op, int V>
 __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int64_t rows, const int C, const int S,
-                                                         float* __restrict__ part) {
+                                                         float* __restrict__ part, unsigned* __restrict__ cnt, const int fuse) {
   constexpr int NO = Op::NOUT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* red = reinterpret_cast<float*>(smem_raw);  // [TY][TX][NO*V]
@@ -71,6 +80,55 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
         for (int y = 0; y < TY; ++y) s += red[((size_t)(y * TX + tx)) * (NO * V) + o * V + v];
         if (c + v < C) part[(((int64_t)seg * S + z) * NO + o) * C + c + v] = s;
       }
+  }
+  if (!fuse) return;
+  if (S > 1) {
+    __shared__ int s_last;
+    __threadfence();  // release: this workgroup's partial row is visible device-wide before its arrival is counted
+    __syncthreads();
+    if (tx == 0 && ty == 0) {
+      unsigned* slot = cnt + (size_t)seg * gridDim.x + blockIdx.x;
+      const unsigned prev = atomicAdd(slot, 1u);
+      s_last = (prev == (unsigned)S - 1u) ? 1 : 0;
+      if (s_last) atomicExch(slot, 0u);  // every other workgroup of this column block has already arrived
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();  // acquire: the other workgroups' partial rows, not stale cache lines
+  } else {
+    __syncthreads();  // S == 1: the partial row just written by this workgroup's ty == 0 threads
+  }
+  // second stage for the TX * V channels of this column block, 64 at a time: lane zl of channel fx adds the partial rows
+  // z = zl, zl + 4, .. in fp64, the four lane sums are combined ((0 + 1) + 2) + 3 - exactly seg_finalize_kernel
+  double* dred = reinterpret_cast<double*>(smem_raw);  // [4][64][NO]
+  const int tid = ty * TX + tx, fx = tid & 63, zl = tid >> 6;
+  const int nch = TX * V, cb = blockIdx.x * nch;
+  const float* __restrict__ rd = part;
+  for (int ch0 = 0; ch0 < nch; ch0 += 64) {
+    const int cc = cb + ch0 + fx;
+    const bool act = (ch0 + fx < nch) && cc < C;
+    double sum[NO];
+#pragma unroll
+    for (int o = 0; o < NO; ++o) sum[o] = 0.0;
+    if (act) {
+      constexpr int UNROLL = NO <= 2 ? 8 : 1;
+#pragma unroll UNROLL
+      for (int z2 = zl; z2 < S; z2 += 4) {
+        const float* q = rd + (((int64_t)seg * S + z2) * NO) * C + cc;
+#pragma unroll
+        for (int o = 0; o < NO; ++o) sum[o] += (double)q[(int64_t)o * C];
+      }
+    }
+    __syncthreads();  // the first stage's (or the previous 64 channels') use of the LDS buffer is over
+#pragma unroll
+    for (int o = 0; o < NO; ++o) dred[(zl * 64 + fx) * NO + o] = sum[o];
+    __syncthreads();
+    if (zl == 0 && act) {
+#pragma unroll
+      for (int o = 0; o < NO; ++o)
+        sum[o] = ((dred[(0 * 64 + fx) * NO + o] + dred[(1 * 64 + fx) * NO + o]) + dred[(2 * 64 + fx) * NO + o]) + dred[(3 * 64 + fx) * NO + o];
+      op.finalize(seg, cc, sum);
+    }
   }
 }
 
@@ -133,6 +191,9 @@ static inline SegPlan seg_plan(int num_cus, int nseg, int64_t rows, int C, bool 
   int64_t S = sg_cdiv((int64_t)4 * num_cus, (int64_t)pl.gx);
   const int64_t maxS = sg_cdiv(rows, (int64_t)pl.TY * 4);
   if (S > maxS) S = maxS;
+  // short segments (<= 16 rows per thread: the per-tile BatchNorm statistics, pooled maps, gates): one workgroup per
+  // column block, which then finalises its channels itself - one launch of a few microseconds instead of two
+  if (rows <= (int64_t)pl.TY * 16) S = 1;
   if (S > 1024) S = 1024;  // few-channel maps at full resolution (C = 32: one column block) need the row split
                            // for occupancy: 1024 workgroups = 4 per CU
   if (S < 1) S = 1;
@@ -141,23 +202,67 @@ static inline SegPlan seg_plan(int num_cus, int nseg, int64_t rows, int C, bool 
   return pl;
 }
 
-// Launch reduce + finalize.  `part` must hold pl.part_bytes.
+// Arrival counters of the fused second stage: n zeroed words out of a per-device ring (this translation unit's own).
+// The kernels leave their words zero again, and launches that may overlap (different streams, captured graphs) sit at
+// different ring positions; nullptr (too many column blocks, no device memory, allocation refused inside a stream capture)
+// sends the launch down the two-kernel path.
+static inline unsigned* seg_counters(int64_t n) {
+  constexpr unsigned RING = 1u << 18;  // words: 1 MiB
+  struct Ring { unsigned* buf = nullptr; unsigned pos = 0; bool failed = false; };
+  static Ring ring[16];
+  static std::mutex mu;
+  int dev = 0;
+  if (n < 1 || n > 8192 || hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  std::lock_guard<std::mutex> lk(mu);
+  Ring& r = ring[dev];
+  if (!r.buf) {
+    if (r.failed) return nullptr;
+    unsigned* q = nullptr;
+    if (hipMalloc(&q, (size_t)RING * 4) != hipSuccess || hipMemset(q, 0, (size_t)RING * 4) != hipSuccess) {
+      (void)hipGetLastError();
+      if (q) (void)hipFree(q);
+      r.failed = true;
+      return nullptr;
+    }
+    r.buf = q;
+  }
+  if (r.pos + (unsigned)n > RING) r.pos = 0;
+  unsigned* out = r.buf + r.pos;
+  r.pos += (unsigned)n;
+  return out;
+}
+
+// Launch the reduction (second stage fused into it, see seg_reduce_kernel; SG_SEG_FUSED=0: separate finalize launch).
+// `part` must hold pl.part_bytes.
 template <class Op>
 static inline int seg_reduce_launch(const Op& op, const SegPlan& pl, int nseg, int64_t rows, int C, float* part,
                                     hipStream_t st, const char* name) {
   if (nseg <= 0 || rows <= 0 || C <= 0) return 0;
-  const size_t lds = (size_t)256 * Op::NOUT * pl.V * sizeof(float);
+  // SG_SEG_FUSED: 0 = always the separate finalize launch, 1 (default) = fused when S == 1 (no communication between
+  // workgroups), 2 = fused for every S through the arrival counters.  Mode 2 is correct (full GPU suite) but a LOSS on this
+  // part: the agent-scope release / acquire pair makes every workgroup write back and invalidate its XCD's whole L2 -
+  // which holds the previous kernel's output, i.e. this kernel's input - and the DeepLabv3+ step went 86 -> 117 ms (fp32),
+  // 39 -> 63 ms (bf16).  Kept for re-measurement only.
+  static const int fused_mode = getenv("SG_SEG_FUSED") ? atoi(getenv("SG_SEG_FUSED")) : 1;
+  unsigned* cnt = nullptr;
+  int fuse = 0;
+  if (fused_mode >= 1 && pl.S == 1) fuse = 1;
+  else if (fused_mode >= 2 && (cnt = seg_counters((int64_t)nseg * pl.gx)) != nullptr) fuse = 1;
+  const size_t lds1 = (size_t)256 * Op::NOUT * pl.V * sizeof(float), lds2 = (size_t)4 * 64 * Op::NOUT * sizeof(double);
+  const size_t lds = lds1 > lds2 ? lds1 : lds2;
   dim3 grid((unsigned)pl.gx, (unsigned)nseg, (unsigned)pl.S), block((unsigned)pl.TX, (unsigned)pl.TY);
   if (pl.V == 8) {
-    if constexpr (Op::NOUT <= 2) hipLaunchKernelGGL((seg_reduce_kernel<Op, 8>), grid, block, lds, st, op, rows, C, pl.S, part);
+    if constexpr (Op::NOUT <= 2) hipLaunchKernelGGL((seg_reduce_kernel<Op, 8>), grid, block, lds, st, op, rows, C, pl.S, part, cnt, fuse);
   } else if (pl.V == 4)
-    hipLaunchKernelGGL((seg_reduce_kernel<Op, 4>), grid, block, lds, st, op, rows, C, pl.S, part);
+    hipLaunchKernelGGL((seg_reduce_kernel<Op, 4>), grid, block, lds, st, op, rows, C, pl.S, part, cnt, fuse);
   else
-    hipLaunchKernelGGL((seg_reduce_kernel<Op, 1>), grid, block, lds, st, op, rows, C, pl.S, part);
+    hipLaunchKernelGGL((seg_reduce_kernel<Op, 1>), grid, block, lds, st, op, rows, C, pl.S, part, cnt, fuse);
   SG_LAUNCH_CHECK(name);
-  hipLaunchKernelGGL((seg_finalize_kernel<Op>), dim3((unsigned)sg_cdiv(C, 64), (unsigned)nseg), dim3(256), 0, st, op, nseg,
-                     C, pl.S, (const float*)part);
-  SG_LAUNCH_CHECK(name);
+  if (!fuse) {
+    hipLaunchKernelGGL((seg_finalize_kernel<Op>), dim3((unsigned)sg_cdiv(C, 64), (unsigned)nseg), dim3(256), 0, st, op, nseg,
+                       C, pl.S, (const float*)part);
+    SG_LAUNCH_CHECK(name);
+  }
   return 0;
 }
 
