@@ -26,7 +26,13 @@ struct B16L {
   __device__ static __forceinline__ int swz(int row) { return (row >> WSH) & (CPR - 1); }
 };
 
-template <int BN, int WGM, int WGN, int KS>
+// PD = register sets of prefetched slabs (1 or 2; SG_B16_PD, default 1).  Two sets (the loads of slab s + 2 in flight as
+// well) were built on the theory that short-K layers run at the memory latency; measured (profiles/r02_b16_prefetch_ab.txt)
+// they help the ASPP forward (308 -> 280 us) and cost everywhere else (728 -> 728: 38 -> 41 us, 304 -> 256 3x3: 528 -> 578 us,
+// occupancy 6 -> 4 waves per SIMD).  The timing ablations of the same file say why: of the 728 -> 728 layer's 40 us, 12.5 are
+// the two launches and the prologue, 3 the epilogue, and the K loop's 24 us are ~15 us of operand delivery alone (286 MB from
+// L2 to the CUs: A six times, the weights 128 times) - it is bound by the L2 -> CU path, not by latency or the matrix pipe.
+template <int BN, int WGM, int WGN, int KS, int PD = 1>
 __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel(const IgemmParams p) {
   using L = B16L<KS>;
   constexpr int BKB = L::BKB, RB = L::RB, CPR = L::CPR;
@@ -115,8 +121,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
   const __amdgpu_buffer_rsrc_t rsrc_w =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wq), 0, (int)p.w_bytes, 0x00020000);
 
-  u32x4_t ra[NA], rb[NB];
-  auto load_AB = [&](int k0) {
+  u32x4_t ra[PD][NA], rb[PD][NB];
+  auto load_AB = [&](int k0, auto SET) {
+    constexpr int S = decltype(SET)::value;
     const int tap = (int)fd_div((uint32_t)k0, p.fd_c);
     if (tap != cur_tap) {  // uniform
       cur_tap = tap;
@@ -134,23 +141,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
     const bool kvalid = !ktail || (k0 + 8 * kc < p.K);
 #pragma unroll
     for (int j = 0; j < NA; ++j)
-      ra[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
+      ra[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
     const int soff_b = k0 * 2;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
+    for (int i = 0; i < NB; ++i) rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
   };
-  auto store_AB = [&]() {
+  auto store_AB = [&](auto SET) {
+    constexpr int S = decltype(SET)::value;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const int arow = r0 + RS * j;
-      *reinterpret_cast<u32x4_t*>(Ap + arow * RB + ((kc ^ L::swz(arow)) << 4)) = ra[j];
+      *reinterpret_cast<u32x4_t*>(Ap + arow * RB + ((kc ^ L::swz(arow)) << 4)) = ra[S][j];
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
       const int idx = t + NT * i;
       if ((NBC % NT == 0) || idx < NBC) {
         const int row = idx / CPR, c = idx % CPR;
-        *reinterpret_cast<u32x4_t*>(Bp + row * RB + ((c ^ L::swz(row)) << 4)) = rb[i];
+        *reinterpret_cast<u32x4_t*>(Bp + row * RB + ((c ^ L::swz(row)) << 4)) = rb[S][i];
       }
     }
   };
@@ -246,13 +254,44 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
   };
 
   if (nslab > 0) {
-    load_AB(next_k0());
-    for (int s = 0; s < nslab; ++s) {
-      __syncthreads();  // every wave has finished reading the previous slab
-      store_AB();
-      __syncthreads();
-      load_AB(next_k0());  // the tail reloads the last slab (unused): no branch
-      compute();
+    if constexpr (PD == 1) {
+      load_AB(next_k0(), IC<0>{});
+#ifdef SG_B16_ABL  // experiment build (make ABL=1): timing-only ablations, results wrong; p.ablate from SG_B16_ABLATE
+      const bool ab_ld = (p.ablate & 1) != 0, ab_st = (p.ablate & 2) != 0, ab_mm = (p.ablate & 4) != 0;
+      for (int s = 0; s < nslab; ++s) {
+        if (!ab_st) {
+          __syncthreads();
+          store_AB(IC<0>{});
+          __syncthreads();
+        }
+        if (!ab_ld) load_AB(next_k0(), IC<0>{});
+        if (!ab_mm) compute();
+      }
+#else
+      for (int s = 0; s < nslab; ++s) {
+        __syncthreads();  // every wave has finished reading the previous slab
+        store_AB(IC<0>{});
+        __syncthreads();
+        load_AB(next_k0(), IC<0>{});  // the tail reloads the last slab (unused): no branch
+        compute();
+      }
+#endif
+    } else {
+      load_AB(next_k0(), IC<0>{});
+      load_AB(next_k0(), IC<1>{});
+      for (int s = 0; s < nslab; s += 2) {
+        __syncthreads();
+        store_AB(IC<0>{});
+        __syncthreads();
+        load_AB(next_k0(), IC<0>{});  // slab s + 2 (the tail reloads the last slab, unused)
+        compute();
+        if (s + 1 >= nslab) break;
+        __syncthreads();
+        store_AB(IC<1>{});
+        __syncthreads();
+        load_AB(next_k0(), IC<1>{});
+        compute();
+      }
     }
   }
 
@@ -283,6 +322,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
     }
     __syncthreads();
     constexpr int CPT = BN / 8;  // 16-byte chunks per tile row
+#ifdef SG_B16_ABL
+    if (!(p.ablate & 8))
+#endif
     for (int idx = t; idx < BM * CPT; idx += NT) {
       const int rl = idx / CPT, c = idx - rl * CPT;
       const int row = m0 + rl, col = n0 + 8 * c;
@@ -350,8 +392,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
   }
 }
 
-template <int BN, int WGM, int WGN, int KS>
-int launch_b16(const IgemmParams& p, hipStream_t st) {
+template <int BN, int WGM, int WGN, int KS, int PD>
+int launch_b16_pd(const IgemmParams& p, hipStream_t st) {
   constexpr int NT = 64 * WGM * WGN;
   constexpr size_t slab_lds = (size_t)(BM + BN) * B16L<KS>::RB;
   constexpr size_t stat_lds = (size_t)(WGM + 1) * BN * sizeof(float);
@@ -361,7 +403,7 @@ int launch_b16(const IgemmParams& p, hipStream_t st) {
   (void)NT;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(conv_b16_kernel<BN, WGM, WGN, KS>, lds);
+    int rc = set_dyn_lds(conv_b16_kernel<BN, WGM, WGN, KS, PD>, lds);
     if (rc) return rc;
     attr_done = true;
   }
@@ -370,9 +412,16 @@ int launch_b16(const IgemmParams& p, hipStream_t st) {
     sg_set_error("conv_b16: bad tile count %lld", (long long)tiles);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL((conv_b16_kernel<BN, WGM, WGN, KS>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((conv_b16_kernel<BN, WGM, WGN, KS, PD>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("conv_b16_kernel");
   return 0;
+}
+
+// SG_B16_PD = 2: two register sets of prefetched slabs (A/B switch), default 1
+template <int BN, int WGM, int WGN, int KS>
+int launch_b16(const IgemmParams& p, hipStream_t st) {
+  static const int pd = getenv("SG_B16_PD") ? atoi(getenv("SG_B16_PD")) : 1;
+  return pd == 2 ? launch_b16_pd<BN, WGM, WGN, KS, 2>(p, st) : launch_b16_pd<BN, WGM, WGN, KS, 1>(p, st);
 }
 
 // slab depth (k-steps of 16) for a launch whose taps are `c` channels deep: the deepest of 8 / 4 / 2 that keeps every slab
@@ -393,6 +442,9 @@ inline int dispatch_b16(const IgemmParams& p_in, int num_cus, hipStream_t st) {
   plan_common(p, true, bn, true, 2);
   p.stagger = 0;
   p.ablate = 0;
+#ifdef SG_B16_ABL
+  p.ablate = getenv("SG_B16_ABLATE") ? atoi(getenv("SG_B16_ABLATE")) : 0;
+#endif
   const int ks = b16_ks(p.C, p.K == p.C);
   if (bn == 128) {
     if (ks == 8) return launch_b16<128, 2, 4, 8>(p, st);

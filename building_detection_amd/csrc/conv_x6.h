@@ -785,6 +785,8 @@ struct X6WPitch {
 // and the loads of slab s+3 woven into the MFMA gaps of slab s).
 // NPL / TA as in conv_x6_kernel: NPL = 1 is the bf16 product (one plane, one MFMA per k-step and tile); with TA = bf16_t
 // both operands are bf16 in HBM and a thread's 16-byte chunk (8 channels) goes to LDS unchanged.
+constexpr int WG_NS = 1;  // register sets of the bf16 wgrad: 2 measured no faster (728 -> 728: 55 us either way,
+                          // profiles/r02_b16_prefetch_ab.txt), 4 spills at BN = 128
 template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float>
 __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM * WGN / 2) void wgrad_x6_kernel(const WgradParams p) {
   static_assert(NPL == 3 || NPL == 1, "planes");
@@ -869,7 +871,11 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     b_voff[i] = (idx < NBC && (n0 + CH * c4) < p.Cout) ? (unsigned)(kr * p.y_ld + n0 + CH * c4) * (unsigned)EB : OOB;
   }
 
-  u32x4_t ra[PF][NA], rb[PF][NB];
+  // NS register sets of prefetched slabs.  The bf16-storage form has 4 MFMAs per wave and slab against a memory latency of
+  // several slab times: it keeps WG_NS slabs of loads in flight (a set is two 16-byte registers there); the six-pass form
+  // (24 MFMAs per slab, 24 registers per set) keeps one, or two with the double-buffered structure.
+  constexpr int NS = (PF == 1 && NPL == 1 && A16) ? WG_NS : PF;
+  u32x4_t ra[NS][NA], rb[NS][NB];
   auto load_AB = [&](int p0, auto SET) {
     constexpr int S = decltype(SET)::value;
     uint32_t q, ow0, n_, oh;
@@ -1010,7 +1016,33 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   if (nslab > 0) {
     // p.stagger carries SG_X6_ABLATE here (timing-only diagnostics, results wrong): 1 = no global loads in the loop,
     // 2 = no split + LDS store + barriers, 4 = no fragment reads + MFMAs
-    if constexpr (PF == 1) {
+    if constexpr (PF == 1 && NS > 1) {
+      auto slab_at = [&](int i) -> int { return slab_of(i < lasti ? i : lasti) * BK; };
+      auto step = [&](auto SET, int s) {
+        __syncthreads();
+        store_AB(SET, 0);
+        __syncthreads();
+        load_AB(slab_at(s + NS), SET);  // past the end: the last slab again (unused)
+        compute(0);
+      };
+      load_AB(slab_at(0), IC<0>{});
+      load_AB(slab_at(1), IC<1>{});
+      if constexpr (NS == 4) {
+        load_AB(slab_at(2), IC<2>{});
+        load_AB(slab_at(3), IC<3>{});
+      }
+      for (int s = 0; s < nslab; s += NS) {
+        step(IC<0>{}, s);
+        if (s + 1 >= nslab) break;
+        step(IC<1>{}, s + 1);
+        if constexpr (NS == 4) {
+          if (s + 2 >= nslab) break;
+          step(IC<2>{}, s + 2);
+          if (s + 3 >= nslab) break;
+          step(IC<3>{}, s + 3);
+        }
+      }
+    } else if constexpr (PF == 1) {
       const bool do_ld = !(p.stagger & 1), do_st = !(p.stagger & 2), do_mm = !(p.stagger & 4);
       load_AB(slab_of(0) * BK, IC<0>{});
       for (int s = 0; s < nslab; ++s) {
