@@ -68,6 +68,24 @@ _TRACE_MARK = os.environ.get("SG_TRACE_MARK", "0") == "1"
 _MARK_TAGS = {"dilated_conv": 0, "gemm_conv": 1}
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (lambda i: torch.cuda.current_stream(i).cuda_stream)
+
+
+class _NoTimer:
+    """`with eng.timed(tag)` while no profile is open: nothing to do, nothing to allocate."""
+
+    __slots__ = ()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+_NO_TIMER = _NoTimer()
+
+
 class _Timed:
     """`with eng.timed(tag):` brackets the launches inside with two HIP events on the current stream while a
     profile is open (eng.profile_begin()); otherwise it is free."""
@@ -108,6 +126,9 @@ class Engine:
         self.ctx = _lib.Context(device)
         self.h = self.ctx.handle
         self.device = torch.device("cuda", device)
+        self._dev_index = int(device)
+        self._prof = None       # open profile: tag -> [(event, event)] (profile_begin / profile_end)
+        self._prof_all = False
         self._ws = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
         self._ws_peak = 0          # largest workspace request seen (GraphedPredict sizes its private buffer by it)
         self._ws_pinned = False    # True while a private workspace is installed: growth is an error, not a realloc
@@ -119,7 +140,9 @@ class Engine:
     # ------------------------------------------------------------------------------------------ plumbing
     @property
     def stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        # torch's CURRENT stream of this device (a hipGraph capture swaps it), by the raw-handle call: one C call instead of
+        # building a torch.cuda.Stream object per launch (~1800 launches per training step)
+        return C.c_void_p(_raw_stream(self._dev_index))
 
     def ws(self, nbytes: int):
         nbytes = int(nbytes)
@@ -153,7 +176,7 @@ class Engine:
         self._prof_all = bool(all_convs)
 
     def _gemm_tag(self):
-        return "gemm_conv" if getattr(self, "_prof_all", False) and getattr(self, "_prof", None) is not None else None
+        return "gemm_conv" if self._prof_all and self._prof is not None else None
 
     def profile_end(self):
         prof, self._prof = getattr(self, "_prof", None) or {}, None
@@ -166,6 +189,8 @@ class Engine:
         return out
 
     def timed(self, tag):
+        if self._prof is None or not tag:
+            return _NO_TIMER
         return _Timed(self, tag)
 
     def empty(self, *shape, dtype=torch.float32):
