@@ -581,31 +581,85 @@ e = get_engine(0)
 g = torch.Generator().manual_seed(5)
 out = {}
 for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+  for shp, cout, dil in (("a", 96, 2), ("p", 32, 1)):   # "p": the patch-form kernels (forward / dgrad and wgrad)
     x = (torch.randn(5, 32, 32, 64, generator=g)).cuda().to(dt)
-    w = (torch.randn(3, 3, 64, 96, generator=g) * 0.05).cuda()
-    b = torch.randn(96, generator=g).cuda()
-    d = e.conv_desc(tuple(x.shape), 96, 3, 3, 1, 2, "same")
+    w = (torch.randn(3, 3, 64, cout, generator=g) * 0.05).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    d = e.conv_desc(tuple(x.shape), cout, 3, 3, 1, dil, "same")
     y = e.conv2d_fwd(x, w, b, desc=d)
     dy = torch.randn(*y.shape, generator=g).cuda().to(dt)
     dx = e.conv2d_dgrad(dy, w, d)
     dw, db = e.conv2d_wgrad(x, dy, d)
     for k, v in (("y", y), ("dx", dx), ("dw", dw), ("db", db)):
-        out[f"{tag}_{k}"] = v.float().cpu().numpy()
+        out[f"{tag}{shp}_{k}"] = v.float().cpu().numpy()
 np.savez(sys.argv[2], **out)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for name, limit in (("whole", None), ("chunked", str(2 * 32 * 32 * 96 * 4 + 1000))):   # two fp32 output images fit
+        for name, limit in (("whole", None), ("chunked", str(2 * 32 * 32 * 64 * 4 + 1000))):   # two fp32 input images fit
             env = dict(os.environ)
             if limit:
                 env["SG_CONV_MAX_BYTES"] = limit
             path = os.path.join(td, name + ".npz")
             subprocess.run([sys.executable, "-c", code, root, path], check=True, env=env, timeout=300)
             res[name] = dict(np.load(path))
-    for tag in ("f32", "bf16"):
+    for tag in ("f32a", "f32p", "bf16a", "bf16p"):
         assert np.array_equal(res["whole"][f"{tag}_y"], res["chunked"][f"{tag}_y"])
         assert np.array_equal(res["whole"][f"{tag}_dx"], res["chunked"][f"{tag}_dx"])
         for k in ("dw", "db"):
             a, b = res["whole"][f"{tag}_{k}"], res["chunked"][f"{tag}_{k}"]
             assert np.abs(a - b).max() <= 2e-5 * np.abs(a).max(), (tag, k)
+
+
+def test_fused_second_stage_of_the_reductions_is_bit_identical(engine):
+    """sg_reduce.h: the second stage (fp64 sums of the partial rows + the Op's finalize) runs inside the reduce kernel when one
+    workgroup covers a column block (default), as a separate launch (SG_SEG_FUSED=0) or in the last-arriving workgroup
+    (SG_SEG_FUSED=2, arrival counters).  Same lanes, same order of additions: the three forms must agree to the bit on
+    BatchNorm backward, the depthwise filter gradient (both kernels), pooling and a bias gradient."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from building_detection_amd.ops import get_engine
+e = get_engine(0)
+g = torch.Generator().manual_seed(11)
+out = {}
+for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+    for n, h, c in ((4, 32, 728), (2, 64, 96), (3, 8, 40)):
+        x = torch.randn(n, h, h, c, generator=g).cuda().to(dt)
+        dy = torch.randn(n, h, h, c, generator=g).cuda().to(dt)
+        gamma, beta = torch.rand(c, generator=g).cuda() + 0.5, torch.randn(c, generator=g).cuda()
+        y, mean, invstd = e.bn_train_fwd(x, gamma, beta, torch.zeros(c).cuda(), torch.ones(c).cuda(), relu=True)
+        dx, dg, db = e.bn_train_bwd(x, y, dy, gamma, mean, invstd, relu=True, beta=beta)
+        wd = torch.randn(3, 3, c, generator=g).cuda()
+        d = e.conv_desc(tuple(x.shape), c, 3, 3, 1, 1, "same")
+        dwg = e.dwconv_wgrad(x, dy, d, True)
+        ds = e.conv_desc(tuple(x.shape), c, 3, 3, 2, 1, "same")
+        dys = torch.randn(n, ds.Ho, ds.Wo, c, generator=g).cuda().to(dt)
+        dwg2 = e.dwconv_wgrad(x, dys, ds, False)
+        gap = e.avgpool_fwd(x, h, h)   # GlobalAveragePooling2D: one window per image
+        bias = e.empty(c)
+        e.bias_grad(dy, bias)
+        for k, v in (("mean", mean), ("invstd", invstd), ("dx", dx), ("dg", dg), ("db", db), ("dwg", dwg), ("dwg2", dwg2),
+                     ("gap", gap), ("bias", bias)):
+            out[f"{tag}_{h}_{c}_{k}"] = v.float().cpu().numpy()
+np.savez(sys.argv[2], **out)
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for mode in ("0", "1", "2"):
+            env = dict(os.environ)
+            env["SG_SEG_FUSED"] = mode
+            path = os.path.join(td, mode + ".npz")
+            subprocess.run([sys.executable, "-c", code, root, path], check=True, env=env, timeout=300)
+            res[mode] = dict(np.load(path))
+    assert len(res["0"]) == 2 * 3 * 9
+    for k, v in res["0"].items():
+        assert np.isfinite(v).all(), k
+        assert np.array_equal(v, res["1"][k]), ("separate launch vs fused (S == 1)", k)
+        assert np.array_equal(v, res["2"][k]), ("separate launch vs arrival counters", k)
