@@ -1499,6 +1499,17 @@ inline int images_per_2gib(const sg_conv_desc* d, int eb = 4) {
   return (int)(nb < 1 ? 0 : nb);
 }
 
+// the same for a launch whose input and output differ in element size (x: ebx bytes, y: eby bytes)
+inline int images_per_2gib_mixed(const sg_conv_desc* d, int ebx, int eby) {
+  const int64_t xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+  const int64_t xi = (int64_t)d->H * d->W * xl * ebx, yi = (int64_t)d->Ho * d->Wo * yl * eby;
+  const int64_t per = xi > yi ? xi : yi;
+  const int64_t lim = images_limit_bytes();
+  if (per * d->N < lim) return d->N;
+  const int64_t nb = lim / per;
+  return (int)(nb < 1 ? 0 : nb);
+}
+
 struct WgradPlan {
   int S;
   int slabs_per_split;
@@ -1746,11 +1757,22 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
   SG_CHECK_ARG(!head32 || (b16 && d->Cout <= 4), "sg_conv2d_fwd: SG_HEAD_F32 needs Cout <= 4 (a softmax head) on bf16 storage");
   hipStream_t st = (hipStream_t)stream;
   if (head32 && !(thin_ok(d) && aligned16(x))) {  // a head that is not a 1x1 convolution: the any-shape kernel, fp32 out
-    SG_CHECK_ARG(images_per_2gib(d, 4) >= d->N, "sg_conv2d_fwd: softmax head beyond 2 GiB");
-    IgemmParams ph;
-    fill_fwd_params(ph, d, x, w, bias, y, flags, eb);
-    const bool vec4 = (d->Cin % 4 == 0) && (ph.x_ld % 4 == 0) && (((uintptr_t)x & 7) == 0);
-    return dispatch_igemm_mixed<bf16_t, float>(ph, vec4, ctx->num_cus, st);
+    // sub-batches of whole images when the bf16 input or the fp32 output passes 2 GiB (1024 x 1024 ensemble tiles)
+    const int nb = images_per_2gib_mixed(d, 2, 4);
+    SG_CHECK_ARG(nb >= 1, "sg_conv2d_fwd: one image of the softmax head beyond 2 GiB");
+    const int64_t xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+    for (int n0 = 0; n0 < d->N; n0 += nb) {
+      sg_conv_desc sub = *d;
+      sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
+      const char* xs = (const char*)x + (int64_t)n0 * d->H * d->W * xl * 2;
+      char* ys = (char*)y + (int64_t)n0 * d->Ho * d->Wo * yl * 4;
+      IgemmParams ph;
+      fill_fwd_params(ph, &sub, xs, w, bias, ys, flags, eb);
+      const bool vec4 = (d->Cin % 4 == 0) && (ph.x_ld % 4 == 0) && (((uintptr_t)xs & 7) == 0);
+      int rch = dispatch_igemm_mixed<bf16_t, float>(ph, vec4, ctx->num_cus, st);
+      if (rch) return rch;
+    }
+    return 0;
   }
   if (!head32) {
     // The fast kernels address their operands through 2 GiB buffer descriptors.  A larger batch is run as
@@ -1948,15 +1970,25 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   SG_CHECK_ARG(!head32 || (b16 && d->Cout <= 4), "sg_conv2d_dgrad: SG_HEAD_F32 needs Cout <= 4 (a softmax head) on bf16 storage");
   hipStream_t st = (hipStream_t)stream;
   if (head32 && !thin) {  // fp32 dy in, bf16 dx out, any shape
-    SG_CHECK_ARG(images_per_2gib(d, 4) >= d->N, "sg_conv2d_dgrad: softmax head beyond 2 GiB");
+    const int nb = images_per_2gib_mixed(d, 2, 4);  // dx bf16 (the forward's x), dy fp32
+    SG_CHECK_ARG(nb >= 1, "sg_conv2d_dgrad: one image of the softmax head beyond 2 GiB");
     float* wth = (float*)ws;
     dim3 grid((unsigned)sg_cdiv(d->Cout, 32), (unsigned)sg_cdiv(d->Cin, 32), (unsigned)(d->KH * d->KW));
     hipLaunchKernelGGL(transpose_taps_kernel, grid, dim3(256), 0, st, (const float*)w, wth, d->Cin, d->Cout);
     SG_LAUNCH_CHECK("transpose_taps_kernel");
-    IgemmParams ph;
-    fill_dgrad_params(ph, d, dy, wth, bias, dx, flags, 4);
-    const bool vec4 = (d->Cout % 4 == 0) && (ph.x_ld % 4 == 0) && aligned16(dy);
-    return dispatch_igemm_mixed<float, bf16_t>(ph, vec4, ctx->num_cus, st);
+    const int64_t xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+    for (int n0 = 0; n0 < d->N; n0 += nb) {
+      sg_conv_desc sub = *d;
+      sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
+      const char* dys = (const char*)dy + (int64_t)n0 * d->Ho * d->Wo * yl * 4;
+      char* dxs = (char*)dx + (int64_t)n0 * d->H * d->W * xl * 2;
+      IgemmParams ph;
+      fill_dgrad_params(ph, &sub, dys, wth, bias, dxs, flags, 4);
+      const bool vec4 = (d->Cout % 4 == 0) && (ph.x_ld % 4 == 0) && aligned16(dys);
+      int rch = dispatch_igemm_mixed<float, bf16_t>(ph, vec4, ctx->num_cus, st);
+      if (rch) return rch;
+    }
+    return 0;
   }
   if (!head32) {
     const int nb = images_per_2gib(d, eb);  // see sg_conv2d_fwd_ws

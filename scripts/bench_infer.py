@@ -16,6 +16,10 @@ from building_detection_amd.ops import get_engine  # noqa: E402
 size = int(os.environ.get("SIZE", "1024"))
 batch = int(os.environ.get("BATCH", "8"))
 iters = int(os.environ.get("ITERS", "3"))
+DTYPE = os.environ.get("DTYPE", "f32")  # "bf16": activations stored as bf16 (mixed_bfloat16 policy)
+if DTYPE == "bf16":
+    from building_detection_amd import mixed_precision
+    mixed_precision.set_global_policy("mixed_bfloat16")
 eng = get_engine(0)
 g = torch.Generator().manual_seed(1103)
 x = (torch.randint(0, 256, (batch, size, size, 3), generator=g).float() / 127.5 - 1).cuda()
@@ -32,7 +36,7 @@ def timeit(fn):
     return (time.perf_counter() - t0) / iters
 
 
-out = {"config": f"5-model ensemble inference {size}x{size} bs={batch} fp32", "models": {}}
+out = {"config": f"5-model ensemble inference {size}x{size} bs={batch} {'bf16 storage' if DTYPE == 'bf16' else 'fp32'}", "models": {}}
 masks = []
 tot_e = tot_g = 0.0
 for name in ("res34", "hrnet", "v3plus", "scse", "bam"):

@@ -592,6 +592,17 @@ for tag, dt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
     dw, db = e.conv2d_wgrad(x, dy, d)
     for k, v in (("y", y), ("dx", dx), ("dw", dw), ("db", db)):
         out[f"{tag}{shp}_{k}"] = v.float().cpu().numpy()
+# the fp32 softmax head of a bf16 model that is not a 1x1 convolution (Res34-UNet: 3x3, 64 -> 2): bf16 in, fp32 out
+x = torch.randn(5, 32, 32, 64, generator=g).cuda().to(torch.bfloat16)
+w = (torch.randn(3, 3, 64, 2, generator=g) * 0.05).cuda()
+b = torch.randn(2, generator=g).cuda()
+d = e.conv_desc(tuple(x.shape), 2, 3, 3, 1, 1, "same")
+y = e.conv2d_fwd(x, w, b, desc=d, head_f32=True)
+assert y.dtype == torch.float32
+dyh = torch.randn(*y.shape, generator=g).cuda()
+dx = e.conv2d_dgrad(dyh, w, d, out_dtype=torch.bfloat16)
+assert dx.dtype == torch.bfloat16
+out["head_y"], out["head_dx"] = y.cpu().numpy(), dx.float().cpu().numpy()
 np.savez(sys.argv[2], **out)
 '''
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -604,6 +615,8 @@ np.savez(sys.argv[2], **out)
             path = os.path.join(td, name + ".npz")
             subprocess.run([sys.executable, "-c", code, root, path], check=True, env=env, timeout=300)
             res[name] = dict(np.load(path))
+    assert np.array_equal(res["whole"]["head_y"], res["chunked"]["head_y"])
+    assert np.array_equal(res["whole"]["head_dx"], res["chunked"]["head_dx"])
     for tag in ("f32a", "f32p", "bf16a", "bf16p"):
         assert np.array_equal(res["whole"][f"{tag}_y"], res["chunked"][f"{tag}_y"])
         assert np.array_equal(res["whole"][f"{tag}_dx"], res["chunked"][f"{tag}_dx"])
