@@ -155,6 +155,10 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = BASELINE configs[1] (the reference's precision, default); bf16 = configs[2]: bf16 activation "
                          "storage, one-pass bf16 MFMA products with fp32 accumulation, fp32 master weights / BN / loss / Adam")
+    ap.add_argument("--jit", action="store_true",
+                    help="Model.compile(jit_compile=True): the training step replayed as ONE hipGraph (single-GPU; the "
+                         "roofline figures then come from two extra EAGER steps after the timed region, because the "
+                         "launches inside a graph replay cannot be bracketed with events)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--comm", default=os.environ.get("SG_BENCH_COMM", "sg"), choices=["sg", "torch"],
@@ -202,7 +206,10 @@ def main():
         model = zoo.BUILDERS[args.model]((args.size, args.size, 3), 2, aspp_pool=args.size // 16)
     else:
         model = zoo.BUILDERS[args.model]((args.size, args.size, 3))
-    model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
+    jit = bool(args.jit) and dist is None
+    model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score], jit_compile=jit)
+    if jit and args.warmup < 3:
+        args.warmup = 3   # two eager steps per shape, the third call captures (and replays) the graph
     if dist is not None:
         from building_detection_amd.dist import DataParallel
         dp = DataParallel(model, comm="sg_or_torch" if args.comm == "sg" else "torch")
@@ -233,6 +240,8 @@ def main():
     # outside the timed region: two more steps with EVERY GEMM-convolution launch bracketed (the whole kernel family)
     # (every rank runs them - the data-parallel step all-reduces - but only rank 0 brackets its launches)
     fam = {}
+    if jit:
+        model.jit_compile = False   # the two bracketed steps below run eagerly
     if rank == 0:
         eng.profile_begin(all_convs=True)
     for _ in range(2):
@@ -240,6 +249,9 @@ def main():
     if rank == 0:
         fam = eng.profile_end()
     sync()
+    if jit and rank == 0:   # the dilated set of the two eager steps stands in for the (unbracketable) replays
+        prof = {"dilated_conv": fam.get("dilated_conv", 0.0) * args.steps / 2.0,
+                "dilated_conv_launches": fam.get("dilated_conv_launches", 0) * args.steps // 2}
     if dist is not None:
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -302,7 +314,8 @@ def main():
                        "global_batch": world * args.batch, "model_flops_per_step_tflop": round(step_tflop, 3),
                        "step_achieved_tflops": round(step_tflop / (ms_per_step / 1e3), 2),
                        "final_loss": float(loss.item()),
-                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2)},
+                       "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2),
+                       "train_step": "one hipGraph replay per step (compile(jit_compile=True))" if jit else "eager launches"},
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / peak, 4),

@@ -112,8 +112,12 @@ __global__ __launch_bounds__(256) void confusion_kernel(int64_t rows, int y_cols
   }
 }
 
+// lr_dev != nullptr: the step's learning rate is read from device memory (a hipGraph-captured training step: the
+// bias-corrected rate changes every step, the captured kernel arguments do not)
 __global__ void adam_kernel(int64_t n, float* __restrict__ w, float* __restrict__ m, float* __restrict__ v,
-                            const float* __restrict__ g, float lr_t, float b1, float b2, float eps, float gs) {
+                            const float* __restrict__ g, float lr_arg, const float* __restrict__ lr_dev, float b1, float b2,
+                            float eps, float gs) {
+  const float lr_t = lr_dev ? lr_dev[0] : lr_arg;
   const int64_t nv = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
     f32x4 wv = reinterpret_cast<f32x4*>(w)[i], mv = reinterpret_cast<f32x4*>(m)[i], vv = reinterpret_cast<f32x4*>(v)[i];
@@ -264,7 +268,21 @@ int sg_adam_step(sg_ctx* ctx, void* stream, int64_t n, void* w, void* m, void* v
   int64_t blocks = sg_cdiv(n / 4 + 1, 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, (float*)w, (float*)m,
-                     (float*)v, (const float*)g, lr_t, beta1, beta2, eps, grad_scale);
+                     (float*)v, (const float*)g, lr_t, (const float*)nullptr, beta1, beta2, eps, grad_scale);
+  SG_LAUNCH_CHECK("adam_kernel");
+  return 0;
+}
+
+int sg_adam_step_lr(sg_ctx* ctx, void* stream, int64_t n, void* w, void* m, void* v, const void* g, const void* lr_t_dev,
+                    float beta1, float beta2, float eps, float grad_scale) {
+  SG_CHECK_ARG(ctx && w && m && v && g && lr_t_dev && n >= 0, "sg_adam_step_lr: bad argument");
+  SG_CHECK_ARG(sg_aligned16(w) && sg_aligned16(m) && sg_aligned16(v) && sg_aligned16(g),
+               "sg_adam_step_lr: arenas must be 16-byte aligned");
+  if (n == 0) return 0;
+  int64_t blocks = sg_cdiv(n / 4 + 1, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, n, (float*)w, (float*)m,
+                     (float*)v, (const float*)g, 0.f, (const float*)lr_t_dev, beta1, beta2, eps, grad_scale);
   SG_LAUNCH_CHECK("adam_kernel");
   return 0;
 }

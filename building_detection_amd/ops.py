@@ -546,7 +546,12 @@ class Engine:
                                            C.c_void_p(out.data_ptr())), "sg_confusion_counts")
         return out
 
-    def adam_step(self, w, m, v, g, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0):
+    def adam_step(self, w, m, v, g, lr_t, beta1=0.9, beta2=0.999, eps=1e-7, grad_scale=1.0, lr_dev=None):
+        """lr_dev: a one-float device tensor holding lr_t (a captured training step; lr_t is then ignored)."""
+        if lr_dev is not None:
+            check(self.lib.sg_adam_step_lr(self.h, self.stream, w.numel(), _ptr(w), _ptr(m), _ptr(v), _ptr(g), _ptr(lr_dev),
+                                           beta1, beta2, eps, float(grad_scale)), "sg_adam_step_lr")
+            return
         check(self.lib.sg_adam_step(self.h, self.stream, w.numel(), _ptr(w), _ptr(m), _ptr(v), _ptr(g), float(lr_t), beta1,
                                     beta2, eps, float(grad_scale)), "sg_adam_step")
 

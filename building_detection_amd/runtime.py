@@ -225,7 +225,10 @@ class Model:
         load_weights(self, path)
 
     # ------------------------------------------------------------------------------------------ compile
-    def compile(self, optimizer="adam", loss=None, metrics=None, **kw):
+    def compile(self, optimizer="adam", loss=None, metrics=None, jit_compile=False, **kw):
+        """jit_compile (tf.keras's name for "compile the train step"): capture the whole training step - forward, loss,
+        metric counts, backward, Adam - into one hipGraph per input shape and replay it (GraphedTrainStep).  Same
+        kernels, same order: bit-identical to the eager step; ~1800 launches per step become one."""
         if isinstance(optimizer, str):
             if optimizer.lower() != "adam":
                 raise ValueError("the reference compiles with optimizer='adam' (DeepLabv3plus.py:835)")
@@ -233,6 +236,9 @@ class Model:
         self.optimizer = optimizer
         self.loss_kind = LS.resolve_loss(loss)
         self.metric_names = [LS.resolve_metric(m) for m in (metrics or [])]
+        self.jit_compile = bool(jit_compile)
+        self._train_graphs = {}
+        self._train_graph_seen = {}
 
     # ------------------------------------------------------------------------------------------ predict
     def predict(self, x, batch_size=32, verbose=0, **kw):
@@ -289,6 +295,19 @@ class Model:
         rt = self._runtime()
         with rt.eng.lock:
             xd, yd = rt.to_device(x), rt.to_device(y)
+            if getattr(self, "jit_compile", False) and self.dist is None:
+                key = (tuple(xd.shape), tuple(yd.shape), xd.dtype, yd.dtype)
+                g = self._train_graphs.get(key)
+                if g is None:
+                    # two eager steps per shape first: they size the scratch buffer and the weight-plane arena, run every
+                    # kernel's one-time attribute calls and warm the allocator - and they are real training steps
+                    seen = self._train_graph_seen.get(key, 0)
+                    self._train_graph_seen[key] = seen + 1
+                    if seen >= 2:
+                        g = self._train_graphs[key] = GraphedTrainStep(self, xd, yd)
+                if g is not None:
+                    loss, counts = g.run(xd, yd)
+                    return (loss, counts) if return_device_scalars else self._logs(loss, counts)
             p = rt.forward(xd, training=True)
             loss = rt.eng.loss_fwd(self.loss_kind, p, yd)
             counts = rt.eng.confusion_counts(p, yd) if self.metric_names else None
@@ -416,16 +435,70 @@ class GraphedPredict:
                 with torch.cuda.graph(self.graph):
                     self.y = rt.forward(self.x, training=False)
             rt.values = {}
+            # the planes this graph reads: kept alive and refreshed by the graph's owner, whatever the runtime's current
+            # planes are by then (a later call with another batch size re-keys and re-allocates them)
+            self._planes = (rt._planes_arena, rt._planes_jobs, rt._planes_launch)
+            self._planes_version = rt._w_version
 
     def __call__(self, x_dev):
         """Replays the graph on x_dev.  The returned tensor is the graph's static output buffer: consume (or clone) it
         before the next call."""
         with self.rt.eng.lock:
-            if self.rt._planes_dirty:  # weights were replaced after the capture: the graph reads the same planes arena
-                self.rt.ensure_planes(self.x.shape[0], False)
+            if self._planes_version != self.rt._w_version and self._planes[0] is not None:  # weights replaced since
+                self.rt.prepare_into(*self._planes)
+                self._planes_version = self.rt._w_version
             self.x.copy_(x_dev, non_blocking=True)
             self.graph.replay()
         return self.y
+
+
+class GraphedTrainStep:
+    """One optimisation step of a compiled model - forward, loss, confusion counts, backward, Adam - captured into a
+    hipGraph for one (x, y) shape (Model.compile(jit_compile=True)).  The step's inputs are two static device buffers, its
+    outputs (loss, counts) two more; Adam's bias-corrected learning rate, the only number that changes from replay to
+    replay, is read by the kernel from a one-float device buffer written before each replay (sg_adam_step_lr).  The weight
+    planes are rebuilt inside the graph (the capture starts with them marked stale), BatchNorm's moving statistics and the
+    optimiser moments are updated in place as in the eager step.  Data-parallel models keep the eager step (their bucketed
+    all-reduce runs on a second stream behind host-side hooks)."""
+
+    def __init__(self, model: "Model", xd, yd):
+        import torch
+        rt = model._runtime()
+        eng = rt.eng
+        self.torch, self.model, self.rt = torch, model, rt
+        opt = model.optimizer
+        self.x, self.y = torch.empty_like(xd), torch.empty_like(yd)
+        self.lr = eng.zeros(4)
+        self.ws = torch.empty(max(eng._ws_peak, 256) + 256, dtype=torch.uint8, device=eng.device)
+        rt.release()
+        rt.weights_changed()  # the graph must contain the plane preparation: every replay follows an optimiser step
+        torch.cuda.synchronize(eng.device)
+        self.graph = torch.cuda.CUDAGraph()
+        with eng.private_ws(self.ws):
+            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+                p = rt.forward(self.x, training=True)
+                self.loss = eng.loss_fwd(model.loss_kind, p, self.y)
+                self.counts = eng.confusion_counts(p, self.y) if model.metric_names else None
+                dp = eng.loss_bwd(model.loss_kind, p, self.y, 1.0)
+                rt.backward(dp)
+                eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, 0.0, opt.beta_1, opt.beta_2, opt.epsilon, 1.0,
+                              lr_dev=self.lr)
+        self._planes = (rt._planes_arena, rt._planes_jobs)  # kept alive: the graph's nodes carry their addresses
+        rt.release()
+        rt.weights_changed()
+
+    def run(self, xd, yd):
+        """Replays the step on (xd, yd).  Returns the graph's static loss / counts buffers: read them before the next step."""
+        opt = self.model.optimizer
+        self.x.copy_(xd, non_blocking=True)
+        self.y.copy_(yd, non_blocking=True)
+        opt.iterations += 1
+        t = opt.iterations
+        lr_t = float(opt.lr) * math.sqrt(1.0 - opt.beta_2 ** t) / (1.0 - opt.beta_1 ** t)
+        self.lr.fill_(lr_t)
+        self.graph.replay()
+        self.rt.weights_changed()
+        return self.loss, self.counts
 
 
 class _Runtime:
@@ -465,6 +538,7 @@ class _Runtime:
         self._planes_jobs = None
         self._planes_launch = (0, 0)
         self._planes_dirty = True
+        self._w_version = 0   # bumped by weights_changed(): captured graphs compare it with the version their planes hold
         self._use_planes = os.environ.get("SG_PREPARED_PLANES", "1") != "0"
 
     # -- parameters ---------------------------------------------------------------------------------------
@@ -494,6 +568,16 @@ class _Runtime:
         """Call after writing the weight arena (Adam, set_weights, broadcast): the bf16 operand planes the convolution
         kernels read are re-derived from it before the next forward."""
         self._planes_dirty = True
+        self._w_version += 1
+
+    def prepare_into(self, arena, jobs, launch):
+        """Rebuild the weight planes of a SNAPSHOT (arena, job table, (jobs, blocks)) taken at a hipGraph capture: the graph's
+        kernel nodes carry that arena's addresses whatever batch size / mode the runtime's current planes describe."""
+        import ctypes as C
+        if launch[0]:
+            _lib.check(self.eng.lib.sg_prepare_planes(self.eng.h, self.eng.stream, C.c_void_p(self.w_train.data_ptr()),
+                                                      C.c_void_p(arena.data_ptr()), C.c_void_p(jobs.data_ptr()), launch[0],
+                                                      launch[1]), "sg_prepare_planes")
 
     def planes(self, node, tag):
         """Device address of the prepared planes of `node`'s launch `tag` ("f" / "d"), or None (the launch then converts its

@@ -316,6 +316,12 @@ int sg_confusion_counts(sg_ctx* ctx, void* stream, int64_t rows, int y_cols, con
  * lr_t = lr*sqrt(1-b2^t)/(1-b1^t) precomputed by the host.  g is scaled by grad_scale first (1/world). */
 int sg_adam_step(sg_ctx* ctx, void* stream, int64_t n, void* w, void* m, void* v, const void* g,
                  float lr_t, float beta1, float beta2, float eps, float grad_scale);
+/* The same step with lr_t read from device memory (one float): for a training step captured into a hipGraph, whose
+ * bias-corrected learning rate lr * sqrt(1 - beta2^t) / (1 - beta1^t) changes at every replay while the captured kernel
+ * arguments cannot (tf.keras Adam, optimizer_v2/adam.py: the reference compiles with optimizer='adam',
+ * train_model/DeepLabv3plus.py:835). */
+int sg_adam_step_lr(sg_ctx* ctx, void* stream, int64_t n, void* w, void* m, void* v, const void* g, const void* lr_t_dev,
+                    float beta1, float beta2, float eps, float grad_scale);
 
 /* Label channels of train_data_gen (DeepLabv3plus.py:70-100) from label[N,H,W] (gray/255, float): y[N,H,W,4] =
  * (1-fg, fg, f_edge, p_edge); fg = 1 iff label == 1.0 (to_categorical truncation); `iterations` (5 in the

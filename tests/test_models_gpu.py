@@ -526,3 +526,39 @@ def test_prepared_weight_planes_equal_per_launch_conversion(engine, policy):
         finally:
             engine.lib.sg_set_conv_x6(prev)
         assert np.array_equal(ma.predict(x), mb.predict(x))
+
+
+@pytest.mark.parametrize("policy", ["float32", "mixed_bfloat16"])
+def test_jit_compiled_train_step_is_bit_identical_to_the_eager_one(engine, policy):
+    """Model.compile(jit_compile=True): the training step captured into a hipGraph (GraphedTrainStep) replays exactly the eager
+    launches - same loss, same metric counts and the same weights to the bit after several Adam steps (whose bias-corrected
+    learning rate changes every step and is read from device memory by the captured kernel) - also when a prediction with
+    another batch size, a validation step and a change of the learning rate come in between (the runtime's weight planes are
+    re-keyed by the first, the graph keeps its own)."""
+    from building_detection_amd import mixed_precision as MP, zoo
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss, PA, IoU
+    from building_detection_amd.runtime import GraphedTrainStep
+    MP.set_global_policy(policy)
+    try:
+        ma = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+        mb = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+    finally:
+        MP.set_global_policy("float32")
+    mb.set_weights(ma.get_weights())
+    ma.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU])
+    mb.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU], jit_compile=True)
+    batches = [synthetic_batch(2, 64, 64, seed=40 + i) for i in range(7)]
+    xv, yv = synthetic_batch(3, 64, 64, seed=99)
+    for i, (x, y) in enumerate(batches):
+        la, lb = ma.train_on_batch(x, y), mb.train_on_batch(x, y)
+        assert la == lb, (i, la, lb)
+        if i == 3:   # in between: another batch size through predict / test_on_batch, and a new learning rate
+            assert np.array_equal(ma.predict(xv), mb.predict(xv))
+            assert ma.test_on_batch(xv, yv) == mb.test_on_batch(xv, yv)
+            ma.optimizer.lr = mb.optimizer.lr = 3e-4
+    assert len(mb._train_graphs) == 1 and isinstance(next(iter(mb._train_graphs.values())), GraphedTrainStep)
+    assert not getattr(ma, "_train_graphs", None)
+    for wa, wb in zip(ma.get_weights(), mb.get_weights()):
+        assert np.array_equal(wa, wb)
+    assert np.array_equal(ma.predict(xv), mb.predict(xv))
