@@ -1252,7 +1252,7 @@ int dispatch_wgrad(const WgradParams& p_in, int S, bool vec, hipStream_t st) {
       p.stagger = abl;  // the x6 wgrad kernel has no stagger; the field carries the ablation mask
     }
     static const int wpf2 = getenv("SG_X6_WGRAD_PF2") ? atoi(getenv("SG_X6_WGRAD_PF2")) : 0;  // A/B switch
-    if (wpf2) {
+    if (wpf2 && p.stride == 1) {  // (the double-buffered experiment addresses its slabs for stride 1 only)
       if (bn == 128) return launch_wgrad_x6<128, 2, 4, 2>(p, S, st);
       if (bn == 64) return launch_wgrad_x6<64, 4, 2, 2>(p, S, st);
       return launch_wgrad_x6<32, 4, 1, 2>(p, S, st);
@@ -1563,7 +1563,8 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d, bool b16 = false) {
   const double flops = 2.0 * (double)tiles * BM * bn * (double)P;  // padded tile work
   // sustained rate of the kernel that will run: the x6 wgrad (geometry test as in wgrad_x6_ok) or the fp32 MFMA one
   static const double rate_x6 = getenv("SG_WGRAD_PLAN_RATE") ? atof(getenv("SG_WGRAD_PLAN_RATE")) * 1e12 : 110e12;
-  const bool x6_geom = d->stride == 1 && d->Ho == d->H && d->Wo == d->W && d->W % 32 == 0 && d->Cout >= 16 && d->Cin % 4 == 0;
+  const bool x6_geom = ((d->stride == 1 && d->Ho == d->H && d->Wo == d->W) || (d->stride == 2 && d->dilation == 1)) &&
+                      d->Wo % 32 == 0 && d->Cout >= 16 && d->Cin % 4 == 0;
   // the one-pass bf16 kernel multiplies ~4x faster than the six-pass one: the split's partial-slab traffic weighs more
   static const double rate_b16 = getenv("SG_WGRAD_PLAN_RATE_B16") ? atof(getenv("SG_WGRAD_PLAN_RATE_B16")) * 1e12 : 110e12;  // measured 110 / 250 / 450 / 900: no gain from a higher rate (profiles/r02_b16_deep_ab.txt)
   const double rate = x6_geom ? (b16 ? rate_b16 : rate_x6) : 110e12;

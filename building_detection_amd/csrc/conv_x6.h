@@ -862,8 +862,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
   unsigned a_voffc[NA], b_voff[NB];
 #pragma unroll
-  for (int j = 0; j < NA; ++j)
-    a_voffc[j] = rvalid ? (unsigned)((pr0 + PS * j + s_dh * p.W + s_dw + SH) * p.x_ld + ci0) * (unsigned)EB : OOB;
+  for (int j = 0; j < NA; ++j)  // output pixel pr0 + PS j of the slab reads input pixel stride * (pr0 + PS j) + tap shift
+    a_voffc[j] = rvalid ? (unsigned)((p.stride * (pr0 + PS * j) + s_dh * p.W + s_dw + SH) * p.x_ld + ci0) * (unsigned)EB : OOB;
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int idx = t + NT * i;
@@ -881,13 +881,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     uint32_t q, ow0, n_, oh;
     fd_divmod((uint32_t)p0, p.fd_ow, q, ow0);
     fd_divmod(q, p.fd_oh, n_, oh);
-    const int ih = (int)oh + s_dh;
+    // the slab's 32 output pixels (one output row, OW % 32 == 0) read input row oh * stride + s_dh, columns
+    // (ow0 + k) * stride + s_dw: the slab's first input pixel is the scalar offset, the rest rides in the voffsets
+    const int ih = (int)oh * p.stride + s_dh;
     const bool row_ok = (unsigned)ih < (unsigned)p.H;
-    const int soff_a = p0 * p.x_ld * EB;
-    const int col0 = (int)ow0 + s_dw + pr0;
+    const int soff_a = (((int)n_ * p.H + (int)oh * p.stride) * p.W + (int)ow0 * p.stride) * p.x_ld * EB;
+    const int col0 = ((int)ow0 + pr0) * p.stride + s_dw;
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-      const bool v = row_ok && ((unsigned)(col0 + PS * j) < (unsigned)p.W);
+      const bool v = row_ok && ((unsigned)(col0 + PS * j * p.stride) < (unsigned)p.W);
       ra[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a, 0);
     }
     const int soff_b = p0 * p.y_ld * EB;
@@ -1181,8 +1183,12 @@ int launch_wgrad_x6(const WgradParams& p, int S, hipStream_t st) {
 }
 
 inline bool wgrad_x6_ok(const WgradParams& p, bool vec, bool force = false) {
-  const bool fast = p.stride == 1 && p.OH == p.H && p.OW == p.W && p.x_bytes != 0 && p.dy_bytes != 0;
-  const int64_t sh_bytes = ((int64_t)p.pad_t * p.W + p.pad_l + 64) * p.x_ld * 4;
+  // stride 1: "same" geometry; stride 2 (round 2: the Xception shortcuts, strided stems, Conv2DTranspose gradients): the
+  // output is the input subsampled, OH = ceil(H / 2) - the slab addressing above covers both; dilation 1 only at stride 2
+  const bool geom = (p.stride == 1 && p.OH == p.H && p.OW == p.W) ||
+                    (p.stride == 2 && p.dil == 1 && p.OH == (p.H + 1) / 2 && p.OW == (p.W + 1) / 2);
+  const bool fast = geom && p.x_bytes != 0 && p.dy_bytes != 0;
+  const int64_t sh_bytes = ((int64_t)p.pad_t * p.W + p.pad_l + 64 * p.stride) * p.x_ld * 4;
   return (force || x6_enabled()) && vec && fast && (p.OW % BK == 0) && p.Cout >= 16 &&
          ((int64_t)p.x_bytes + 2 * sh_bytes < (1ll << 31));
 }

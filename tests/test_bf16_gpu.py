@@ -52,7 +52,8 @@ CONV_CASES = [
     ("c32_c64_3x3", 5, 12, 16, 32, 64, 3, 1, 1),
     ("vpad_304", 2, 32, 32, 304, 256, 3, 1, 1),     # Cin % 32 != 0: virtual channel padding
     ("vpad_48", 2, 64, 64, 48, 96, 3, 1, 1),
-    ("s2_entry", 2, 64, 64, 32, 64, 3, 2, 1),        # stride 2: bf16-pipe forward/dgrad, fp32-MFMA wgrad fallback
+    ("s2_entry", 2, 64, 64, 32, 64, 3, 2, 1),        # stride 2: bf16-pipe forward / dgrad / wgrad (OW % 32 == 0)
+    ("s2_ragged", 2, 48, 48, 32, 64, 3, 2, 1),       # stride 2, OW = 24: the wgrad falls back to the fp32-MFMA kernel
     ("first_conv", 2, 64, 64, 3, 32, 3, 2, 1),       # Cin = 3: the any-shape fallback (widening loads)
     ("odd_45", 2, 32, 32, 45, 45, 3, 1, 4),          # BAM reduce dim 45
     ("dense_like", 16, 1, 1, 256, 64, 1, 1, 1),

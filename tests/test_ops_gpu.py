@@ -73,6 +73,11 @@ CONV_CASES = [
     (2, 20, 48, 32, 32, 3, 1, 1, "wpatch_c32_n32_h20"),
     (5, 12, 16, 32, 64, 3, 1, 1, "wpatch_c32_n64"),
     (1, 44, 80, 64, 64, 3, 1, 1, "wpatch_c64_n64"),
+    # stride-2 filter gradients on the bf16-pipe slab kernel (OW % 32 == 0): 3x3 with TF's asymmetric "same" padding, the
+    # 1x1 shortcut, an odd input height (the last input row is never read)
+    (2, 64, 64, 64, 128, 3, 2, 1, "x6_wgrad_s2_3x3"),
+    (2, 64, 64, 128, 256, 1, 2, 1, "x6_wgrad_s2_1x1"),
+    (1, 63, 64, 32, 48, 3, 2, 1, "x6_wgrad_s2_odd_h"),
 ]
 
 
@@ -133,10 +138,12 @@ def test_conv2d_into_concat_slice(engine, hw):
     close(dw, wr.grad, what="slice wgrad")
 
 
-@pytest.mark.parametrize("k,tag", [(3, "convT3"), (2, "convT2")])
-def test_conv2d_transpose(engine, k, tag):
+@pytest.mark.parametrize("k,tag,hw", [(3, "convT3", (9, 11)), (2, "convT2", (9, 11)), (3, "convT3_w32", (16, 32)),
+                                      (2, "convT2_w32", (8, 32))])
+def test_conv2d_transpose(engine, k, tag, hw):
+    """(…_w32: the kernel gradient is a stride-2 filter gradient with OW % 32 == 0, i.e. the bf16-pipe slab kernel)"""
     g = torch.Generator().manual_seed(11 + k)
-    n, h, w, cin, cout = 2, 9, 11, 64, 32
+    n, (h, w), cin, cout = 2, hw, 64, 32
     x = rnd(g, n, h, w, cin)
     wt = rnd(g, k, k, cout, cin) * 0.1
     b = rnd(g, cout)
