@@ -132,7 +132,7 @@ def spawn_ranks(n: int) -> int:
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=None if r == 0 else sys.stderr))
+                                      stdout=_JSON_FD if r == 0 else sys.stderr))  # rank 0 gets the REAL stdout
     rc = 0
     try:
         for p in procs:
@@ -144,7 +144,21 @@ def spawn_ranks(n: int) -> int:
     return rc
 
 
+# The contract is ONE JSON line on stdout.  Libraries write there too (RCCL prints a five-line version banner from
+# ncclCommInitRank): file descriptor 1 is pointed at stderr for the whole run and the JSON line goes to a saved copy of the
+# real stdout.
+_JSON_FD = 1
+
+
+def _claim_stdout():
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
+
+
 def main():
+    _claim_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -344,7 +358,8 @@ def main():
                     out["cpu_baseline"]["parity"]["what"] += " (bf16 engine vs the fp32 oracle: the tolerance contract of DESIGN.md section 8, not the 1e-3 fp32 bar)"
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(_JSON_FD, (json.dumps(out) + "\n").encode())   # the ONE line on the real stdout
     if dist is not None:
         dist.destroy_process_group()
 
