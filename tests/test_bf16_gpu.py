@@ -55,6 +55,7 @@ CONV_CASES = [
     ("s2_entry", 2, 64, 64, 32, 64, 3, 2, 1),        # stride 2: bf16-pipe forward / dgrad / wgrad (OW % 32 == 0)
     ("s2_ragged", 2, 48, 48, 32, 64, 3, 2, 1),       # stride 2, OW = 24: the wgrad falls back to the fp32-MFMA kernel
     ("first_conv", 2, 64, 64, 3, 32, 3, 2, 1),       # Cin = 3: the any-shape fallback (widening loads)
+    ("first_conv7", 1, 64, 64, 3, 64, 7, 2, 1),      # Res34-UNet's 7x7 stem, same kernel
     ("odd_45", 2, 32, 32, 45, 45, 3, 1, 4),          # BAM reduce dim 45
     ("dense_like", 16, 1, 1, 256, 64, 1, 1, 1),
 ]
@@ -71,7 +72,7 @@ def test_conv_bf16_vs_fp64_on_rounded_operands(engine, case):
     b = torch.randn(Cout, generator=g) * 0.1
     # the bf16-pipe kernels multiply bf16(w), the any-shape fallback (first_conv, odd_45: fp32 MFMA with widening loads) the
     # fp32 weights themselves: the reference follows the kernel that runs
-    wr = w if name in ("first_conv", "odd_45") else rb(w)
+    wr = w if name in ("first_conv", "first_conv7", "odd_45") else rb(w)
     xd, wd, bd = x.cuda().to(BF), w.cuda(), b.cuda()
     d = e.conv_desc(tuple(x.shape), Cout, k, k, stride, dil, "same")
     y = e.conv2d_fwd(xd, wd, bd, desc=d)

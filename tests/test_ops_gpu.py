@@ -78,6 +78,10 @@ CONV_CASES = [
     (2, 64, 64, 64, 128, 3, 2, 1, "x6_wgrad_s2_3x3"),
     (2, 64, 64, 128, 256, 1, 2, 1, "x6_wgrad_s2_1x1"),
     (1, 63, 64, 32, 48, 3, 2, 1, "x6_wgrad_s2_odd_h"),
+    # RGB stems (Cin = 3: the scalar any-shape kernels) at the sizes and kernel shapes of the five models
+    (2, 64, 64, 3, 32, 3, 2, 1, "stem_s2_w32"),
+    (1, 64, 64, 3, 64, 7, 2, 1, "stem7_s2_w32"),
+    (2, 32, 32, 3, 64, 3, 1, 1, "stem_s1_w32"),
 ]
 
 
