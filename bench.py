@@ -99,6 +99,23 @@ def cpu_baseline(threads, batch, size, steps, model=None):
                       threads, 2)
         out["config1_res34_256_bs2"] = {"value": round(2 / t2, 4), "unit": "256x256 tiles/s", "cores": threads,
                                         "sample": f"BASELINE configs[0]: Res34-UNet 256x256 bs=2 full step, min of 2, {t2:.2f} s/step"}
+        # (c) the roofline kernel set on the CPU: the six dilated 3x3 convolutions (3 x 2048 -> 256, 3 x 256 -> 256 at 32 x 32,
+        # rates 6 / 12 / 18), forward + both gradients, bs 2, through the oracle's conv2d
+        from oracle import tfops as T
+        gq = torch.Generator().manual_seed(3)
+        tt = 0.0
+        for cin in (2048, 256):
+            for rate in (6, 12, 18):
+                xq = torch.randn(2, 32, 32, cin, generator=gq).requires_grad_()
+                wq = (torch.randn(3, 3, cin, 256, generator=gq) * 0.02).requires_grad_()
+                for rep in range(2):
+                    xq.grad = wq.grad = None
+                    t0 = time.time()
+                    T.conv2d(xq, wq, None, 1, rate, "same").sum().backward()
+                    dtq = time.time() - t0
+                tt += dtq   # the second repetition
+        out["dilated_set"] = {"value": round(DILATED_GFLOP_PER_TILE * 2 / 1e3 / tt, 4), "unit": "TFLOP/s (nominal)", "cores": threads,
+                              "sample": f"the six dilated 3x3 convolutions fwd + dgrad + wgrad, bs=2, {tt:.2f} s"}
     except Exception as e:  # extras never take the main figure down
         out["extras_error"] = repr(e)
     if model is not None:
