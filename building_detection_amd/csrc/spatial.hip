@@ -145,6 +145,13 @@ struct DwRunParams {
   const T* __restrict__ mask;      // dgrad with pre_relu: forward input, else null
   T* __restrict__ out;
   int N, H, W, C, in_ld, out_ld, mask_ld, relu_in, flip;
+  // BN = true kernels: the input is the RAW output of the producing convolution and the preceding training-mode
+  // BatchNormalization (+ ReLU) is applied as the window is loaded - fmaf((x - mean) * invstd, gamma, beta), the very
+  // expression of bn_apply_kernel - so that normalised tensor is never written or read (sg_dwconv2d_fwd_bn)
+  const float* __restrict__ bn_gamma;
+  const float* __restrict__ bn_beta;
+  const float* __restrict__ bn_mean;
+  const float* __restrict__ bn_invstd;
   int lc;                          // lanes per run along the channels (set by launch_dw_run)
   int runs_per_row;                // W / 4
   int64_t nruns;                   // N * H * runs_per_row
@@ -156,7 +163,7 @@ struct DwRunParams {
 // RELU / MASK are compile-time and the window is branch-free (rows and columns outside the image load a valid address
 // and are zeroed by a select): with the run-time `if (relu_in)` and the `continue` on the row test every load sat in its
 // own basic block behind an s_waitcnt vmcnt(0) - 18..36 serialised memory latencies per run.
-template <int RR, typename T, bool RELU, bool MASK>
+template <int RR, typename T, bool RELU, bool MASK, bool BN = false>
 __global__ __launch_bounds__(256, 3) void dw_s1_run_kernel(const DwRunParams<T> p) {
   // p.lc lanes (a power of two <= 64) cover the channel chunks of one run; with few channels (C = 64: 16 chunks)
   // a wave takes several runs instead of idling three quarters of its lanes
@@ -166,6 +173,13 @@ __global__ __launch_bounds__(256, 3) void dw_s1_run_kernel(const DwRunParams<T> 
   f32x4 wt[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (p.flip ? 8 - t : t) * p.C + c);
+  f32x4 gm, bt, mv, iv;
+  if constexpr (BN) {
+    gm = *reinterpret_cast<const f32x4*>(p.bn_gamma + c);
+    bt = *reinterpret_cast<const f32x4*>(p.bn_beta + c);
+    mv = *reinterpret_cast<const f32x4*>(p.bn_mean + c);
+    iv = *reinterpret_cast<const f32x4*>(p.bn_invstd + c);
+  }
   const int64_t stride = (int64_t)gridDim.y * rpb;
   for (int64_t run = (int64_t)blockIdx.y * rpb + threadIdx.x / lc; run < p.nruns; run += stride) {
     uint32_t rowi, q, n, ohb;
@@ -188,8 +202,12 @@ __global__ __launch_bounds__(256, 3) void dw_s1_run_kernel(const DwRunParams<T> 
       for (int b = 0; b < 6; ++b) {
         const bool ok = rowok && (b == 0 ? lok : (b == 5 ? rok : true));
         const int db = (b == 0 && !lok) ? 0 : ((b == 5 && !rok) ? 3 : b - 1);   // a valid column when masked
-        const f32x4 t = ld4<T>(rowp + (int64_t)db * p.in_ld);
-        v[b] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 t = ld4<T>(rowp + (int64_t)db * p.in_ld);
+        if constexpr (BN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = fmaf((t[e] - mv[e]) * iv[e], gm[e], bt[e]);
+        }
+        v[b] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};   // zero padding of the NORMALISED tensor
         if constexpr (RELU) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[b][e] = fmaxf(v[b][e], 0.f);
@@ -230,7 +248,15 @@ __global__ __launch_bounds__(256, 3) void dw_s1_run_kernel(const DwRunParams<T> 
 // wgrad, same window: a "row" of the segmented reducer is a run of RR rows x 4 output pixels.  Branch-free like the
 // stencil above (PRE compile-time, rows / columns outside the image masked by a select): 22 loads of a run in flight
 // together instead of one at a time.
-template <int RR, typename T, bool PRE>
+// BN: x is the raw output of the producing convolution; the training-mode BatchNormalization (+ ReLU, PRE) in front of this
+// depthwise convolution is applied on load with bn_apply_kernel's expression (sg_dwconv2d_wgrad_bn), its four per-channel
+// parameters loaded once per thread (the reducer's context hook).
+template <int V>
+struct DwBnCtx {
+  float gm[V], bt[V], mv[V], iv[V];
+};
+
+template <int RR, typename T, bool PRE, bool BN = false>
 struct DwWgradRunOp {
   static constexpr int NOUT = 9;
   const T* __restrict__ x;
@@ -238,8 +264,23 @@ struct DwWgradRunOp {
   float* dw;
   int H, W, C, x_ld, y_ld;
   FastDiv fd_rpr, fd_h;
+  const float* __restrict__ bn_gamma;
+  const float* __restrict__ bn_beta;
+  const float* __restrict__ bn_mean;
+  const float* __restrict__ bn_invstd;
   template <int V>
-  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[9][V]) const {
+  __device__ __forceinline__ DwBnCtx<V> begin(int, int c) const {
+    DwBnCtx<V> k;
+    if constexpr (BN) {
+      ldv<V>(bn_gamma + c, k.gm);
+      ldv<V>(bn_beta + c, k.bt);
+      ldv<V>(bn_mean + c, k.mv);
+      ldv<V>(bn_invstd + c, k.iv);
+    }
+    return k;
+  }
+  template <int V>
+  __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[9][V], const DwBnCtx<V>& bn) const {
     if constexpr (V != 4) {
       return;  // the run path is only planned with 16-byte chunks (seg_plan vec_ok = true, C % 4 == 0)
     } else {
@@ -265,7 +306,11 @@ struct DwWgradRunOp {
       for (int b = 0; b < 6; ++b) {
         const bool ok = rowok && (b == 0 ? lok : (b == 5 ? rok : true));
         const int db = (b == 0 && !lok) ? 0 : ((b == 5 && !rok) ? 3 : b - 1);
-        const f32x4 t = ld4<T>(rowp + (int64_t)db * x_ld);
+        f32x4 t = ld4<T>(rowp + (int64_t)db * x_ld);
+        if constexpr (BN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = fmaf((t[e] - bn.mv[e]) * bn.iv[e], bn.gm[e], bn.bt[e]);
+        }
         v[b] = ok ? t : f32x4{0.f, 0.f, 0.f, 0.f};
         if constexpr (PRE) {
 #pragma unroll
@@ -329,13 +374,23 @@ int launch_dw_run(const DwRunParams<T>& p_in, hipStream_t st) {
     else if (p.relu_in) hipLaunchKernelGGL((dw_s1_run_kernel<RR_, T, true, false>), grid, dim3(256), 0, st, p);         \
     else hipLaunchKernelGGL((dw_s1_run_kernel<RR_, T, false, false>), grid, dim3(256), 0, st, p);                       \
   } while (0)
-  if (p.mask && p.relu_in) {
-    sg_set_error("dw_s1_run: mask and relu_in together");
+  if (p.mask && (p.relu_in || p.bn_gamma)) {
+    sg_set_error("dw_s1_run: mask together with relu_in / a fused BatchNormalization");
     return SG_EINVAL;
   }
-  if (rr == 4) SG_DW_RUN(4);
+#define SG_DW_RUN_BN(RR_)                                                                                               \
+  do {                                                                                                                  \
+    if (p.relu_in) hipLaunchKernelGGL((dw_s1_run_kernel<RR_, T, true, false, true>), grid, dim3(256), 0, st, p);        \
+    else hipLaunchKernelGGL((dw_s1_run_kernel<RR_, T, false, false, true>), grid, dim3(256), 0, st, p);                 \
+  } while (0)
+  if (p.bn_gamma) {
+    if (rr == 4) SG_DW_RUN_BN(4);
+    else if (rr == 2) SG_DW_RUN_BN(2);
+    else SG_DW_RUN_BN(1);
+  } else if (rr == 4) SG_DW_RUN(4);
   else if (rr == 2) SG_DW_RUN(2);
   else SG_DW_RUN(1);
+#undef SG_DW_RUN_BN
 #undef SG_DW_RUN
   SG_LAUNCH_CHECK("dw_s1_run_kernel");
   return 0;
@@ -570,11 +625,21 @@ void dw_fill(DwParams<T>& p, const sg_conv_desc* d) {
 
 extern "C" {
 
-int sg_dwconv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w, void* y,
-                    int pre_relu) {
+static int dwconv2d_fwd_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w, void* y,
+                             int pre_relu, const void* bn_gamma, const void* bn_beta, const void* bn_mean, const void* bn_invstd) {
   int rc = dw_check(ctx, dtype, d, "sg_dwconv2d_fwd");
   if (rc) return rc;
   SG_CHECK_ARG(x && w && y, "sg_dwconv2d_fwd: null tensor");
+  if (bn_gamma) {
+    SG_CHECK_ARG(bn_beta && bn_mean && bn_invstd, "sg_dwconv2d_fwd_bn: null BatchNormalization parameter");
+    const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+    if (!((d->Cin % 4 == 0) && (xl % 4 == 0) && (yl % 4 == 0) && sg_aligned16(x) && sg_aligned16(w) && sg_aligned16(y) &&
+          sg_aligned16(bn_gamma) && sg_aligned16(bn_beta) && sg_aligned16(bn_mean) && sg_aligned16(bn_invstd) && dw_run_ok(d))) {
+      sg_set_error("sg_dwconv2d_fwd_bn: only the stride-1 3x3 run kernels (W %% 4 == 0, C %% 4 == 0, 16-byte aligned) fuse the "
+                   "BatchNormalization; materialise it instead");
+      return SG_EUNSUPPORTED;
+    }
+  }
   SG_DTYPE_SWITCH(dtype, "sg_dwconv2d_fwd", {
     DwParams<T> p;
     dw_fill(p, d);
@@ -583,6 +648,7 @@ int sg_dwconv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     if (vec && dw_run_ok(d)) {
       DwRunParams<T> r;
       r.in = (const T*)x; r.w = (const float*)w; r.mask = nullptr; r.out = (T*)y;
+      r.bn_gamma = (const float*)bn_gamma; r.bn_beta = (const float*)bn_beta; r.bn_mean = (const float*)bn_mean; r.bn_invstd = (const float*)bn_invstd;
       r.N = d->N; r.H = d->H; r.W = d->W; r.C = p.C; r.in_ld = p.x_ld; r.out_ld = p.y_ld; r.mask_ld = 0;
       r.relu_in = pre_relu; r.flip = 0; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
       r.fd_rpr = make_fastdiv((uint32_t)r.runs_per_row); r.fd_h = make_fastdiv((uint32_t)d->H);
@@ -596,6 +662,17 @@ int sg_dwconv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   });
   SG_LAUNCH_CHECK("dw_fwd_kernel");
   return 0;
+}
+
+int sg_dwconv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w, void* y,
+                    int pre_relu) {
+  return dwconv2d_fwd_impl(ctx, stream, dtype, d, x, w, y, pre_relu, nullptr, nullptr, nullptr, nullptr);
+}
+
+int sg_dwconv2d_fwd_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w, void* y,
+                       const void* gamma, const void* beta, const void* mean, const void* invstd, int relu) {
+  SG_CHECK_ARG(gamma != nullptr, "sg_dwconv2d_fwd_bn: null gamma");
+  return dwconv2d_fwd_impl(ctx, stream, dtype, d, x, w, y, relu, gamma, beta, mean, invstd);
 }
 
 int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
@@ -613,6 +690,7 @@ int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
     if (vec && dw_run_ok(d)) {  // stride-1 dgrad = the same stencil with the kernel flipped
       DwRunParams<T> r;
       r.in = (const T*)dy; r.w = (const float*)w; r.mask = pre_relu ? (const T*)x_for_mask : nullptr; r.out = (T*)dx;
+      r.bn_gamma = r.bn_beta = r.bn_mean = r.bn_invstd = nullptr;
       r.N = d->N; r.H = d->H; r.W = d->W; r.C = p.C; r.in_ld = p.y_ld; r.out_ld = p.x_ld; r.mask_ld = p.x_ld;
       r.relu_in = 0; r.flip = 1; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
       r.fd_rpr = make_fastdiv((uint32_t)r.runs_per_row); r.fd_h = make_fastdiv((uint32_t)d->H);
@@ -638,11 +716,21 @@ size_t sg_dwconv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
   return m + 256;
 }
 
-int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
-                      void* dw, int pre_relu, void* ws, size_t ws_bytes) {
+static int dwconv2d_wgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
+                               void* dw, int pre_relu, void* ws, size_t ws_bytes, const void* bn_gamma, const void* bn_beta,
+                               const void* bn_mean, const void* bn_invstd) {
   int rc = dw_check(ctx, dtype, d, "sg_dwconv2d_wgrad");
   if (rc) return rc;
   SG_CHECK_ARG(x && dy && dw, "sg_dwconv2d_wgrad: null tensor");
+  if (bn_gamma) {
+    SG_CHECK_ARG(bn_beta && bn_mean && bn_invstd, "sg_dwconv2d_wgrad_bn: null BatchNormalization parameter");
+    const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+    if (!((d->Cin % 4 == 0) && (xl % 4 == 0) && (yl % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy) && sg_aligned16(bn_gamma) &&
+          sg_aligned16(bn_beta) && sg_aligned16(bn_mean) && sg_aligned16(bn_invstd) && dw_run_ok(d))) {
+      sg_set_error("sg_dwconv2d_wgrad_bn: only the stride-1 3x3 run kernels fuse the BatchNormalization; materialise it instead");
+      return SG_EUNSUPPORTED;
+    }
+  }
   SG_CHECK_ARG(d->KH == 3 && d->KW == 3, "sg_dwconv2d_wgrad: only 3x3 depthwise kernels occur on this path");
   SG_DTYPE_SWITCH(dtype, "sg_dwconv2d_wgrad", {
     DwWgradOp<T> op;
@@ -664,9 +752,21 @@ int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
       auto run = [&](auto ro) -> int {
         ro.x = (const T*)x; ro.dy = (const T*)dy; ro.dw = (float*)dw; ro.H = d->H; ro.W = d->W; ro.C = op.C;
         ro.x_ld = op.x_ld; ro.y_ld = op.y_ld;
+        ro.bn_gamma = (const float*)bn_gamma; ro.bn_beta = (const float*)bn_beta; ro.bn_mean = (const float*)bn_mean;
+        ro.bn_invstd = (const float*)bn_invstd;
         ro.fd_rpr = make_fastdiv((uint32_t)(d->W / 4)); ro.fd_h = make_fastdiv((uint32_t)(d->H / rr));
         return seg_reduce_launch(ro, rp, 1, nruns, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad_run");
       };
+      if (bn_gamma) {
+        if (pre_relu) {
+          if (rr == 4) return run(DwWgradRunOp<4, T, true, true>{});
+          if (rr == 2) return run(DwWgradRunOp<2, T, true, true>{});
+          return run(DwWgradRunOp<1, T, true, true>{});
+        }
+        if (rr == 4) return run(DwWgradRunOp<4, T, false, true>{});
+        if (rr == 2) return run(DwWgradRunOp<2, T, false, true>{});
+        return run(DwWgradRunOp<1, T, false, true>{});
+      }
       if (pre_relu) {
         if (rr == 4) return run(DwWgradRunOp<4, T, true>{});
         if (rr == 2) return run(DwWgradRunOp<2, T, true>{});
@@ -684,6 +784,18 @@ int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
     return seg_reduce_launch(op, pl, 1, rows, op.C, (float*)ws, (hipStream_t)stream, "dw_wgrad");
   });
   return 0;
+}
+
+int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
+                      void* dw, int pre_relu, void* ws, size_t ws_bytes) {
+  return dwconv2d_wgrad_impl(ctx, stream, dtype, d, x, dy, dw, pre_relu, ws, ws_bytes, nullptr, nullptr, nullptr, nullptr);
+}
+
+int sg_dwconv2d_wgrad_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy, void* dw,
+                         const void* gamma, const void* beta, const void* mean, const void* invstd, int relu, void* ws,
+                         size_t ws_bytes) {
+  SG_CHECK_ARG(gamma != nullptr, "sg_dwconv2d_wgrad_bn: null gamma");
+  return dwconv2d_wgrad_impl(ctx, stream, dtype, d, x, dy, dw, relu, ws, ws_bytes, gamma, beta, mean, invstd);
 }
 
 int sg_maxpool_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride, int pad_t,

@@ -151,6 +151,7 @@ class _SepConvNode(Node):
         super().__init__(name)
         self.filters, self.stride, self.activation = filters, stride, activation
         self.pre_relu = False  # set by the fusion pass when the producer is a single-consumer ReLU
+        self.bn_src = None     # set by the fusion pass: the training-mode BatchNormalization(+ReLU) applied in the gather
 
     def build(self, x):
         _, h, w, c = x.shape
@@ -168,9 +169,15 @@ class _SepConvNode(Node):
     def forward(self, rt, xs, training):
         (x,) = xs
         e = rt.eng
-        t = e.dwconv_fwd(x, rt.param(self.dw), self.stride, self.pre_relu)
+        bn = None
+        if training and self.bn_src is not None:
+            sv = rt._saved.get(id(self.bn_src))
+            if sv is not None and sv.get("deferred"):  # x is that layer's RAW input: normalise (+ReLU) while gathering
+                src = self.bn_src
+                bn = (rt.param(src.gamma), rt.param(src.beta), sv["mean"], sv["invstd"], src.relu)
+        t = e.dwconv_fwd(x, rt.param(self.dw), self.stride, self.pre_relu, bn=bn)
         if training:
-            rt.save(self, t=t)
+            rt.save(self, t=t, bn=bn)
             if getattr(self, "emit_bn_stats", False):
                 y, st = e.conv2d_fwd(t, rt.param(self.pw), rt.param(self.b), want_stats=True, planes=rt.planes(self, "f"))
                 if st is not None:
@@ -188,7 +195,7 @@ class _SepConvNode(Node):
         e.conv2d_wgrad(t, dz, dpw, want_b, dw=rt.grad(self.pw), db=rt.grad(self.b) if want_b else None)
         dt = e.conv2d_dgrad(dz, rt.param(self.pw), dpw, planes=rt.planes(self, "d"))
         ddw = e.conv_desc(tuple(x.shape), x.shape[-1], 3, 3, self.stride, 1, "same")
-        e.dwconv_wgrad(x, dt, ddw, self.pre_relu, dw=rt.grad(self.dw))
+        e.dwconv_wgrad(x, dt, ddw, self.pre_relu, dw=rt.grad(self.dw), bn=rt.saved(self).get("bn"))
         dx = e.dwconv_dgrad(dt, rt.param(self.dw), ddw, x=x, pre_relu=self.pre_relu) if rt.needs_grad(self.inputs[0]) else None
         return [dx]
 
@@ -330,6 +337,7 @@ class _BNNode(Node):
         super().__init__(name)
         self.momentum, self.epsilon = momentum, epsilon
         self.relu = False  # fused by the optimisation pass when followed by a single-consumer ReLU
+        self.defer_to = None  # fused by the optimisation pass: the SeparableConv2D that applies this layer in its gather
 
     def build(self, x):
         c = x.shape[-1]
@@ -345,9 +353,13 @@ class _BNNode(Node):
         if training:
             st = rt.bn_stats.pop(id(x), None)
             if st is not None:  # statistics already produced by the conv that wrote x
+                defer = self.defer_to is not None
                 y, mean, invstd = e.bn_train_fwd_from_tiles(x, st[0], st[1], rt.param(self.gamma), rt.param(self.beta),
                                                             rt.param(self.mm), rt.param(self.mv), relu=self.relu,
-                                                            momentum=self.momentum, eps=self.epsilon)
+                                                            momentum=self.momentum, eps=self.epsilon, apply=not defer)
+                if defer:  # the consumer's depthwise gather normalises: this layer's "output" is its raw input
+                    rt.save(self, mean=mean, invstd=invstd, deferred=True)
+                    return x
             else:
                 y, mean, invstd = e.bn_train_fwd(x, rt.param(self.gamma), rt.param(self.beta), rt.param(self.mm),
                                                  rt.param(self.mv), relu=self.relu, momentum=self.momentum, eps=self.epsilon)

@@ -288,11 +288,18 @@ class Engine:
         return db
 
     # --------------------------------------------------------------------------------------- depthwise
-    def dwconv_fwd(self, x, w, stride=1, pre_relu=False, out=None, desc=None):
+    def dwconv_fwd(self, x, w, stride=1, pre_relu=False, out=None, desc=None, bn=None):
+        """bn = (gamma, beta, mean, invstd, relu): x is the RAW input of a training-mode BatchNormalization(+ReLU) whose
+        output this depthwise convolution consumes; the normalisation is applied in the gather (sg_dwconv2d_fwd_bn)."""
         _chk(x, "x"); _chk(w, "w")
         kh, kw, c = w.shape[0], w.shape[1], w.shape[2]
         d = desc or self.conv_desc(x.shape, c, kh, kw, stride, 1, "same")
         y = out if out is not None else self.empty(d.N, d.Ho, d.Wo, c, dtype=x.dtype)
+        if bn is not None:
+            gamma, beta, mean, invstd, relu = bn
+            check(self.lib.sg_dwconv2d_fwd_bn(self.h, self.stream, _dt(x), C.byref(d), _ptr(x), _ptr(w), _ptr(y), _ptr(gamma),
+                                              _ptr(beta), _ptr(mean), _ptr(invstd), int(relu)), "sg_dwconv2d_fwd_bn")
+            return y
         check(self.lib.sg_dwconv2d_fwd(self.h, self.stream, _dt(x), C.byref(d), _ptr(x), _ptr(w), _ptr(y), int(pre_relu)),
               "sg_dwconv2d_fwd")
         return y
@@ -303,11 +310,16 @@ class Engine:
                                          int(pre_relu)), "sg_dwconv2d_dgrad")
         return dx
 
-    def dwconv_wgrad(self, x, dy, d: ConvDesc, pre_relu=False, dw=None):
+    def dwconv_wgrad(self, x, dy, d: ConvDesc, pre_relu=False, dw=None, bn=None):
         if dw is None:
             dw = self.empty(d.KH, d.KW, d.Cin, 1)
         need = self.lib.sg_dwconv2d_wgrad_ws_bytes(self.h, C.byref(d))
         wsp, wsn = self.ws(need)
+        if bn is not None:  # see dwconv_fwd
+            gamma, beta, mean, invstd, relu = bn
+            check(self.lib.sg_dwconv2d_wgrad_bn(self.h, self.stream, _dt(x), C.byref(d), _ptr(x), _ptr(dy), _ptr(dw), _ptr(gamma),
+                                                _ptr(beta), _ptr(mean), _ptr(invstd), int(relu), wsp, wsn), "sg_dwconv2d_wgrad_bn")
+            return dw
         check(self.lib.sg_dwconv2d_wgrad(self.h, self.stream, _dt(x), C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
                                          int(pre_relu), wsp, wsn), "sg_dwconv2d_wgrad")
         return dw
@@ -325,18 +337,22 @@ class Engine:
                                        int(x.dim() == 4), wsp, wsn), "sg_bn_train_fwd")
         return y, mean, invstd
 
-    def bn_train_fwd_from_tiles(self, x, stats, tiles, gamma, beta, mm, mv, relu=False, momentum=0.99, eps=1e-3, out=None):
-        """Training forward with the statistics the producing conv left in `stats` (conv2d_fwd(want_stats=True))."""
+    def bn_train_fwd_from_tiles(self, x, stats, tiles, gamma, beta, mm, mv, relu=False, momentum=0.99, eps=1e-3, out=None,
+                                apply=True):
+        """Training forward with the statistics the producing conv left in `stats` (conv2d_fwd(want_stats=True)).
+        apply=False: statistics (and the moving averages) only - the consumer applies the normalisation itself
+        (dwconv_fwd(bn=...)); returns (None, mean, invstd)."""
         c = x.shape[-1]
         rows = x.numel() // c
-        y = out if out is not None else torch.empty_like(x)
+        y = (out if out is not None else torch.empty_like(x)) if apply else None
         mean, invstd = self.empty(c), self.empty(c)
         wsp, wsn = self.ws(self.lib.sg_bn_tiles_ws_bytes(self.h, int(tiles), c))
         check(self.lib.sg_bn_train_fwd_tiles(self.h, self.stream, _dt(x), rows, c, _ptr(stats), int(tiles), _ptr(mm), _ptr(mv),
                                              _ptr(mean), _ptr(invstd), momentum, eps, int(x.dim() == 4), wsp, wsn),
               "sg_bn_train_fwd_tiles")
-        check(self.lib.sg_bn_apply(self.h, self.stream, _dt(x), rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean),
-                                   _ptr(invstd), _ptr(y), int(relu)), "sg_bn_apply")
+        if apply:
+            check(self.lib.sg_bn_apply(self.h, self.stream, _dt(x), rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean),
+                                       _ptr(invstd), _ptr(y), int(relu)), "sg_bn_apply")
         return y, mean, invstd
 
     def bn_train_bwd(self, x, y, dy, gamma, mean, invstd, relu=False, out=None, dgamma=None, dbeta=None, beta=None):

@@ -139,6 +139,26 @@ class Model:
             cons = n.output.consumers
             if len(cons) == 1 and isinstance(cons[0], L._SepConvNode) and id(n.output) not in outs and not cons[0].pre_relu:
                 cons[0].pre_relu, n.fused_away = True, True
+        # BatchNormalization (+ fused ReLU) -> SeparableConv2D, training mode: the depthwise gather applies the normalisation
+        # to the raw tensor (sg_dwconv2d_fwd_bn / _wgrad_bn), so the normalised tensor is never written or read - two of the
+        # layer's seven tensor passes.  Needs the statistics from the producing convolution's epilogue (decided at run
+        # time: _BNNode.forward falls back to the materialising form) and the stride-1 run kernels' geometry.
+        # Default OFF: measured on the DeepLabv3+ step the 39 dropped bn_apply launches save 1.05 ms and the
+        # depthwise kernels, which are instruction- not bandwidth-bound, give 0.8 ms of it back (fp32 -0.3 ms, bf16 0.0).
+        if os.environ.get("SG_BN_DEFER", "0") == "1":
+            for n in self.nodes:
+                if not isinstance(n, L._BNNode) or len(n.output.shape) != 4 or id(n.output) in outs:
+                    continue
+                t = n.output
+                while (len(t.consumers) == 1 and isinstance(t.consumers[0], L._ActNode) and t.consumers[0].fused_away
+                       and id(t.consumers[0].output) not in outs):
+                    t = t.consumers[0].output
+                if len(t.consumers) != 1 or not isinstance(t.consumers[0], L._SepConvNode) or id(t) in outs:
+                    continue
+                sc = t.consumers[0]
+                _, h, w, c = t.shape
+                if sc.stride == 1 and not sc.pre_relu and sc.bn_src is None and w % 4 == 0 and c % 4 == 0:
+                    n.defer_to, sc.bn_src = sc, n
 
     def _layout_params(self):
         self.params: List[ParamSpec] = [p for n in self.nodes for p in n.params]

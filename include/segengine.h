@@ -153,6 +153,19 @@ int sg_dwconv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
                     const void* w, void* y, int pre_relu);
 int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
                       const void* w, const void* x_for_mask, void* dx, int pre_relu);
+/* The depthwise convolution of a SeparableConv2D whose input is BatchNormalization(+ReLU) of a tensor x_raw, in training
+ * mode, with that normalisation applied as the window is loaded - fmaf((x - mean) * invstd, gamma, beta), then max(., 0) if
+ * relu - so that the normalised tensor is never written (the pattern BatchNormalization -> Activation('relu') ->
+ * SeparableConv2D of the Xception middle flow, predict_model/v3plus.py:170-260).  x is x_raw; mean / invstd are the batch
+ * statistics sg_bn_train_fwd / sg_bn_train_fwd_tiles saved.  Stride-1 3x3, W % 4 == 0, C % 4 == 0, 16-byte aligned tensors
+ * only (SG_EUNSUPPORTED otherwise: apply sg_bn_apply and call the plain entry points).  sg_dwconv2d_wgrad_bn is the filter
+ * gradient of the same layer (workspace: sg_dwconv2d_wgrad_ws_bytes); the input gradient is sg_dwconv2d_dgrad without a mask
+ * (the ReLU's mask belongs to sg_bn_train_bwd, which recomputes it from x_raw). */
+int sg_dwconv2d_fwd_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w, void* y,
+                       const void* gamma, const void* beta, const void* mean, const void* invstd, int relu);
+int sg_dwconv2d_wgrad_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy, void* dw,
+                         const void* gamma, const void* beta, const void* mean, const void* invstd, int relu, void* ws,
+                         size_t ws_bytes);
 size_t sg_dwconv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d);
 int sg_dwconv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
                       const void* dy, void* dw, int pre_relu, void* ws, size_t ws_bytes);

@@ -562,3 +562,43 @@ def test_jit_compiled_train_step_is_bit_identical_to_the_eager_one(engine, polic
     for wa, wb in zip(ma.get_weights(), mb.get_weights()):
         assert np.array_equal(wa, wb)
     assert np.array_equal(ma.predict(xv), mb.predict(xv))
+
+
+@pytest.mark.parametrize("policy", ["float32", "mixed_bfloat16"])
+def test_batchnorm_applied_in_the_depthwise_gather(engine, policy, monkeypatch):
+    """Fusion BatchNormalization(+ReLU) -> SeparableConv2D (training): the depthwise gather normalises the raw tensor with
+    bn_apply's own expression, the normalised tensor is never materialised (SG_BN_DEFER=1; off by default: no net gain).  In fp32 that is the
+    same arithmetic: loss, gradients and the weights after two Adam steps must equal the materialising graph's to the bit.
+    With bf16 storage the fused form skips one rounding (the stored normalised tensor), so it is compared within the mode's
+    tolerance instead.  The fused graph must actually contain deferred layers."""
+    from building_detection_amd import mixed_precision as MP, zoo
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss
+    from building_detection_amd import layers as L
+    MP.set_global_policy(policy)
+    try:
+        monkeypatch.setenv("SG_BN_DEFER", "0")
+        ma = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+        monkeypatch.setenv("SG_BN_DEFER", "1")
+        mb = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+    finally:
+        MP.set_global_policy("float32")
+    n_def = sum(1 for n in mb.nodes if isinstance(n, L._BNNode) and n.defer_to is not None)
+    assert n_def >= 30 and not any(isinstance(n, L._BNNode) and n.defer_to is not None for n in ma.nodes), n_def
+    mb.set_weights(ma.get_weights())
+    x, y = synthetic_batch(2, 64, 64, seed=77)
+    for m in (ma, mb):
+        m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
+    exact = policy == "float32"
+    for step in range(2):
+        la, lb = ma.train_on_batch(x, y), mb.train_on_batch(x, y)
+        if exact:
+            assert la["loss"] == lb["loss"], (step, la, lb)
+            for ga, gb in zip(ma.get_gradients(), mb.get_gradients()):
+                assert np.array_equal(ga, gb)
+        else:
+            assert abs(la["loss"] - lb["loss"]) <= 2e-2 * abs(la["loss"]), (step, la, lb)
+    if exact:
+        for wa, wb in zip(ma.get_weights(), mb.get_weights()):
+            assert np.array_equal(wa, wb)
+    assert np.array_equal(ma.predict(x), mb.predict(x)) or not exact   # inference never defers: same graph, same weights
