@@ -72,6 +72,19 @@ class TorchTransport:
     def barrier(self):
         self.dist.barrier(group=self.group)
 
+    def scalar(self, v: float):
+        """A one-element fp32 tensor where this transport can reduce it (device memory for nccl, host for gloo)."""
+        import torch
+        t = torch.tensor([float(v)], dtype=torch.float32)
+        return t.cuda() if self.dist.get_backend(self.group) == "nccl" else t
+
+
+def _unique_id(lib, _lib) -> bytes:
+    """The 128 opaque bytes of an RCCL unique id (sg_comm_unique_id); raises SgError when RCCL cannot be loaded."""
+    buf = C.create_string_buffer(_lib.SG_COMM_ID_BYTES)
+    _lib.check(lib.sg_comm_unique_id(buf), "sg_comm_unique_id")
+    return bytes(buf.raw)
+
 
 class SgTransport:
     """RCCL through libsegengine's C ABI (sg_comm_*), on a communication stream of its own.
@@ -89,14 +102,22 @@ class SgTransport:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = torch.device("cuda", device) if isinstance(device, int) else device
-        ident = [None]
+        # Rank 0 draws the RCCL id; EVERY rank then takes part in the broadcast, whatever happened on rank 0: a failure
+        # there (no usable librccl for dlopen - the one case DataParallel's "sg_or_torch" fallback exists for) travels as
+        # (None, message), so that all ranks raise the same error after the same collective and meet again in the
+        # caller's next one, instead of rank 0 leaving the others waiting inside this broadcast.
+        ident = [(None, None)]
         if self.rank == 0:
-            buf = C.create_string_buffer(_lib.SG_COMM_ID_BYTES)
-            _lib.check(self.lib.sg_comm_unique_id(buf), "sg_comm_unique_id")
-            ident[0] = bytes(buf.raw)
+            try:
+                ident[0] = (_unique_id(self.lib, _lib), None)
+            except Exception as e:
+                ident[0] = (None, f"{type(e).__name__}: {e}")
         dist.broadcast_object_list(ident, src=0, group=group)  # any backend: the id is 128 opaque host bytes
+        uid, err = ident[0]
+        if uid is None:
+            raise _lib.SgError(f"sg_comm_unique_id failed on rank 0: {err}")
         h = C.c_void_p()
-        _lib.check(self.lib.sg_comm_init(ident[0], self.rank, self.world, self.device.index, C.byref(h)), "sg_comm_init")
+        _lib.check(self.lib.sg_comm_init(uid, self.rank, self.world, self.device.index, C.byref(h)), "sg_comm_init")
         self.h = h
         self.stream = torch.cuda.Stream(self.device)
         self._pending = False
@@ -132,6 +153,9 @@ class SgTransport:
         self.join()
         self.torch.cuda.current_stream(self.device).synchronize()
 
+    def scalar(self, v: float):
+        return self.torch.tensor([float(v)], dtype=self.torch.float32, device=self.device)
+
     def close(self):
         if getattr(self, "h", None):
             self.torch.cuda.synchronize(self.device)
@@ -143,6 +167,46 @@ class SgTransport:
             self.close()
         except Exception:
             pass
+
+
+def make_transport(comm: str, device, group=None, fallback_backend: str = "nccl"):
+    """The gradient transport of a DataParallel model.
+
+    comm: "torch" | "sg" | "sg_or_torch" | "auto" (torch on an nccl group, sg otherwise).  "sg_or_torch" falls back to
+    torch.distributed when libsegengine cannot bring RCCL up.  The decision is a collective: SgTransport.__init__ lets
+    every rank see rank 0's failure (same broadcast, same exception), then all ranks sum a failure flag - also covering a
+    rank-local failure after the broadcast - and take the same branch.  `fallback_backend` is "nccl" in production; the
+    CPU tests pass "gloo"."""
+    import torch
+    import torch.distributed as dist
+    if comm == "auto":
+        comm = "torch" if dist.get_backend(group) == "nccl" else "sg"
+    if comm == "torch":
+        return TorchTransport(group)
+    if comm not in ("sg", "sg_or_torch"):
+        raise ValueError(f"comm={comm!r}")
+    tp, err = None, None
+    try:
+        tp = SgTransport(device, group)
+    except Exception as e:  # e.g. no usable librccl for dlopen
+        err = e
+    if comm == "sg":
+        if tp is None:
+            raise err
+        return tp
+    flag = torch.tensor([0 if tp is not None else 1], dtype=torch.int32)
+    if dist.get_backend(group) == "nccl":
+        flag = flag.to(device)
+    dist.all_reduce(flag, group=group)
+    if int(flag.item()) > 0:  # somebody failed: all fall back to torch.distributed
+        import sys
+        print(f"[dist] sg_comm transport unavailable ({err!r}); falling back to torch.distributed {fallback_backend}",
+              file=sys.stderr)
+        if tp is not None:
+            tp.close()
+        g2 = group if dist.get_backend(group) == fallback_backend else dist.new_group(backend=fallback_backend)
+        tp = TorchTransport(g2)
+    return tp
 
 
 class BucketReducer:
@@ -187,31 +251,7 @@ class DataParallel:
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         model.dist = self
         rt = model._runtime()
-        if comm == "auto":
-            comm = "torch" if dist.get_backend(group) == "nccl" else "sg"
-        if comm in ("sg", "sg_or_torch"):
-            self.tp, err = None, None
-            try:
-                self.tp = SgTransport(rt.eng.device, group)
-            except Exception as e:  # e.g. no usable librccl for dlopen: every rank must take the same way out
-                err = e
-            if comm == "sg_or_torch":
-                import torch
-                flag = torch.tensor([0 if self.tp is not None else 1], dtype=torch.int32)
-                if dist.get_backend(group) == "nccl":
-                    flag = flag.to(rt.eng.device)
-                dist.all_reduce(flag, group=group)
-                if int(flag.item()) > 0:  # somebody failed: all fall back to torch.distributed's RCCL
-                    import sys
-                    print(f"[dist] sg_comm transport unavailable ({err!r}); falling back to torch.distributed nccl", file=sys.stderr)
-                    if self.tp is not None:
-                        self.tp.close()
-                    g2 = group if dist.get_backend(group) == "nccl" else dist.new_group(backend="nccl")
-                    self.tp = TorchTransport(g2)
-            elif self.tp is None:
-                raise err
-        else:
-            self.tp = TorchTransport(group)
+        self.tp = make_transport(comm, rt.eng.device, group)
         self.world, self.rank = self.tp.world, self.tp.rank
         # identical replicas: broadcast rank-0 weights and BN statistics once
         self.tp.broadcast(rt.w_train, src=0)
@@ -245,6 +285,14 @@ class DataParallel:
 
     def barrier(self):
         self.tp.barrier()
+
+    def any_failed(self, failed: bool) -> bool:
+        """Collective OR of a per-rank failure flag (also a barrier): lets every rank leave a collective section the same
+        way when one of them - rank 0 writing a checkpoint - hit an error."""
+        t = self.tp.scalar(1.0 if failed else 0.0)
+        self.tp.allreduce_async(t)
+        self.tp.join()
+        return float(t.item()) > 0.0
 
 
 def param_ranges(model) -> List[Tuple[int, int, int]]:

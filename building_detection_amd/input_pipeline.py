@@ -152,42 +152,55 @@ class Prefetcher:
         self._thread = threading.Thread(target=self._run, daemon=True)
         self._thread.start()
 
+    def _put(self, item) -> bool:
+        """Blocking put that gives up when close() was called (a consumer that has gone away must not pin this thread -
+        and, on the GPU path, its pinned batches - forever).  True when the item was queued."""
+        while not self._stop.is_set():
+            try:
+                self._q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
     def _run(self):
         try:
             for item in self._gen:
-                while not self._stop.is_set():
-                    try:
-                        self._q.put(item, timeout=0.1)
-                        break
-                    except queue.Full:
-                        continue
-                if self._stop.is_set():
+                if not self._put(item):
                     return
-            self._q.put(self._END)
+            self._put(self._END)
         except BaseException as e:  # hand the failure to the consumer
-            self._q.put(e)
+            self._put(e)
 
     def __iter__(self):
         return self
 
     def __next__(self):
-        item = self._q.get()
-        if item is self._END:
-            self._q.put(self._END)
+        final = getattr(self, "_final", None)
+        if final is None:
+            item = self._q.get()
+            if not (item is self._END or isinstance(item, BaseException)):
+                return item
+            final = self._final = item   # remembered, not re-queued (a consumer must never block on a put of its own)
+        if final is self._END:
             raise StopIteration
-        if isinstance(item, BaseException):
-            self._q.put(item)
-            raise item
-        return item
+        raise final
 
     def close(self):
+        """Stops the producer and joins it: the queue is drained until the thread has really exited (a put racing with a
+        single drain could otherwise refill it and leave the join to time out)."""
         self._stop.set()
+        while self._thread.is_alive():
+            try:
+                self._q.get(timeout=0.05)
+            except queue.Empty:
+                pass
+            self._thread.join(timeout=0.05)
         while True:
             try:
                 self._q.get_nowait()
             except queue.Empty:
                 break
-        self._thread.join(timeout=5)
 
     def __del__(self):
         try:

@@ -231,14 +231,21 @@ class Model:
         """Under data parallelism the BatchNorm moving statistics of the replicas are averaged first and only rank 0
         writes the file; every rank must call it (it is a collective then)."""
         from .weights_io import save_weights
-        if self.dist is not None:
-            self.dist.sync_moving_stats(self._runtime())
-            if self.dist.rank != 0:
-                self.dist.barrier()
-                return
-        save_weights(self, path)
-        if self.dist is not None:
-            self.dist.barrier()
+        if self.dist is None:
+            save_weights(self, path)
+            return
+        self.dist.sync_moving_stats(self._runtime())
+        err = None
+        if self.dist.rank == 0:
+            try:
+                save_weights(self, path)
+            except Exception as e:  # the other ranks are about to enter the collective below: meet them there first
+                err = e
+        failed = self.dist.any_failed(err is not None)  # collective OR of the outcome; doubles as the barrier
+        if err is not None:
+            raise err
+        if failed:
+            raise RuntimeError(f"save_weights({path!r}) failed on rank 0")
 
     def load_weights(self, path):
         from .weights_io import load_weights
@@ -356,6 +363,8 @@ class Model:
             p = rt.forward(xd, training=False)
             loss = rt.eng.loss_fwd(self.loss_kind, p, yd)
             counts = rt.eng.confusion_counts(p, yd) if self.metric_names else None
+            if self.dist is not None:  # val_* logs describe the GLOBAL validation batch on every rank, as the training
+                loss, counts = self.dist.reduce_step_scalars(loss, counts)  # logs do: callbacks then decide alike
             rt.release()
         return self._logs(loss, counts)
 
@@ -442,7 +451,7 @@ class GraphedPredict:
         eng = rt.eng
         with eng.lock:
             self.x = eng.zeros(*shape)
-            eng._ws_peak = 0
+            peak_before, eng._ws_peak = eng._ws_peak, 0
             for _ in range(2):  # warm-up outside capture: first-launch attribute calls, and the sizing pass of the scratch
                 rt.forward(self.x, training=False)
                 rt.release()
@@ -450,6 +459,8 @@ class GraphedPredict:
             # The graph's kernel nodes carry the scratch pointer: give this graph a buffer of its own (sized by the
             # warm-up pass), never the engine's shared one, which a later eager call or another model may re-grow.
             self.ws = torch.empty(max(eng._ws_peak, 256) + 256, dtype=torch.uint8, device=eng.device)
+            # the engine-wide peak stays monotone: a training-step capture that follows sizes its buffer by it
+            eng._ws_peak = max(eng._ws_peak, peak_before)
             self.graph = torch.cuda.CUDAGraph()
             with eng.private_ws(self.ws):
                 with torch.cuda.graph(self.graph):
@@ -491,7 +502,13 @@ class GraphedTrainStep:
         self.lr = eng.zeros(4)
         self.ws = torch.empty(max(eng._ws_peak, 256) + 256, dtype=torch.uint8, device=eng.device)
         rt.release()
+        # The job table of the weight planes is (re)built HERE, outside the capture, for this batch and mode: a forward with
+        # another batch size since the eager warm-up steps (a validation batch, a predict()) has re-keyed the runtime's
+        # planes, and the rebuild allocates the plane arena and copies the table from pageable host memory - neither may
+        # happen inside a stream capture.  What the capture then records of ensure_planes is the one sg_prepare_planes launch.
+        rt.ensure_planes(int(xd.shape[0]), True)
         rt.weights_changed()  # the graph must contain the plane preparation: every replay follows an optimiser step
+        self._planes_key = rt._planes_key
         torch.cuda.synchronize(eng.device)
         self.graph = torch.cuda.CUDAGraph()
         with eng.private_ws(self.ws):
@@ -503,6 +520,7 @@ class GraphedTrainStep:
                 rt.backward(dp)
                 eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, 0.0, opt.beta_1, opt.beta_2, opt.epsilon, 1.0,
                               lr_dev=self.lr)
+        assert rt._planes_key == self._planes_key, "the weight-plane job table was rebuilt inside the capture"
         self._planes = (rt._planes_arena, rt._planes_jobs)  # kept alive: the graph's nodes carry their addresses
         rt.release()
         rt.weights_changed()

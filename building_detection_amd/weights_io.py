@@ -15,9 +15,9 @@ reference handles (predict.py:23); an HDF5 file outside the supported subset rai
 reason.  UNPINNED: no real Keras file has been read by this code (none exists here, nor h5py to make one); the tests pin
 the writer against the reader and the reader against a byte-level fixture assembled from the specification.
 
-Layer matching (Keras `load_weights`, by_name=False, walks `model.layers` with weights in order): first by position; if
-the shapes then disagree (Keras orders `model.layers` by graph depth, this engine by creation), by (layer class, ordinal
-within the class) - `conv2d_7` is the 8th Conv2D created whatever the global uid offset of the session that saved it.
+Layer matching: `_match_layers` - exact layer names, else (layer class, ordinal within the class), position only as a
+last resort and with a warning (Keras orders `model.layers` by graph depth, this engine by creation; a positional fit of
+equal-shaped parallel layers can be a coincidence).
 """
 from __future__ import annotations
 
@@ -128,30 +128,64 @@ def load_weights(model, path):
         return
     file_layers = _read_keras_h5(path)
     ours = _layers_with_weights(model)
-
-    def fits(pairs):
-        return all(len(fw) == len(ps) and all(tuple(a.shape) == tuple(p.shape) for a, p in zip(fw, ps)) for (_, fw), (_, ps) in pairs)
-
-    if len(file_layers) != len(ours):
-        raise ValueError(f"{path}: {len(file_layers)} layers with weights, the model has {len(ours)}")
-    pairs = list(zip(file_layers, ours))
-    if not fits(pairs):
-        def ranked(layers):
-            by = {}
-            for item in layers:
-                cls, idx = _class_key(item[0])
-                by.setdefault(cls, []).append((idx, item))
-            return {cls: [it for _, it in sorted(v, key=lambda t: t[0])] for cls, v in by.items()}
-        rf, ro = ranked(file_layers), ranked(ours)
-        if set(rf) != set(ro) or any(len(rf[c]) != len(ro[c]) for c in rf):
-            raise ValueError(f"{path}: layer classes differ from the model's: file {sorted((c, len(v)) for c, v in rf.items())}, "
-                             f"model {sorted((c, len(v)) for c, v in ro.items())}")
-        pairs = [(a, b) for c in rf for a, b in zip(rf[c], ro[c])]
-        if not fits(pairs):
-            bad = next((a[0], b[0]) for a, b in pairs if not fits([(a, b)]))
-            raise ValueError(f"{path}: weight shapes of file layer {bad[0]!r} do not match model layer {bad[1]!r}")
+    pairs = _match_layers(path, file_layers, ours)
     value = {}
     for (_, fw), (_, ps) in pairs:
         for a, p in zip(fw, ps):
             value[id(p)] = np.asarray(a, dtype=np.float32)
     model.set_weights([value[id(p)] for p in model.params])
+
+
+def _fits(pairs) -> bool:
+    return all(len(fw) == len(ps) and all(tuple(a.shape) == tuple(p.shape) for a, p in zip(fw, ps)) for (_, fw), (_, ps) in pairs)
+
+
+def _first_misfit(pairs):
+    return next((a[0], b[0]) for a, b in pairs if not _fits([(a, b)]))
+
+
+def _match_layers(path, file_layers, ours):
+    """Pairs (file layer, model layer).  Keras writes `layer_names` in `model.layers` order - sorted by graph depth - while this
+    engine lists layers in creation order, and branched graphs hold equal-shaped parallel layers (ASPP rates 6 / 12 / 18,
+    the SK branches, HRNet's stages): a positional pairing can fit every shape by coincidence and still put weights on the
+    wrong layers.  So the layer's identity decides, in this order:
+      1. exact layer names, when the file's set of names is the model's;
+      2. (layer class, ordinal within the class): `conv2d_7` is the 8th Conv2D created, whatever uid offset the saving
+         session had reached - file and model are each ranked per class and paired rank by rank;
+      3. position, only when the names carry no usable class structure (custom `name=` arguments), and with a warning.
+    A pairing chosen by 1 or 2 whose shapes do not fit is an error (another architecture), never a reason to try 3."""
+    if len(file_layers) != len(ours):
+        raise ValueError(f"{path}: {len(file_layers)} layers with weights, the model has {len(ours)}")
+    fnames, onames = [n for n, _ in file_layers], [n for n, _ in ours]
+    if len(set(fnames)) == len(fnames) and set(fnames) == set(onames):
+        by = dict(ours)
+        pairs = [((n, fw), (n, by[n])) for n, fw in file_layers]
+        if not _fits(pairs):
+            bad = _first_misfit(pairs)
+            raise ValueError(f"{path}: weight shapes of layer {bad[0]!r} do not match the model's layer of that name")
+        return pairs
+
+    def ranked(layers):
+        by = {}
+        for item in layers:
+            cls, idx = _class_key(item[0])
+            by.setdefault(cls, []).append((idx, item))
+        return {cls: [it for _, it in sorted(v, key=lambda t: t[0])] for cls, v in by.items()}
+
+    rf, ro = ranked(file_layers), ranked(ours)
+    if set(rf) == set(ro) and all(len(rf[c]) == len(ro[c]) for c in rf):
+        pairs = [(a, b) for c in rf for a, b in zip(rf[c], ro[c])]
+        if not _fits(pairs):
+            bad = _first_misfit(pairs)
+            raise ValueError(f"{path}: weight shapes of file layer {bad[0]!r} do not match model layer {bad[1]!r}")
+        return pairs
+    pairs = list(zip(file_layers, ours))
+    if not _fits(pairs):
+        raise ValueError(f"{path}: layer classes differ from the model's (file {sorted((c, len(v)) for c, v in rf.items())}, "
+                         f"model {sorted((c, len(v)) for c, v in ro.items())}) and the layers do not fit by position either: "
+                         f"file layer {_first_misfit(pairs)[0]!r}")
+    import warnings
+    warnings.warn(f"{path}: layer names match neither the model's names nor its (class, ordinal) structure; weights were "
+                  "assigned BY POSITION (every shape fits, but equal-shaped parallel layers may be permuted if the file was "
+                  "written in another layer order)", RuntimeWarning, stacklevel=3)
+    return pairs

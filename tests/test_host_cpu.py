@@ -325,3 +325,57 @@ def test_data_parallel_real_graph_sweep_gloo_world2():
     for rank, ok, nb in res:
         assert ok, f"rank {rank}: reduced arena != sum of the per-rank gradients"
         assert nb >= 4
+
+
+def _fallback_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import datetime
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from building_detection_amd import _lib, dist as D
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+
+    def no_rccl(lib, _l):
+        raise _lib.SgError("sg_comm_unique_id: librccl.so could not be loaded (test)")
+    D._unique_id = no_rccl   # only rank 0 ever calls it
+    # comm="sg": every rank raises the SAME error, after the same broadcast ...
+    try:
+        D.make_transport("sg", 0)
+        same_error = False
+    except _lib.SgError as e:
+        same_error = "rank 0" in str(e) and "librccl" in str(e)
+    # ... so they are still in step: the next collective pairs up
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t)
+    # comm="sg_or_torch": all ranks fall back together and the fallback transport carries a reduction
+    tp = D.make_transport("sg_or_torch", 0, fallback_backend="gloo")
+    g = torch.full((5,), float(rank + 1))
+    tp.allreduce_async(g)
+    tp.join()
+    q.put((rank, same_error, float(t.item()), tp.name, g.tolist()))
+    dist.destroy_process_group()
+
+
+def test_sg_comm_failure_on_rank0_keeps_the_ranks_in_step_gloo_world2():
+    """ADVICE r2 (dist.py:95): when rank 0 cannot draw the RCCL id (no librccl to dlopen - the case the sg_or_torch fallback
+    exists for) it used to raise BEFORE the id broadcast and go on to the flag all-reduce, while the other ranks waited inside
+    broadcast_object_list: mismatched collectives, a hang.  Now the failure travels through the broadcast as a sentinel,
+    every rank raises the same error and all of them meet in the next collective."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=120) for _ in procs]
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    for rank, same_error, s, name, g in sorted(res):
+        assert same_error, f"rank {rank} did not see rank 0's sg_comm_unique_id failure"
+        assert s == 3.0
+        assert name == "torch" and g == [3.0] * 5

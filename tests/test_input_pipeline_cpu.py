@@ -120,3 +120,35 @@ def test_prefetcher_keeps_order_propagates_errors_and_stops():
     assert [next(p) for _ in range(5)] == [0, 1, 2, 3, 4]
     p.close()
     assert not p._thread.is_alive()
+
+
+def test_prefetcher_end_and_error_puts_cannot_block_forever():
+    """ADVICE r2 (input_pipeline.py:168): the END marker and a producer exception are queued with the same stop-aware put as
+    ordinary items, so a producer that finishes (or fails) while the queue is full and the consumer has stopped reading
+    exits as soon as close() is called; StopIteration / the error repeat on later next() calls without re-queuing."""
+    import time
+    from building_detection_amd.input_pipeline import Prefetcher
+
+    def short(n, fail):
+        for i in range(n):
+            yield i
+        if fail:
+            raise RuntimeError("late failure")
+
+    for fail in (False, True):
+        p = Prefetcher(short(2, fail), depth=2)   # two items fill the queue: the END / error put has to wait
+        time.sleep(0.3)
+        assert p._thread.is_alive()               # parked in its put, not gone with the marker lost
+        p.close()
+        assert not p._thread.is_alive()
+    p = Prefetcher(short(3, False), depth=1)
+    assert list(p) == [0, 1, 2]
+    for _ in range(3):
+        with pytest.raises(StopIteration):
+            next(p)
+    p = Prefetcher(short(1, True), depth=1)
+    assert next(p) == 0
+    for _ in range(2):
+        with pytest.raises(RuntimeError, match="late failure"):
+            next(p)
+    p.close()

@@ -602,3 +602,33 @@ def test_batchnorm_applied_in_the_depthwise_gather(engine, policy, monkeypatch):
         for wa, wb in zip(ma.get_weights(), mb.get_weights()):
             assert np.array_equal(wa, wb)
     assert np.array_equal(ma.predict(x), mb.predict(x)) or not exact   # inference never defers: same graph, same weights
+
+
+def test_jit_capture_after_a_validation_batch_of_another_size(engine):
+    """ADVICE r2 (runtime.py:494): fit_generator with steps_per_epoch=2 and a validation batch of another size under
+    compile(jit_compile=True).  The two eager warm-up steps are epoch 1; its validation pass re-keys the runtime's weight
+    planes to batch 3, so the capture (first step of epoch 2) starts with a stale job table: the rebuild - an allocation and
+    a pageable host-to-device copy - must happen BEFORE the capture begins, not inside it.  Logs of every epoch and the
+    final weights equal the eager model's to the bit."""
+    from building_detection_amd import zoo
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss, PA, IoU
+    from building_detection_amd.runtime import GraphedTrainStep
+    ma = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+    mb = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+    mb.set_weights(ma.get_weights())
+    ma.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU])
+    mb.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU], jit_compile=True)
+
+    def gen(bs, seed):
+        i = 0
+        while True:
+            yield synthetic_batch(bs, 64, 64, seed=seed + i)
+            i += 1
+
+    ha = ma.fit_generator(gen(2, 300), steps_per_epoch=2, epochs=3, verbose=0, validation_data=gen(3, 900), validation_steps=1)
+    hb = mb.fit_generator(gen(2, 300), steps_per_epoch=2, epochs=3, verbose=0, validation_data=gen(3, 900), validation_steps=1)
+    assert ha.history == hb.history, (ha.history, hb.history)
+    assert len(mb._train_graphs) == 1 and isinstance(next(iter(mb._train_graphs.values())), GraphedTrainStep)
+    for wa, wb in zip(ma.get_weights(), mb.get_weights()):
+        assert np.array_equal(wa, wb)

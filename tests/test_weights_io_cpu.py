@@ -263,3 +263,67 @@ def test_long_name_lists_are_split_like_keras(tmp_path):
     assert "layer_names" not in f.attrs and "layer_names0" in f.attrs and "layer_names1" in f.attrs
     WIO.load_weights(b, p)
     assert all(np.array_equal(x, y) for x, y in zip(a.get_weights(), b.get_weights()))
+
+
+def _write_keras_file(path, model, order, rename=None):
+    """A Keras-layout weight file of `model` with its layers listed in `order` (and optionally renamed)."""
+    rename = rename or {}
+    ws = {p.name: w for p, w in zip(model.params, model.get_weights())}
+    w = H.Writer()
+    w.attr("", "layer_names", np.array([rename.get(n, n).encode() for n in order]))
+    for n in order:
+        node = next(x for x in model.nodes if x.name == n)
+        fn = rename.get(n, n)
+        w.group(fn)
+        names = [f"{fn}/{p.name.split('/')[1]}:0" for p in node.params]
+        w.attr(fn, "weight_names", np.array([s.encode() for s in names]))
+        for p, s in zip(node.params, names):
+            w.dataset(f"{fn}/{s}", ws[p.name])
+    w.save(path)
+
+
+# three equal-shaped parallel convolutions (the ASPP branches at rates 6 / 12 / 18 look like this) between two others
+PARALLEL = [("conv2d", [("kernel", (1, 1, 4, 8)), ("bias", (8,))]),
+            ("conv2d_1", [("kernel", (3, 3, 8, 8)), ("bias", (8,))]),
+            ("conv2d_2", [("kernel", (3, 3, 8, 8)), ("bias", (8,))]),
+            ("conv2d_3", [("kernel", (3, 3, 8, 8)), ("bias", (8,))]),
+            ("conv2d_4", [("kernel", (1, 1, 24, 2)), ("bias", (2,))])]
+
+
+def test_equal_shaped_parallel_layers_are_matched_by_name_not_by_a_positional_coincidence(tmp_path):
+    """ADVICE r2 (weights_io.py:137): Keras writes layer_names in depth-sorted order.  With equal-shaped parallel layers a
+    permuted file still FITS position by position - the old loader accepted that and put the branch weights on the wrong
+    layers.  Names (and, with another uid offset, class ordinals) decide now."""
+    a = _FakeModel(PARALLEL, 11)
+    order = ["conv2d", "conv2d_3", "conv2d_1", "conv2d_2", "conv2d_4"]  # every position fits every shape
+    p = str(tmp_path / "perm.h5")
+    _write_keras_file(p, a, order)
+    b = _FakeModel(PARALLEL, 12)
+    WIO.load_weights(b, p)
+    for x, y in zip(a.get_weights(), b.get_weights()):
+        assert np.array_equal(x, y)
+    # the same file written by a session whose Conv2D counter stood at 50: class ordinals pair the layers
+    p2 = str(tmp_path / "perm50.h5")
+    _write_keras_file(p2, a, order, rename={n: f"conv2d_{50 + i}" for i, (n, _) in enumerate(PARALLEL)})
+    c = _FakeModel(PARALLEL, 13)
+    WIO.load_weights(c, p2)
+    for x, y in zip(a.get_weights(), c.get_weights()):
+        assert np.array_equal(x, y)
+
+
+def test_positional_matching_is_a_last_resort_and_warns(tmp_path):
+    a = _FakeModel(PARALLEL, 21)
+    p = str(tmp_path / "custom.h5")
+    _write_keras_file(p, a, [n for n, _ in PARALLEL], rename={"conv2d": "stem", "conv2d_1": "aspp_r6", "conv2d_2": "aspp_r12",
+                                                            "conv2d_3": "aspp_r18", "conv2d_4": "head"})
+    b = _FakeModel(PARALLEL, 22)
+    with pytest.warns(RuntimeWarning, match="BY POSITION"):
+        WIO.load_weights(b, p)
+    for x, y in zip(a.get_weights(), b.get_weights()):
+        assert np.array_equal(x, y)
+    # same names, another architecture: an error, not a positional retry
+    other = _FakeModel(PARALLEL[:-1] + [("conv2d_4", [("kernel", (1, 1, 24, 3)), ("bias", (3,))])], 23)
+    p3 = str(tmp_path / "named.h5")
+    _write_keras_file(p3, a, [n for n, _ in PARALLEL])
+    with pytest.raises(ValueError, match="conv2d_4"):
+        WIO.load_weights(other, p3)
