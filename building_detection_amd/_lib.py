@@ -113,6 +113,7 @@ _SIGNATURES = {
     "sg_adam_step": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _f, _f, _f, _f, _f]),
     "sg_adam_step_lr": (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _vp, _f, _f, _f, _f]),
     "sg_edge_labels": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "sg_resize_linear_u8": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _i, _vp]),
     "sg_argmax_accumulate_i8": (_i, [_vp, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i]),
     "sg_vote_ge": (_i, [_vp, _vp, _i, _pp, _i64, _i, _vp]),
     "sg_mask_objects_ws_bytes": (_sz, [_i, _i]),

@@ -10,6 +10,7 @@
 #include "sg_common.h"
 #include <dlfcn.h>
 #include <string.h>
+#include <mutex>
 
 namespace {
 
@@ -30,15 +31,12 @@ struct Rccl {
   fn_all_reduce all_reduce = nullptr;
   fn_comm_destroy comm_destroy = nullptr;
   fn_get_error_string get_error_string = nullptr;
-  bool tried = false;
 };
 
 Rccl g_rccl;
+std::once_flag g_rccl_once;
 
-const Rccl* rccl() {
-  // not thread-safe by itself; the first call comes from sg_comm_unique_id / sg_comm_init, which a rank makes once
-  if (g_rccl.tried) return g_rccl.handle ? &g_rccl : nullptr;
-  g_rccl.tried = true;
+void rccl_load() {
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
   for (const char* n : names) {  // a copy the process already holds wins
@@ -46,15 +44,21 @@ const Rccl* rccl() {
     if (h) break;
   }
   for (int i = 0; !h && i < 3; ++i) h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
-  if (!h) return nullptr;
+  if (!h) return;
   g_rccl.get_unique_id = (fn_get_unique_id)dlsym(h, "ncclGetUniqueId");
   g_rccl.comm_init_rank = (fn_comm_init_rank)dlsym(h, "ncclCommInitRank");
   g_rccl.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
   g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
   g_rccl.get_error_string = (fn_get_error_string)dlsym(h, "ncclGetErrorString");
-  if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.comm_destroy) return nullptr;
-  g_rccl.handle = h;
-  return &g_rccl;
+  if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.comm_destroy) return;
+  g_rccl.handle = h;  // published last: a non-null handle means every entry point above is resolved
+}
+
+// Resolved exactly once per process, whichever thread asks first (std::call_once: concurrent callers wait for the one
+// that loads); nullptr when no usable RCCL was found - every caller checks.
+const Rccl* rccl() {
+  std::call_once(g_rccl_once, rccl_load);
+  return g_rccl.handle ? &g_rccl : nullptr;
 }
 
 int rccl_fail(const Rccl* r, const char* what, int code) {
@@ -125,6 +129,10 @@ int sg_comm_allreduce_sum(sg_comm* comm, void* stream, int dtype, void* buf, int
     default: sg_set_error("sg_comm_allreduce_sum: dtype %d", dtype); return SG_EINVAL;
   }
   const Rccl* r = rccl();
+  if (!r) {  // cannot happen for a communicator sg_comm_init returned, but a null here must not be a crash
+    sg_set_error("sg_comm_allreduce_sum: RCCL is not loaded");
+    return SG_EUNSUPPORTED;
+  }
   const int rc = r->all_reduce(buf, buf, (size_t)count, nccl_type, /*ncclSum*/ 0, comm->comm, (hipStream_t)stream);
   if (rc != 0) return rccl_fail(r, "ncclAllReduce", rc);
   return 0;

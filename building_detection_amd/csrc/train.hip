@@ -170,10 +170,71 @@ __global__ void vote_kernel(const VoteArgs a, int64_t n, int k, unsigned char* _
 }
 
 // train_data_gen label channels (train_model/DeepLabv3plus.py:70-100): one-hot by integer truncation (only
-// label == 1.0 is class 1), 5 x erode / dilate with a 3x3 kernel == 11x11 min / max box (out-of-image cells are
-// ignored, as cv.erode / cv.dilate's default border does), p_edge = 2 where label - erode == 1, f_edge = 2
+// label == 1.0 is class 1), 5 x erode / dilate with a 3x3 kernel == (2R+1)x(2R+1) min / max box with R = 5 (out-of-image
+// cells are ignored, as cv.erode / cv.dilate's default border does), p_edge = 2 where label - erode == 1, f_edge = 2
 // where dilate - label == 1; channel order (bg, fg, f_edge, p_edge).
-__global__ void edge_labels_kernel(const float* __restrict__ lab, float* __restrict__ y, int N, int H, int W, int radius) {
+//
+// Separable form: a workgroup owns an EL_TH x EL_TW output tile of one image.  (1) the (EL_TH+2R) x (EL_TW+2R) label
+// window goes to LDS once; (2) row pass: per window row and output column the min / max over the 2R+1 columns that lie
+// inside the image (rows outside the image become +inf / -inf, the identities); (3) column pass over 2R+1 window rows.
+// 2 (2R+1) = 22 LDS reads for the two passes and ~1.6 global loads per pixel, where the plain window walk
+// (edge_labels_window_kernel below, kept for R > EL_RMAX) issues (2R+1)^2 = 121 global loads.
+constexpr int EL_TH = 16, EL_TW = 64, EL_RMAX = 8;
+
+__global__ __launch_bounds__(256) void edge_labels_sep_kernel(const float* __restrict__ lab, float* __restrict__ y, int H, int W,
+                                                             int R, int tiles_x, int tiles_y) {
+  __shared__ float win[(EL_TH + 2 * EL_RMAX) * (EL_TW + 2 * EL_RMAX)];
+  __shared__ float rmin[(EL_TH + 2 * EL_RMAX) * EL_TW];
+  __shared__ float rmax[(EL_TH + 2 * EL_RMAX) * EL_TW];
+  const int t = threadIdx.x;
+  const int tx = blockIdx.x % tiles_x, ty = (blockIdx.x / tiles_x) % tiles_y, n = blockIdx.x / (tiles_x * tiles_y);
+  const int x0 = tx * EL_TW, y0 = ty * EL_TH;
+  const int WW = EL_TW + 2 * R, WH = EL_TH + 2 * R;
+  const float* img = lab + (int64_t)n * H * W;
+  for (int i = t; i < WH * WW; i += 256) {
+    const int r = i / WW, c = i - r * WW;
+    const int gy = y0 - R + r, gx = x0 - R + c;
+    win[i] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? img[(int64_t)gy * W + gx] : 0.f;
+  }
+  __syncthreads();
+  for (int i = t; i < WH * EL_TW; i += 256) {
+    const int r = i / EL_TW, c = i - r * EL_TW;
+    const int gy = y0 - R + r;
+    float mn = INFINITY, mx = -INFINITY;
+    if ((unsigned)gy < (unsigned)H) {
+      for (int b = 0; b <= 2 * R; ++b) {
+        const int gx = x0 + c - R + b;
+        const float v = win[r * WW + c + b];
+        const bool in = (unsigned)gx < (unsigned)W;
+        mn = in ? fminf(mn, v) : mn;
+        mx = in ? fmaxf(mx, v) : mx;
+      }
+    }
+    rmin[i] = mn;
+    rmax[i] = mx;
+  }
+  __syncthreads();
+  for (int i = t; i < EL_TH * EL_TW; i += 256) {
+    const int r = i / EL_TW, c = i - r * EL_TW;
+    const int gy = y0 + r, gx = x0 + c;
+    if (gy >= H || gx >= W) continue;
+    float er = INFINITY, di = -INFINITY;
+    for (int a = 0; a <= 2 * R; ++a) {
+      er = fminf(er, rmin[(r + a) * EL_TW + c]);
+      di = fmaxf(di, rmax[(r + a) * EL_TW + c]);
+    }
+    const float m = win[(r + R) * WW + c + R];
+    const float fg = ((int)m == 1) ? 1.f : 0.f;
+    float4 o;
+    o.x = 1.f - fg;
+    o.y = fg;
+    o.z = (di - m == 1.f) ? 2.f : 1.f;
+    o.w = (m - er == 1.f) ? 2.f : 1.f;
+    *reinterpret_cast<float4*>(y + 4 * ((int64_t)n * H * W + (int64_t)gy * W + gx)) = o;
+  }
+}
+
+__global__ void edge_labels_window_kernel(const float* __restrict__ lab, float* __restrict__ y, int N, int H, int W, int radius) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)N * H * W) return;
   const int w = (int)(i % W), h = (int)((i / W) % H);
@@ -198,6 +259,52 @@ __global__ void edge_labels_kernel(const float* __restrict__ lab, float* __restr
   o.z = (di - m == 1.f) ? 2.f : 1.f;
   o.w = (m - er == 1.f) ? 2.f : 1.f;
   *reinterpret_cast<float4*>(y + 4 * i) = o;
+}
+
+// cv.resize(img, (OW, OH)) of 8-bit pixels, default INTER_LINEAR (decode_img / decode_lbel, DeepLabv3plus.py:35,45), in
+// OpenCV's own fixed-point arithmetic (resize.cpp; restated independently in oracle/input_pipeline.py, bit-exact):
+// 11-bit coefficients from fx = float((d + 0.5) * scale - 0.5), horizontal pass in int32, vertical pass
+// ((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2.  The double-precision products are taken with explicit
+// round-to-nearest intrinsics so that no fused multiply-add changes the last bit of fx.  area2 = 1: exact 2x downscale,
+// which resize() routes to the fast INTER_AREA ((a + b + c + d + 2) >> 2).
+__device__ __forceinline__ void cv_linear_coeff(int d, double scale, int n_in, int& s, int& c0, int& c1, bool clamp_index) {
+  float f = __double2float_rn(__dadd_rn(__dmul_rn((double)d + 0.5, scale), -0.5));
+  s = (int)floorf(f);
+  f = f - (float)s;
+  if (clamp_index) {  // columns: the index is clamped AND the weight reset; rows keep their weights (clamped at the read)
+    if (s < 0) { s = 0; f = 0.f; }
+    if (s >= n_in - 1) { s = n_in - 1; f = 0.f; }
+  }
+  c0 = __float2int_rn((1.f - f) * 2048.f);
+  c1 = __float2int_rn(f * 2048.f);
+}
+
+__global__ void resize_linear_u8_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int N, int H, int W,
+                                        int C, int OH, int OW, double sx_scale, double sy_scale, int area2) {
+  const int64_t total = (int64_t)N * OH * OW * C;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    const int c = (int)(i % C);
+    const int dx = (int)((i / C) % OW);
+    const int dy = (int)((i / ((int64_t)C * OW)) % OH);
+    const int n = (int)(i / ((int64_t)C * OW * OH));
+    const unsigned char* img = src + (int64_t)n * H * W * C;
+    if (area2) {
+      const unsigned char* q = img + ((int64_t)(2 * dy) * W + 2 * dx) * C + c;
+      dst[i] = (unsigned char)((q[0] + q[C] + q[(int64_t)W * C] + q[(int64_t)W * C + C] + 2) >> 2);
+      continue;
+    }
+    int sx, a0, a1, sy, b0, b1;
+    cv_linear_coeff(dx, sx_scale, W, sx, a0, a1, true);
+    cv_linear_coeff(dy, sy_scale, H, sy, b0, b1, false);
+    const int sx1 = min(sx + 1, W - 1);
+    const int y0 = min(max(sy, 0), H - 1), y1 = min(max(sy + 1, 0), H - 1);
+    const int d0 = img[((int64_t)y0 * W + sx) * C + c] * a0 + img[((int64_t)y0 * W + sx1) * C + c] * a1;
+    const int d1 = img[((int64_t)y1 * W + sx) * C + c] * a0 + img[((int64_t)y1 * W + sx1) * C + c] * a1;
+    int v = (((b0 * (d0 >> 4)) >> 16) + ((b1 * (d1 >> 4)) >> 16) + 2) >> 2;
+    v = min(max(v, 0), 255);
+    dst[i] = (unsigned char)v;
+  }
 }
 
 inline int loss_parts(int64_t rows) {
@@ -290,9 +397,31 @@ int sg_adam_step_lr(sg_ctx* ctx, void* stream, int64_t n, void* w, void* m, void
 int sg_edge_labels(sg_ctx* ctx, void* stream, int N, int H, int W, int iterations, const void* label, void* y_true4) {
   SG_CHECK_ARG(ctx && label && y_true4 && N > 0 && H > 0 && W > 0 && iterations >= 0, "sg_edge_labels: bad argument");
   const int64_t n = (int64_t)N * H * W;
-  hipLaunchKernelGGL(edge_labels_kernel, dim3((unsigned)sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
+  if (iterations <= EL_RMAX) {  // separable row / column min-max through LDS
+    const int tiles_x = (int)sg_cdiv(W, EL_TW), tiles_y = (int)sg_cdiv(H, EL_TH);
+    const int64_t blocks = (int64_t)N * tiles_x * tiles_y;
+    SG_CHECK_ARG(blocks < (1ll << 31), "sg_edge_labels: %lld tiles", (long long)blocks);
+    hipLaunchKernelGGL(edge_labels_sep_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)label,
+                       (float*)y_true4, H, W, iterations, tiles_x, tiles_y);
+    SG_LAUNCH_CHECK("edge_labels_sep_kernel");
+    return 0;
+  }
+  hipLaunchKernelGGL(edge_labels_window_kernel, dim3((unsigned)sg_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const float*)label, (float*)y_true4, N, H, W, iterations);
-  SG_LAUNCH_CHECK("edge_labels_kernel");
+  SG_LAUNCH_CHECK("edge_labels_window_kernel");
+  return 0;
+}
+
+int sg_resize_linear_u8(sg_ctx* ctx, void* stream, int N, int H, int W, int C, const void* src_u8, int OH, int OW, void* dst_u8) {
+  SG_CHECK_ARG(ctx && src_u8 && dst_u8 && N > 0 && H > 0 && W > 0 && C > 0 && OH > 0 && OW > 0, "sg_resize_linear_u8: bad argument");
+  SG_CHECK_ARG((int64_t)H * W * C < (1ll << 31), "sg_resize_linear_u8: one image of %d x %d x %d exceeds 2 GiB", H, W, C);
+  const int64_t total = (int64_t)N * OH * OW * C;
+  int64_t blocks = sg_cdiv(total, 256);
+  if (blocks > 65536) blocks = 65536;
+  const int area2 = (H == 2 * OH && W == 2 * OW) ? 1 : 0;
+  hipLaunchKernelGGL(resize_linear_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src_u8,
+                     (unsigned char*)dst_u8, N, H, W, C, OH, OW, (double)W / (double)OW, (double)H / (double)OH, area2);
+  SG_LAUNCH_CHECK("resize_linear_u8_kernel");
   return 0;
 }
 

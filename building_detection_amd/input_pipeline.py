@@ -5,9 +5,9 @@ the same text), restated without OpenCV / TensorFlow - names, arguments, yield s
 What is exact and what is not (OpenCV is absent here, so nothing below could be checked against cv2 itself):
   * file decoding goes through Pillow (`cv.imread` = 8-bit, 3 channels, BGR; then BGR2RGB): identical for the 8-bit
     RGB / gray PNG / TIFF tiles of the WHU set;
-  * `cv.resize(img, (512, 512))` is the identity for 512x512 tiles - the case of the data set - and that case is
-    exact; other sizes go through a half-pixel-centre bilinear resize in float with round-half-up, which can differ
-    from cv2's 11-bit fixed-point kernel by one grey level (flagged in the docstring of `_resize_bilinear_u8`);
+  * `cv.resize(img, (512, 512))` is the identity for 512x512 tiles - the case of the data set; other sizes go through
+    OpenCV's own 11-bit fixed-point INTER_LINEAR arithmetic (`_resize_bilinear_u8`; on the GPU `sg_resize_linear_u8`),
+    restated from the published algorithm and held bit-exact to oracle/input_pipeline.py;
   * `cv.cvtColor(BGR2GRAY)` uses cv2's published 14-bit integer weights (4899 R + 9617 G + 1868 B + 8192) >> 14,
     which is the identity on grey label images;
   * `tf.keras.utils.to_categorical(label, 2)` truncates label / 255 to int, so only pixels equal to 255 are class 1;
@@ -40,31 +40,41 @@ def _imread_bgr_order_free(path) -> np.ndarray:
         return np.asarray(im.convert("RGB"), np.uint8)
 
 
+def _cv_coeffs(n_in: int, n_out: int, clamp: bool):
+    """OpenCV's INTER_LINEAR taps for 8-bit images (resize.cpp): first source index and the two 11-bit weights."""
+    f = ((np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5).astype(np.float32)
+    s = np.floor(f).astype(np.int64)
+    f = f - s.astype(np.float32)
+    if clamp:  # columns: index clamped and weight reset; rows keep their weights and clamp at the read
+        edge = (s < 0) | (s >= n_in - 1)
+        f = np.where(edge, np.float32(0), f)
+        s = np.clip(s, 0, n_in - 1)
+    c0 = np.rint((np.float32(1) - f) * np.float32(2048)).astype(np.int64)
+    c1 = np.rint(f * np.float32(2048)).astype(np.int64)
+    return s, c0, c1
+
+
 def _resize_bilinear_u8(img: np.ndarray, size=(SIZE, SIZE)) -> np.ndarray:
-    """cv.resize(img, size) with the default INTER_LINEAR.  Identity (a copy) when the size already matches - exact.
-    Otherwise: half-pixel centres, edge clamp, float arithmetic, round half up.  cv2 computes the same kernel in
-    11-bit fixed point; the two can differ by one grey level (unverified here: no cv2)."""
+    """cv.resize(img, size) with the default INTER_LINEAR, in OpenCV's fixed-point arithmetic for 8-bit pixels: 11-bit
+    coefficients, int32 horizontal pass, vertical pass (((b0 * (D0 >> 4)) >> 16) + ((b1 * (D1 >> 4)) >> 16) + 2) >> 2 (the
+    vectorised row kernel every SIMD build of OpenCV runs on whole vectors; 512 * channels is a multiple of any vector
+    length).  Same size = a copy (coefficients 2048 / 0); an exact 2x downscale is the fast INTER_AREA that resize()
+    substitutes.  The GPU twin is sg_resize_linear_u8; both are held bit-exact to oracle/input_pipeline.py (cv2 itself is
+    absent from this image: the restatement follows the published algorithm, unpinned against a cv2 build)."""
     h, w = img.shape[:2]
     ow, oh = size
     if (h, w) == (oh, ow):
         return img.copy()
-
-    def taps(n_in, n_out):
-        src = (np.arange(n_out, dtype=np.float64) + 0.5) * (n_in / n_out) - 0.5
-        i0 = np.floor(src).astype(np.int64)
-        f = src - i0
-        return np.clip(i0, 0, n_in - 1), np.clip(i0 + 1, 0, n_in - 1), f
-
-    y0, y1, fy = taps(h, oh)
-    x0, x1, fx = taps(w, ow)
-    a = img.astype(np.float64)
-    if a.ndim == 2:
-        a = a[..., None]
-    top = a[y0][:, x0] * (1 - fx)[None, :, None] + a[y0][:, x1] * fx[None, :, None]
-    bot = a[y1][:, x0] * (1 - fx)[None, :, None] + a[y1][:, x1] * fx[None, :, None]
-    out = top * (1 - fy)[:, None, None] + bot * fy[:, None, None]
-    out = np.clip(np.floor(out + 0.5), 0, 255).astype(np.uint8)
-    return out[..., 0] if img.ndim == 2 else out
+    a = img.reshape(h, w, -1).astype(np.int64)
+    if h == 2 * oh and w == 2 * ow:
+        out = (a[0::2, 0::2] + a[0::2, 1::2] + a[1::2, 0::2] + a[1::2, 1::2] + 2) >> 2
+        return out.astype(np.uint8).reshape((oh, ow) + img.shape[2:])
+    sx, a0, a1 = _cv_coeffs(w, ow, True)
+    sy, b0, b1 = _cv_coeffs(h, oh, False)
+    hor = a[:, sx] * a0[None, :, None] + a[:, np.minimum(sx + 1, w - 1)] * a1[None, :, None]   # [h, ow, c], scale 2^11
+    d0, d1 = hor[np.clip(sy, 0, h - 1)], hor[np.clip(sy + 1, 0, h - 1)]
+    out = (((b0[:, None, None] * (d0 >> 4)) >> 16) + ((b1[:, None, None] * (d1 >> 4)) >> 16) + 2) >> 2
+    return np.clip(out, 0, 255).astype(np.uint8).reshape((oh, ow) + img.shape[2:])
 
 
 def decode_img(img_path) -> np.ndarray:
@@ -209,18 +219,23 @@ class Prefetcher:
             pass
 
 
-def _decode_u8(img, seg):
-    """The file-side half of decode_img / decode_lbel: uint8 RGB [512,512,3] and uint8 grey [512,512] (resize included)."""
-    rgb = _resize_bilinear_u8(_imread_bgr_order_free(img))
+def _decode_u8(img, seg, resize=True):
+    """The file-side half of decode_img / decode_lbel: uint8 RGB [h,w,3] and uint8 grey [h,w]; resized to 512 x 512 on the
+    host unless `resize` is False (then the caller resizes on the device)."""
+    rgb = _imread_bgr_order_free(img)
     lab = _imread_bgr_order_free(seg).astype(np.int32)
     gray = ((lab[..., 0] * 4899 + lab[..., 1] * 9617 + lab[..., 2] * 1868 + 8192) >> 14).astype(np.uint8)
-    return rgb, _resize_bilinear_u8(gray)
+    if resize:
+        return _resize_bilinear_u8(rgb), _resize_bilinear_u8(gray)
+    return rgb, gray
 
 
 def device_data_gen(img_path, lab_path, BATCH_SIZE, engine, depth: int = 2, workers: int = 4):
     """train_data_gen for the GPU (loss="edge_focal_loss"): the same sorted, cycled (image, label) pairs, but
       * files are decoded by `workers` threads, `depth` batches ahead of the consumer (Prefetcher),
       * the batch crosses PCIe as uint8 pixels (a quarter of the fp32 bytes), from pinned memory,
+      * tiles that are not 512 x 512 are resized on the device (sg_resize_linear_u8: cv.resize's fixed-point arithmetic)
+        when a batch's files share one size, else on the host by the same arithmetic,
       * normalisation (`/ 127.5 - 1`, `/ 255`: sg_u8_to_f32) and the four label channels (sg_edge_labels) run on the device.
     Yields DEVICE tensors (x float32 [N,512,512,3], y float32 [N,512,512,4]) that `fit_generator` / `train_on_batch` take as
     they are; values are bit-identical to train_data_gen's (tests/test_pipeline_gpu.py).  y is float32 where the reference
@@ -236,7 +251,9 @@ def device_data_gen(img_path, lab_path, BATCH_SIZE, engine, depth: int = 2, work
         with ThreadPoolExecutor(max_workers=max(1, int(workers))) as pool:
             while True:
                 pairs = [next(zipped) for _ in range(BATCH_SIZE)]
-                dec = list(pool.map(lambda p: _decode_u8(*p), pairs))
+                dec = list(pool.map(lambda p: _decode_u8(*p, resize=False), pairs))
+                if len({d[0].shape for d in dec} | {d[1].shape + (3,) for d in dec}) != 1:  # mixed sizes: host resize
+                    dec = [(_resize_bilinear_u8(r), _resize_bilinear_u8(g)) for r, g in dec]
                 xb = torch.from_numpy(np.stack([d[0] for d in dec]))
                 lb = torch.from_numpy(np.stack([d[1] for d in dec]))
                 if torch.cuda.is_available():
@@ -248,6 +265,9 @@ def device_data_gen(img_path, lab_path, BATCH_SIZE, engine, depth: int = 2, work
         for xb, lb in feed:
             xd = xb.to(engine.device, non_blocking=True)
             ld = lb.to(engine.device, non_blocking=True)
+            if tuple(xd.shape[1:3]) != (SIZE, SIZE):
+                xd = engine.resize_linear_u8(xd, SIZE, SIZE)
+                ld = engine.resize_linear_u8(ld, SIZE, SIZE)
             x = engine.u8_to_f32(xd, 127.5, 1.0)
             y = engine.edge_labels(engine.u8_to_f32(ld, 255.0, 0.0))
             yield x, y

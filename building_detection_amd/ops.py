@@ -576,7 +576,7 @@ class Engine:
         _chk(label, "label")
         n, h, w = label.shape
         y = self.empty(n, h, w, 4)
-        check(self.lib.sg_edge_labels(self.h, self.stream, n, h, w, iterations, _ptr(label), _ptr(y)), "sg_edge_labels")
+        check(self.lib.sg_edge_labels(self.h, self.stream, n, h, w, int(iterations), _ptr(label), _ptr(y)), "sg_edge_labels")
         return y
 
     # -------------------------------------------------------------------------------------- inference tail
@@ -604,6 +604,16 @@ class Engine:
         assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous()
         dst = torch.empty(src.shape, dtype=torch.float32, device=self.device)
         check(self.lib.sg_u8_to_f32(self.h, self.stream, src.numel(), _ptr(src), _ptr(dst), float(div), float(sub)), "sg_u8_to_f32")
+        return dst
+
+    def resize_linear_u8(self, src, oh, ow):
+        """cv.resize(img, (ow, oh)) (default INTER_LINEAR, OpenCV's fixed-point arithmetic) of uint8 [N,H,W,C] or [N,H,W]."""
+        assert src.is_cuda and src.dtype == torch.uint8 and src.is_contiguous() and src.dim() in (3, 4)
+        n, h, w = src.shape[:3]
+        c = src.shape[3] if src.dim() == 4 else 1
+        dst = torch.empty((n, oh, ow) + tuple(src.shape[3:]), dtype=torch.uint8, device=self.device)
+        check(self.lib.sg_resize_linear_u8(self.h, self.stream, n, h, w, c, _ptr(src), int(oh), int(ow), _ptr(dst)),
+              "sg_resize_linear_u8")
         return dst
 
     def scale(self, t, a):

@@ -342,6 +342,12 @@ int sg_adam_step_lr(sg_ctx* ctx, void* stream, int64_t n, void* w, void* m, void
  * cells; p_edge = 2 where label - erode == 1 else 1; f_edge = 2 where dilate - label == 1 else 1. */
 int sg_edge_labels(sg_ctx* ctx, void* stream, int N, int H, int W, int iterations, const void* label,
                    void* y_true4);
+/* cv.resize(img, (OW, OH)) with the default INTER_LINEAR on 8-bit pixels - decode_img / decode_lbel of
+ * train_model/DeepLabv3plus.py:35,45 for tiles that are not already 512 x 512: src_u8[N,H,W,C] -> dst_u8[N,OH,OW,C] in
+ * OpenCV's fixed-point arithmetic (11-bit coefficients, the vectorised vertical pass; an exact 2x downscale is the fast
+ * INTER_AREA, as resize() substitutes it).  Bit-exact against oracle/input_pipeline.py:resize_linear_u8. */
+int sg_resize_linear_u8(sg_ctx* ctx, void* stream, int N, int H, int W, int C, const void* src_u8, int OH, int OW,
+                        void* dst_u8);
 
 /* ------------------------------------------------------------------------------------ inference tail
  * predict.py:110-114: mask = argmax(p) (ties -> 0) added as int8 into the canvas window at (y0,x0) of a

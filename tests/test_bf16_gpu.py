@@ -55,7 +55,8 @@ CONV_CASES = [
     ("s2_entry", 2, 64, 64, 32, 64, 3, 2, 1),        # stride 2: bf16-pipe forward / dgrad / wgrad (OW % 32 == 0)
     ("s2_ragged", 2, 48, 48, 32, 64, 3, 2, 1),       # stride 2, OW = 24: the wgrad falls back to the fp32-MFMA kernel
     ("first_conv", 2, 64, 64, 3, 32, 3, 2, 1),       # Cin = 3: the any-shape fallback (widening loads)
-    ("first_conv7", 1, 64, 64, 3, 64, 7, 2, 1),      # Res34-UNet's 7x7 stem, same kernel
+    ("first_conv7", 1, 64, 64, 3, 64, 7, 2, 1),      # a 7x7 s2 kernel on Cin = 3 (no model of the path has one: K = 147 on the any-shape kernel)
+    ("res34_stem", 1, 64, 64, 3, 64, 3, 1, 1),       # Res34-UNet's real first conv: 3 -> 64, 3x3 s1 (predict_model/res34.py:50)
     ("odd_45", 2, 32, 32, 45, 45, 3, 1, 4),          # BAM reduce dim 45
     ("dense_like", 16, 1, 1, 256, 64, 1, 1, 1),
 ]

@@ -152,3 +152,66 @@ def test_prefetcher_end_and_error_puts_cannot_block_forever():
         with pytest.raises(RuntimeError, match="late failure"):
             next(p)
     p.close()
+
+
+# ---- against the oracle's restatement of the reference text (oracle/input_pipeline.py) -------------------
+from oracle import input_pipeline as OIP  # noqa: E402
+
+
+@pytest.mark.parametrize("shape", [(300, 400, 3), (1024, 1024, 3), (700, 333), (512, 512, 3), (64, 48, 3), (513, 511)])
+def test_host_resize_is_the_oracles_cv_resize_bit_for_bit(shape):
+    rng = np.random.default_rng(sum(shape))
+    a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    got, ref = IP._resize_bilinear_u8(a), OIP.resize_linear_u8(a)
+    assert got.shape == ref.shape == (512, 512) + shape[2:] and got.dtype == np.uint8
+    assert np.array_equal(got, ref)
+    if shape[:2] == (1024, 1024):   # exact 2x downscale: resize() runs the fast INTER_AREA
+        q = a.astype(np.int64)
+        assert np.array_equal(ref, ((q[0::2, 0::2] + q[0::2, 1::2] + q[1::2, 0::2] + q[1::2, 1::2] + 2) >> 2).astype(np.uint8))
+
+
+def test_resize_known_answers_of_the_fixed_point_kernel():
+    """Hand-computed values of OpenCV's arithmetic (oracle header): 2x up-sampling of [0, 255] columns.  Output x = 1 maps to
+    fx = 0.25 (weights 1536 / 512): D = 255 * 512 = 130560; both rows equal, b0 + b1 = 2048:
+    ((b0 * (D >> 4)) >> 16) + ((b1 * (D >> 4)) >> 16) with D >> 4 = 8160, b = (512, 1536) -> 63 + 191 = 254; (254 + 2) >> 2 = 64."""
+    a = np.tile(np.array([[0, 255]], np.uint8), (2, 1))
+    r = OIP.resize_linear_u8(a, (4, 4))
+    assert r[0].tolist() == [0, 64, 191, 255], r[0].tolist()
+    assert np.array_equal(IP._resize_bilinear_u8(a, (4, 4)), r)
+    # same size: a copy; constant image: constant
+    b = np.random.default_rng(0).integers(0, 256, (37, 41, 3), dtype=np.uint8)
+    assert np.array_equal(OIP.resize_linear_u8(b, (41, 37)), b)
+    assert np.all(OIP.resize_linear_u8(np.full((30, 50), 201, np.uint8), (77, 91)) == 201)
+
+
+def test_label_channels_match_the_oracle_on_soft_and_border_labels():
+    rng = np.random.default_rng(2)
+    for k in range(4):
+        lab = np.zeros((96, 130), np.float32)
+        for _ in range(6):
+            r0, c0 = int(rng.integers(0, 80)), int(rng.integers(0, 110))
+            lab[r0:r0 + int(rng.integers(3, 30)), c0:c0 + int(rng.integers(3, 30))] = 1.0
+        lab[:7, :9] = 1.0
+        lab[-3:, -20:] = 1.0
+        if k % 2:
+            lab[40:50, 40:60] = np.float32(128 / 255)     # grey: neither class 1 nor an edge source of weight 2
+            lab[10, 10] = np.float32(254 / 255)
+        ref = OIP.label_channels(lab)
+        f_edge, p_edge = edge_weight_channels(lab)
+        oh = IP.to_categorical(lab[..., None], 2)
+        assert np.array_equal(oh, ref[..., :2]) and np.array_equal(f_edge, ref[..., 2]) and np.array_equal(p_edge, ref[..., 3])
+
+
+@pytest.mark.parametrize("size", [512, 300])
+def test_generators_equal_the_oracle_generator(tmp_path, size):
+    rng = np.random.default_rng(size)
+    pairs = [_write_pair(tmp_path, i, rng, size=size, soft=(i == 1)) for i in range(3)]
+    imgs, labs = [p[0] for p in pairs], [p[1] for p in pairs]
+    g, o = IP.train_data_gen(list(imgs), list(labs), 2), OIP.data_gen(list(imgs), list(labs), 2)
+    for _ in range(2):
+        (x, y), (xr, yr) = next(g), next(o)
+        assert x.dtype == xr.dtype == np.float32 and y.dtype == yr.dtype == np.float64
+        assert np.array_equal(x, xr) and np.array_equal(y, yr)
+    _, y2 = next(IP.val_data_gen(list(imgs), list(labs), 1, loss="focal_loss"))
+    _, y2r = next(OIP.data_gen(list(imgs), list(labs), 1, loss="focal_loss"))
+    assert np.array_equal(y2, y2r) and y2.dtype == y2r.dtype

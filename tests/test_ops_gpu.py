@@ -78,7 +78,8 @@ CONV_CASES = [
     (2, 64, 64, 64, 128, 3, 2, 1, "x6_wgrad_s2_3x3"),
     (2, 64, 64, 128, 256, 1, 2, 1, "x6_wgrad_s2_1x1"),
     (1, 63, 64, 32, 48, 3, 2, 1, "x6_wgrad_s2_odd_h"),
-    # RGB stems (Cin = 3: the scalar any-shape kernels) at the sizes and kernel shapes of the five models
+    # RGB stems (Cin = 3: the scalar any-shape kernels): the models' own stems are 3x3 (stride 2: DeepLab / HRNet; stride 1:
+    # the U-Nets, predict_model/res34.py:50-52, scse.py); the 7x7 case is a shape no model has (K = 147, large-kernel path)
     (2, 64, 64, 3, 32, 3, 2, 1, "stem_s2_w32"),
     (1, 64, 64, 3, 64, 7, 2, 1, "stem7_s2_w32"),
     (2, 32, 32, 3, 64, 3, 1, 1, "stem_s1_w32"),
@@ -424,16 +425,51 @@ def test_adam(engine):
 
 
 def test_edge_labels_match_generator(engine):
-    """sg_edge_labels vs the host restatement of train_data_gen's label channels (building_detection_amd.data)."""
+    """sg_edge_labels (separable row / column min-max through LDS) vs the ORACLE's restatement of train_data_gen's label
+    channels (oracle/input_pipeline.py:label_channels, DeepLabv3plus.py:70-100): bit-exact, on rectangles touching every
+    border, on tiles that are not multiples of the kernel's 16 x 64 workgroup tile, on grey (non-binary) label values, for
+    the reference's 5 iterations and other radii (incl. the plain window-walk kernel behind radius > 8)."""
     from building_detection_amd.data import synthetic_batch
+    from oracle import input_pipeline as OIP
     _, y = synthetic_batch(3, 96, 80, seed=4)
-    lab = torch.from_numpy(np.ascontiguousarray(y[..., 1])).cuda()
-    got = engine.edge_labels(lab).cpu().numpy()
-    assert np.array_equal(got, y)
-    soft = lab.clone()
-    soft[0, 10:20, 10:20] = 0.5  # anti-aliased label values are background for to_categorical's truncation
-    g2 = engine.edge_labels(soft).cpu().numpy()
-    assert (g2[0, 10:20, 10:20, 1] == 0).all() and (g2[0, 10:20, 10:20, 0] == 1).all()
+    labs = np.ascontiguousarray(y[..., 1])
+    labs[0, :7, :9] = 1; labs[0, -4:, -11:] = 1; labs[1, 40:, :3] = 1          # all four borders
+    labs[2, 10:20, 10:20] = np.float32(128 / 255)   # anti-aliased values: background for to_categorical, no weight-2 band
+    labs[2, 50, 60] = np.float32(254 / 255)
+    got = engine.edge_labels(torch.from_numpy(labs).cuda()).cpu().numpy()
+    for k in range(3):
+        assert np.array_equal(got[k].astype(np.float64), OIP.label_channels(labs[k])), k
+    assert (got[2, 10:20, 10:20, 1] == 0).all() and (got[2, 10:20, 10:20, 0] == 1).all()
+    rng = np.random.default_rng(9)
+    for (h, w, it) in [(17, 65, 5), (1, 1, 5), (33, 130, 2), (16, 64, 8), (40, 70, 0), (45, 50, 11)]:
+        lab = (rng.random((2, h, w)) > 0.6).astype(np.float32)
+        lab[0, h // 2:, : w // 2] = 1.0
+        g = engine.edge_labels(torch.from_numpy(lab).cuda(), iterations=it).cpu().numpy()
+        for k in range(2):
+            assert np.array_equal(g[k].astype(np.float64), OIP.label_channels(lab[k], it)), (h, w, it, k)
+    # the full-size case of the generator: 512 x 512 (bs 16 in one launch), against the oracle on two of the images
+    _, yf = synthetic_batch(16, 512, 512, seed=12)
+    lf = np.ascontiguousarray(yf[..., 1])
+    gf = engine.edge_labels(torch.from_numpy(lf).cuda()).cpu().numpy()
+    for k in (0, 15):
+        assert np.array_equal(gf[k].astype(np.float64), OIP.label_channels(lf[k])), k
+
+
+@pytest.mark.parametrize("shape", [(2, 300, 400, 3), (1, 1024, 1024, 3), (3, 700, 333), (2, 512, 512, 3), (1, 64, 48, 3),
+                                   (2, 513, 511), (1, 2048, 1536, 3)])
+def test_resize_linear_u8_matches_the_oracles_cv_resize(engine, shape):
+    """sg_resize_linear_u8 = cv.resize(img, (512, 512)) in OpenCV's fixed-point arithmetic (decode_img / decode_lbel of
+    DeepLabv3plus.py:35,45 for tiles that are not 512 x 512), bit-exact against oracle/input_pipeline.py:resize_linear_u8:
+    up- and down-scaling, non-square, one and three channels, the exact-2x INTER_AREA substitution, the identity."""
+    from oracle import input_pipeline as OIP
+    rng = np.random.default_rng(sum(shape))
+    a = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    got = engine.resize_linear_u8(torch.from_numpy(a).cuda(), 512, 512).cpu().numpy()
+    for k in range(shape[0]):
+        ref = OIP.resize_linear_u8(a[k])
+        assert got[k].shape == ref.shape and np.array_equal(got[k], ref), (shape, k, int(np.abs(got[k].astype(int) - ref).max()))
+    small = engine.resize_linear_u8(torch.from_numpy(a[:1]).cuda(), 37, 91).cpu().numpy()[0]   # another target size
+    assert np.array_equal(small, OIP.resize_linear_u8(a[0], (91, 37)))
 
 
 def test_inference_tail(engine):

@@ -119,7 +119,8 @@ def test_file_generator_feeds_fit_generator(engine, tmp_path):
         Image.fromarray(rng.integers(0, 256, size=(512, 512, 3), dtype=np.uint8)).save(pi)
         Image.fromarray(lab).save(pl)
         imgs.append(str(pi)); labs.append(str(pl))
-    xh, yh = next(IP.train_data_gen(list(imgs), list(labs), 2))
+    from oracle import input_pipeline as OIP
+    xh, yh = next(OIP.data_gen(list(imgs), list(labs), 2))     # the oracle's restatement of train_data_gen
     xd, yd = next(IP.train_data_gen(list(imgs), list(labs), 2, engine=engine))
     assert np.array_equal(xh, xd) and yd.dtype == np.float64 and np.array_equal(yh, yd)
     model = zoo.Xception_DeepLabV3_Plus_bam((512, 512, 3), 2)
@@ -189,34 +190,40 @@ def test_predict_is_serialised_across_threads(engine):
     assert not errs, errs[:5]
 
 
-def test_device_data_gen_is_bit_identical_to_the_host_generator(engine, tmp_path):
+@pytest.mark.parametrize("size", [512, 384])
+def test_device_data_gen_is_bit_identical_to_the_oracle_generator(engine, tmp_path, size):
     """SURVEY 8f-1, the non-synchronous feed: files decoded by worker threads ahead of the consumer, uint8 pixels over PCIe,
-    normalisation and label channels on the device - same values as train_data_gen (DeepLabv3plus.py:53-107), bit for bit,
-    in the same (sorted, cycled) order, and fit_generator consumes the device tensors directly."""
+    resize (tiles that are not 512 x 512), normalisation and label channels on the device - the values of the ORACLE's
+    train_data_gen restatement (oracle/input_pipeline.py, DeepLabv3plus.py:32-107) bit for bit, in the same (sorted,
+    cycled) order, and fit_generator consumes the device tensors directly."""
     from PIL import Image
     from building_detection_amd import input_pipeline as IP, zoo
     from building_detection_amd.losses import edge_focal_loss, PA, IoU, MIoU, F1_score
+    from oracle import input_pipeline as OIP
     rng = np.random.default_rng(8)
     imgs, labs = [], []
+    q = size / 512.0
     for i in range(3):
-        lab = np.zeros((512, 512), np.uint8)
-        lab[40 + 90 * i:180 + 90 * i, 60:260 + 40 * i] = 255
-        lab[500:, :30] = 255
-        lab[100, 400] = 128          # a grey value that is NOT building (to_categorical truncation)
+        lab = np.zeros((size, size), np.uint8)
+        lab[int((40 + 90 * i) * q):int((180 + 90 * i) * q), int(60 * q):int((260 + 40 * i) * q)] = 255
+        lab[size - 12:, :30] = 255
+        lab[int(100 * q), int(400 * q)] = 128          # a grey value that is NOT building (to_categorical truncation)
         pi, pl = tmp_path / f"i{i}.png", tmp_path / f"l{i}.png"
-        Image.fromarray(rng.integers(0, 256, size=(512, 512, 3), dtype=np.uint8)).save(pi)
+        Image.fromarray(rng.integers(0, 256, size=(size, size, 3), dtype=np.uint8)).save(pi)
         Image.fromarray(lab).save(pl)
         imgs.append(str(pi)); labs.append(str(pl))
-    host = IP.train_data_gen(list(imgs), list(labs), 2)
+    host = OIP.data_gen(list(imgs), list(labs), 2)
     dev = IP.device_data_gen(list(imgs), list(labs), 2, engine, depth=2, workers=3)
     for _ in range(4):   # more than one cycle of the three files
         xh, yh = next(host)
         xd, yd = next(dev)
         assert xd.is_cuda and xd.dtype == torch.float32 and yd.dtype == torch.float32
+        assert tuple(xd.shape) == (2, 512, 512, 3) and tuple(yd.shape) == (2, 512, 512, 4)
         assert np.array_equal(xd.cpu().numpy(), xh)
         assert np.array_equal(yd.cpu().numpy().astype(np.float64), yh)
-    model = zoo.HRNet((512, 512, 3))
-    model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
-    hist = model.fit_generator(dev, steps_per_epoch=2, epochs=1, verbose=0)
-    assert np.isfinite(hist.history["loss"][-1])
+    if size == 512:
+        model = zoo.HRNet((512, 512, 3))
+        model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score])
+        hist = model.fit_generator(dev, steps_per_epoch=2, epochs=1, verbose=0)
+        assert np.isfinite(hist.history["loss"][-1])
     dev.close()
