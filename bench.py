@@ -186,10 +186,14 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="f32 = BASELINE configs[1] (the reference's precision, default); bf16 = configs[2]: bf16 activation "
                          "storage, one-pass bf16 MFMA products with fp32 accumulation, fp32 master weights / BN / loss / Adam")
-    ap.add_argument("--jit", action="store_true",
-                    help="Model.compile(jit_compile=True): the training step replayed as ONE hipGraph (single-GPU; the "
-                         "roofline figures then come from two extra EAGER steps after the timed region, because the "
-                         "launches inside a graph replay cannot be bracketed with events)")
+    ap.add_argument("--jit", dest="jit", action="store_true", default=None,
+                    help="Model.compile(jit_compile=True): the training step replayed as hipGraphs - ONE graph on a single "
+                         "GPU, one segment per gradient bucket under data parallelism with the RCCL all-reduces issued "
+                         "eagerly between them (runtime.GraphedTrainStep).  The roofline figures then come from two extra "
+                         "EAGER steps after the timed region, because launches inside a replay cannot be bracketed with "
+                         "events.  Default: on for --gpus > 1 (eight Python hosts queueing ~1800 launches per step each leave "
+                         "no slack), off on one GPU (GPU-bound either way, and the roofline events sit in the timed steps)")
+    ap.add_argument("--no-jit", dest="jit", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--comm", default=os.environ.get("SG_BENCH_COMM", "sg"), choices=["sg", "torch"],
@@ -237,7 +241,7 @@ def main():
         model = zoo.BUILDERS[args.model]((args.size, args.size, 3), 2, aspp_pool=args.size // 16)
     else:
         model = zoo.BUILDERS[args.model]((args.size, args.size, 3))
-    jit = bool(args.jit) and dist is None
+    jit = bool(args.jit) if args.jit is not None else (world > 1)
     model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score], jit_compile=jit)
     if jit and args.warmup < 3:
         args.warmup = 3   # two eager steps per shape, the third call captures (and replays) the graph
@@ -257,8 +261,15 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        model.train_on_batch(xd, yd, return_device_scalars=True)
+    for i in range(args.warmup):
+        try:
+            model.train_on_batch(xd, yd, return_device_scalars=True)
+        except Exception as e:   # the capture (third call) failed: this rank goes on eagerly - the eager and the replayed
+            if not (jit and i >= 2):   # step issue the SAME sequence of collectives, so the ranks stay in step
+                raise
+            print(f"[bench] rank {rank}: hipGraph capture of the train step failed ({e!r}); running eager launches", file=sys.stderr)
+            jit = model.jit_compile = False
+            model.train_on_batch(xd, yd, return_device_scalars=True)
     sync()
     eng.profile_begin()
     t0 = time.perf_counter()
@@ -346,7 +357,9 @@ def main():
                        "step_achieved_tflops": round(step_tflop / (ms_per_step / 1e3), 2),
                        "final_loss": float(loss.item()),
                        "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2),
-                       "train_step": "one hipGraph replay per step (compile(jit_compile=True))" if jit else "eager launches"},
+                       "train_step": (("one hipGraph replay per step (compile(jit_compile=True))" if dist is None else
+                                       "hipGraph segments per gradient bucket, eager RCCL all-reduces between them "
+                                       "(compile(jit_compile=True) under DataParallel)") if jit else "eager launches")},
             "roofline": {"bound": "mfma", "achieved": None if achieved is None else round(achieved, 2),
                          "peak": round(peak, 1), "unit": "TFLOP/s",
                          "frac": None if achieved is None else round(achieved / peak, 4),

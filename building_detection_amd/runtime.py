@@ -322,7 +322,7 @@ class Model:
         rt = self._runtime()
         with rt.eng.lock:
             xd, yd = rt.to_device(x), rt.to_device(y)
-            if getattr(self, "jit_compile", False) and self.dist is None:
+            if getattr(self, "jit_compile", False):
                 key = (tuple(xd.shape), tuple(yd.shape), xd.dtype, yd.dtype)
                 g = self._train_graphs.get(key)
                 if g is None:
@@ -484,13 +484,20 @@ class GraphedPredict:
 
 
 class GraphedTrainStep:
-    """One optimisation step of a compiled model - forward, loss, confusion counts, backward, Adam - captured into a
-    hipGraph for one (x, y) shape (Model.compile(jit_compile=True)).  The step's inputs are two static device buffers, its
+    """One optimisation step of a compiled model - forward, loss, confusion counts, backward, Adam - captured into
+    hipGraphs for one (x, y) shape (Model.compile(jit_compile=True)).  The step's inputs are two static device buffers, its
     outputs (loss, counts) two more; Adam's bias-corrected learning rate, the only number that changes from replay to
     replay, is read by the kernel from a one-float device buffer written before each replay (sg_adam_step_lr).  The weight
     planes are rebuilt inside the graph (the capture starts with them marked stale), BatchNorm's moving statistics and the
-    optimiser moments are updated in place as in the eager step.  Data-parallel models keep the eager step (their bucketed
-    all-reduce runs on a second stream behind host-side hooks)."""
+    optimiser moments are updated in place as in the eager step.
+
+    Single process: ONE graph.  Under data parallelism (model.dist set) the capture is CUT wherever the backward sweep
+    completes a gradient bucket (dist.BucketReducer's schedule): the step becomes a short chain of graph SEGMENTS - forward +
+    loss + backward down to the first complete bucket, then one segment per further bucket - plus one graph for Adam.
+    Between two segments the host hands the finished bucket to the transport EXACTLY as the eager step does (an eager
+    sg_comm_allreduce_sum / all_reduce on the communication stream behind an event on the compute stream), so RCCL never
+    runs inside a capture and the all-reduce of bucket k still overlaps the backward of segment k+1.  A step costs the host
+    (segments + 1) graph launches and (buckets + 2) collective calls instead of ~1800 kernel launches."""
 
     def __init__(self, model: "Model", xd, yd):
         import torch
@@ -498,6 +505,7 @@ class GraphedTrainStep:
         eng = rt.eng
         self.torch, self.model, self.rt = torch, model, rt
         opt = model.optimizer
+        dist = model.dist
         self.x, self.y = torch.empty_like(xd), torch.empty_like(yd)
         self.lr = eng.zeros(4)
         self.ws = torch.empty(max(eng._ws_peak, 256) + 256, dtype=torch.uint8, device=eng.device)
@@ -510,16 +518,59 @@ class GraphedTrainStep:
         rt.weights_changed()  # the graph must contain the plane preparation: every replay follows an optimiser step
         self._planes_key = rt._planes_key
         torch.cuda.synchronize(eng.device)
-        self.graph = torch.cuda.CUDAGraph()
+        self.segments = []        # [(graph, [(start, end) arena ranges complete after it])]
+        pool = torch.cuda.graph_pool_handle() if dist is not None else None
+        cuts = _SegmentCuts(dist.reducer.buckets) if dist is not None else None
+        state = {"ctx": None, "graph": None}
+
+        def begin():
+            g = torch.cuda.CUDAGraph()
+            kw = {"pool": pool} if pool is not None else {}
+            ctx = torch.cuda.graph(g, capture_error_mode="thread_local", **kw)
+            ctx.__enter__()
+            state["ctx"], state["graph"] = ctx, g
+
+        def end(ready):
+            state["ctx"].__exit__(None, None, None)
+            self.segments.append((state["graph"], ready))
+            state["ctx"] = state["graph"] = None
+
+        def node_done(index):   # the backward sweep has finished node `index`: cut when that completes buckets
+            ready = cuts.pop_ready(index)
+            if ready:
+                end(ready)
+                begin()
+
+        saved_hook = rt.on_node_done
         with eng.private_ws(self.ws):
-            with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
+            try:
+                rt.on_node_done = node_done if dist is not None else None
+                begin()
                 p = rt.forward(self.x, training=True)
                 self.loss = eng.loss_fwd(model.loss_kind, p, self.y)
                 self.counts = eng.confusion_counts(p, self.y) if model.metric_names else None
                 dp = eng.loss_bwd(model.loss_kind, p, self.y, 1.0)
                 rt.backward(dp)
-                eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, 0.0, opt.beta_1, opt.beta_2, opt.epsilon, 1.0,
-                              lr_dev=self.lr)
+                if dist is None:  # Adam rides in the same graph
+                    eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, 0.0, opt.beta_1, opt.beta_2, opt.epsilon, 1.0,
+                                  lr_dev=self.lr)
+                    end([])
+                else:
+                    end(cuts.pop_ready(-1))
+                    assert cuts.done(), "a gradient bucket was never handed over"
+                    begin()  # its own graph: it runs after the LAST all-reduce has joined the compute stream
+                    eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, 0.0, opt.beta_1, opt.beta_2, opt.epsilon,
+                                  1.0 / dist.world, lr_dev=self.lr)
+                    end([])
+            finally:
+                if state["ctx"] is not None:   # an error inside a capture: leave capture mode before re-raising
+                    try:
+                        state["ctx"].__exit__(None, None, None)
+                    except Exception:
+                        pass
+                rt.on_node_done = saved_hook
+        self.graph = self.segments[0][0]
+        self._loss_out = self._counts_out = None
         assert rt._planes_key == self._planes_key, "the weight-plane job table was rebuilt inside the capture"
         self._planes = (rt._planes_arena, rt._planes_jobs)  # kept alive: the graph's nodes carry their addresses
         rt.release()
@@ -528,15 +579,66 @@ class GraphedTrainStep:
     def run(self, xd, yd):
         """Replays the step on (xd, yd).  Returns the graph's static loss / counts buffers: read them before the next step."""
         opt = self.model.optimizer
+        dist = self.model.dist
         self.x.copy_(xd, non_blocking=True)
         self.y.copy_(yd, non_blocking=True)
         opt.iterations += 1
         t = opt.iterations
         lr_t = float(opt.lr) * math.sqrt(1.0 - opt.beta_2 ** t) / (1.0 - opt.beta_1 ** t)
         self.lr.fill_(lr_t)
-        self.graph.replay()
+        if dist is None:
+            self.graph.replay()
+        else:
+            run_segments([(g.replay, ready) for g, ready in self.segments[:-1]], self.rt.g_train, dist.tp)
+            # loss / counts of the GLOBAL batch: reduced in ordinary buffers of this object (the graphs' own outputs live in
+            # the capture's private pool and are rewritten by the next replay)
+            if self._loss_out is None:
+                self._loss_out = self.torch.empty_like(self.loss)
+                self._counts_out = None if self.counts is None else self.torch.empty_like(self.counts)
+            self._loss_out.copy_(self.loss)
+            if self.counts is not None:
+                self._counts_out.copy_(self.counts)
+            out = dist.reduce_step_scalars(self._loss_out, self._counts_out)
+            self.segments[-1][0].replay()   # Adam on the summed gradients (1 / world folded into the kernel)
+            self.rt.weights_changed()
+            return out
         self.rt.weights_changed()
         return self.loss, self.counts
+
+
+class _SegmentCuts:
+    """Where a captured data-parallel step is cut: `buckets` are dist.plan_buckets' (start, end, ready_node_index) in firing
+    order; pop_ready(i) returns the arena ranges that are complete once the backward sweep (descending node index) has
+    finished node i - the same rule as dist.BucketReducer.node_done, so the captured step hands buckets over at exactly
+    the points the eager step does."""
+
+    def __init__(self, buckets):
+        self.buckets = sorted(buckets, key=lambda b: -b[2])
+        self.next = 0
+
+    def pop_ready(self, node_index):
+        out = []
+        while self.next < len(self.buckets) and self.buckets[self.next][2] >= node_index:
+            s, e, _ = self.buckets[self.next]
+            out.append((s, e))
+            self.next += 1
+        return out
+
+    def done(self):
+        return self.next == len(self.buckets)
+
+
+def run_segments(segments, arena, transport):
+    """The replay loop of a segmented data-parallel step: `segments` = [(launch, [(start, end), ...])]; after launching a
+    segment (a graph replay: stream-ordered, returns at once) each arena range it completed goes to the transport's
+    asynchronous sum-all-reduce, which waits for the compute stream's work queued so far and runs beside the next segment;
+    the compute stream joins the transport before whatever follows (Adam).  Device-agnostic: the CPU tests drive it over
+    gloo with callables that write gradients."""
+    for launch, ready in segments:
+        launch()
+        for s, e in ready:
+            transport.allreduce_async(arena[s:e])
+    transport.join()
 
 
 class _Runtime:

@@ -137,6 +137,20 @@ def _up(x, f, s):
     return L.UpSampling2D(size=s)(_cbr(x, f, 1, activate=False))
 
 
+def _fuse2(b):
+    """fuse_block_2 (predict_model/hrnet.py:114-139): each of the three branches receives the other two, brought to its
+    resolution by 1x1 conv + nearest up-sampling (coarser) or stride-2 3x3 convs (finer); layer creation order as there."""
+    x12, x13 = _up(b[1], 32, 2), _up(b[2], 32, 4)
+    g0 = L.add([b[0], x12, x13])
+    x21 = _cbr(b[0], 64, 3, 2, activate=False)
+    x23 = _up(b[2], 64, 2)
+    g1 = L.add([x21, b[1], x23])
+    x31 = _cbr(_cbr(b[0], 32, 3, 2), 128, 3, 2, activate=False)
+    x32 = _cbr(b[1], 128, 3, 2, activate=False)
+    g2 = L.add([x31, x32, b[2]])
+    return g0, g1, g2
+
+
 def HRNet(shape=(512, 512, 3), num_classes=2):
     inp = L.Input(shape=shape)
     x = _cbr(inp, 64, strides=2)
@@ -151,14 +165,7 @@ def HRNet(shape=(512, 512, 3), num_classes=2):
     # stage 2: three resolutions
     t = [_cbr(f0, 32), _cbr(f1, 64), _cbr(f1, 128, strides=2)]
     b = [_branch(t[0], 32), _branch(t[1], 64), _branch(t[2], 128)]
-    x12, x13 = _up(b[1], 32, 2), _up(b[2], 32, 4)
-    g0 = L.add([b[0], x12, x13])
-    x21 = _cbr(b[0], 64, 3, 2, activate=False)
-    x23 = _up(b[2], 64, 2)
-    g1 = L.add([x21, b[1], x23])
-    x31 = _cbr(_cbr(b[0], 32, 3, 2), 128, 3, 2, activate=False)
-    x32 = _cbr(b[1], 128, 3, 2, activate=False)
-    g2 = L.add([x31, x32, b[2]])
+    g0, g1, g2 = _fuse2(b)
     # stage 3: four resolutions, fused by concatenation at 1/2
     t = [_cbr(g0, 32), _cbr(g1, 64), _cbr(g2, 128), _cbr(g2, 256, strides=2)]
     b = [_branch(t[0], 32), _branch(t[1], 64), _branch(t[2], 128), _branch(t[3], 256)]

@@ -200,6 +200,38 @@ class Net:
         ap = T.upsample_nearest(ap, pool)
         return torch.cat([c1, p1, p2, p3, ap], -1)
 
+    # -- blocks of the U-Nets, callable on their own (tests/test_block_chains_gpu.py) -------------------------
+    def res34_low_to_high(self, low, mid, high):
+        """low_to_high_feature: predict_model/res34.py:151-159 (train_model/res34.py:292-300)."""
+        low1, low2, mid1 = T.max_pool(low, 2), T.max_pool(low, 2, 4), T.max_pool(mid, 2)
+        hi = torch.cat([high, mid1, low2], -1)
+        hi = self.conv(hi, hi.shape[-1], 1, relu=True, init="he_normal")
+        md = torch.cat([mid, low1], -1)
+        md = self.conv(md, md.shape[-1], 1, relu=True, init="he_normal")
+        return md, hi
+
+    def res34_attention(self, t):
+        """attention_demo: predict_model/res34.py:90-105 (train_model/res34.py:231-246)."""
+        c = t.shape[-1]
+        g = T.global_avg_pool(t)
+        g = self.bn(self.dense(g, c // 2), relu=True)
+        g = torch.sigmoid(self.bn(self.dense(g, c)))
+        return t * g.view(-1, 1, 1, c)
+
+    def hr_fuse2(self, b0, b1, b2):
+        """fuse_block_2: predict_model/hrnet.py:114-139 (train_model/hrnet.py:245-298) - every branch to every resolution."""
+        cbr, up = self.conv_bn_relu, T.upsample_nearest
+        x12 = up(cbr(b1, 32, 1, activate=False), 2)
+        x13 = up(cbr(b2, 32, 1, activate=False), 4)
+        g0 = b0 + x12 + x13
+        x21 = cbr(b0, 64, 3, 2, activate=False)
+        x23 = up(cbr(b2, 64, 1, activate=False), 2)
+        g1 = x21 + b1 + x23
+        x31 = cbr(cbr(b0, 32, 3, 2), 128, 3, 2, activate=False)
+        x32 = cbr(b1, 128, 3, 2, activate=False)
+        g2 = x31 + x32 + b2
+        return g0, g1, g2
+
     def xception_backbone(self, x, with_bam: bool):
         """Entry/middle/exit flow shared by predict_model/v3plus.py:173-282 and bam.py:173-279."""
         x = self.conv_bn_relu(x, 32, 3, stride=2)
@@ -340,20 +372,8 @@ def res34_unet(P: Params, x, training=False, backbone_only=False):
         return feats
     conv1, conv2, conv3, conv4, conv5 = feats
 
-    def low_to_high(low, mid, high):           # res34.py:151-159
-        low1, low2, mid1 = T.max_pool(low, 2), T.max_pool(low, 2, 4), T.max_pool(mid, 2)
-        hi = torch.cat([high, mid1, low2], -1)
-        hi = n.conv(hi, hi.shape[-1], 1, relu=True, init=HE)
-        md = torch.cat([mid, low1], -1)
-        md = n.conv(md, md.shape[-1], 1, relu=True, init=HE)
-        return md, hi
-
-    def attention(t):                          # attention_demo, res34.py:90-105
-        c = t.shape[-1]
-        g = T.global_avg_pool(t)
-        g = n.bn(n.dense(g, c // 2), relu=True)
-        g = torch.sigmoid(n.bn(n.dense(g, c)))
-        return t * g.view(-1, 1, 1, c)
+    low_to_high = n.res34_low_to_high          # res34.py:151-159
+    attention = n.res34_attention              # attention_demo, res34.py:90-105
 
     def upsame(low, high):                     # res34.py:143-149
         c = low.shape[-1]
@@ -415,15 +435,7 @@ def hrnet(P: Params, x, training=False, num_classes=2):
     t0, t1, t2 = cbr(f0, 32, 3), cbr(f1, 64, 3), cbr(f1, 128, 3, 2)  # transition_layer2
     b0, b1, b2 = branch(t0, 32), branch(t1, 64), branch(t2, 128)
     # fuse_block_2 (hrnet.py:114-139)
-    x12 = up(cbr(b1, 32, 1, activate=False), 2)
-    x13 = up(cbr(b2, 32, 1, activate=False), 4)
-    g0 = b0 + x12 + x13
-    x21 = cbr(b0, 64, 3, 2, activate=False)
-    x23 = up(cbr(b2, 64, 1, activate=False), 2)
-    g1 = x21 + b1 + x23
-    x31 = cbr(cbr(b0, 32, 3, 2), 128, 3, 2, activate=False)
-    x32 = cbr(b1, 128, 3, 2, activate=False)
-    g2 = x31 + x32 + b2
+    g0, g1, g2 = n.hr_fuse2(b0, b1, b2)
     t0, t1, t2, t3 = cbr(g0, 32, 3), cbr(g1, 64, 3), cbr(g2, 128, 3), cbr(g2, 256, 3, 2)  # transition_layer3
     b0, b1, b2, b3 = branch(t0, 32), branch(t1, 64), branch(t2, 128), branch(t3, 256)
     # fuse_block_3 (hrnet.py:142-162)

@@ -363,3 +363,36 @@ def test_multi_op_chain_bf16(engine):
     print(f"bf16 chain: loss {loss:.6f} (fp64 {loss_ref:.6f}); worst gradient {worst[0]} rel-L2 {worst[1]:.2e}")
     assert abs(loss - loss_ref) <= 1e-3 * abs(loss_ref)
     assert worst[1] <= 8e-2, worst
+
+
+def test_bf16_convergence_ab_100_steps(engine):
+    """VERDICT r2 next #1c: a 104-step fp32-vs-mixed_bfloat16 convergence A/B of DeepLabv3+ on a FIXED set of 32 synthetic
+    tiles (four batches of eight 128x128 tiles, cycled: 26 epochs), same initial weights, same Adam, captured train step.
+    Per-epoch means of the training loss and of MIoU (a single step's value jitters with the batch): the bf16 curve stays
+    inside a band around the fp32 one and ends as low.  Random-init BatchNorm nets are chaotic step by step (two correct
+    fp32 evaluations drift apart too - test_models_gpu.py), so the band is on the epoch means, stated here:
+    loss within 15 % (+ 0.01), MIoU within 0.05, final-epoch loss of bf16 <= 1.15 x fp32's, both losses fall by > 30 %."""
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss, PA, IoU, MIoU, F1_score
+    batches = [synthetic_batch(8, 128, 128, seed=700 + i) for i in range(4)]
+    dev = [(torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()) for x, y in batches]
+    curves, ws0 = {}, None
+    for dt in ("float32", "mixed_bfloat16"):
+        m = _build("v3plus", 128, {"aspp_pool": 8}, dt)
+        if ws0 is None:
+            ws0 = m.get_weights()
+        m.set_weights(ws0)
+        m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score], jit_compile=True)
+        logs = [m.train_on_batch(*dev[s % 4]) for s in range(104)]
+        curves[dt] = (np.array([l["loss"] for l in logs]).reshape(26, 4).mean(1), np.array([l["MIoU"] for l in logs]).reshape(26, 4).mean(1))
+    (la, ma), (lb, mb) = curves["float32"], curves["mixed_bfloat16"]
+    print("epoch-mean loss fp32", np.round(la, 4))
+    print("epoch-mean loss bf16", np.round(lb, 4))
+    print("epoch-mean MIoU fp32", np.round(ma, 4))
+    print("epoch-mean MIoU bf16", np.round(mb, 4))
+    print(f"largest relative loss gap {float(np.max(np.abs(lb - la) / la)):.3f}, largest MIoU gap {float(np.max(np.abs(mb - ma))):.4f}")
+    assert np.all(np.isfinite(lb)) and np.all(np.isfinite(mb))
+    assert la[-1] < 0.7 * la[0] and lb[-1] < 0.7 * lb[0], (la[0], la[-1], lb[0], lb[-1])
+    assert np.all(np.abs(lb - la) <= 0.15 * la + 0.01), (la, lb)
+    assert np.all(np.abs(mb - ma) <= 0.05), (ma, mb)
+    assert lb[-1] <= 1.15 * la[-1] + 0.005

@@ -1,0 +1,336 @@
+"""Exact backward through the model BLOCKS: every gradient within 1e-5 of fp64 autograd.
+
+test_train_step_parity holds whole-model fp32 gradients to 2e-2 only - a random-init BN + ReLU net amplifies rounding
+through ReLU flips - and the two exact chains of test_models_gpu.py cover conv -> BN -> conv and sepconv -> BN -> add ->
+scSE -> convT -> head.  This file closes the rest, block by block, through the engine's own graph executor (layers.py /
+runtime.py: fusion pass, BN statistics from the conv epilogue, prepared weight planes, fused combine nodes - exactly what
+a training step runs), against the oracle's restatement of the same reference text in fp64:
+
+    SKNet_block                    train_model/DeepLabv3plus.py:210-274   zoo.deeplab._sk_block      / oracle Net.sk_block
+    BAM_attention (C = 728, r 45)  train_model/DeepLabv3plus_bam.py:160-211  layers.bam_block        / Net.bam
+    ASPP incl. the pool branch     train_model/DeepLabv3plus.py:431-443   zoo.deeplab._aspp          / Net.aspp
+    HRNet fuse_block_2             train_model/hrnet.py:245-298           zoo.unets._fuse2           / Net.hr_fuse2
+    Res34 low_to_high_feature +    train_model/res34.py:292-300,231-246   ResNetFamily.low_to_high_feature, attention_demo
+      attention_demo                                                      / Net.res34_low_to_high, res34_attention
+
+How flip noise is excluded instead of excused: before the comparison one fp64 "calibration" pass walks the block and
+moves, layer by layer, each BatchNormalization's beta (or each conv+ReLU's bias) per channel to the centre of the widest
+gap of that channel's pre-activations around zero; every ReLU input then lies ~1e-2 away from 0 (asserted > 1e-4), so
+fp32 and fp64 take the same branch everywhere and what remains is pure rounding.  Both sides then run on the SAME
+float32-representable weights.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models as M
+from oracle import tfops as T
+
+pytestmark = pytest.mark.gpu
+
+D = torch.float64
+
+
+def _gap_shift(v: torch.Tensor) -> torch.Tensor:
+    """Per channel (last axis): minus the midpoint of the widest gap between consecutive sorted values whose midpoint lies
+    near zero (within 0.5 sigma; 1.5 sigma for the few-sample channels of a pooled map or a 2-D BatchNormalization).
+    Added to the bias / beta in front of a ReLU it leaves every pre-activation of the channel at least half that gap from 0."""
+    flat = v.detach().reshape(-1, v.shape[-1])
+    n = flat.shape[0]
+    if n == 1:  # one value per channel: push it 0.1 away from zero
+        x = flat[0]
+        return torch.where(x.abs() < 0.1, torch.where(x >= 0, 0.1 - x, -0.1 - x), torch.zeros_like(x))
+    vals = flat.sort(dim=0).values
+    mids, gaps = (vals[1:] + vals[:-1]) / 2, vals[1:] - vals[:-1]
+    lim = (0.5 if n >= 16 else 1.5) * (vals.std(dim=0, keepdim=True) + 1e-12)
+    ok = mids.abs() <= lim
+    ok = torch.where(ok.any(dim=0, keepdim=True), ok, torch.ones_like(ok))
+    idx = torch.where(ok, gaps, torch.full_like(gaps, -1.0)).argmax(dim=0, keepdim=True)
+    return -mids.gather(0, idx)[0]
+
+
+class CalNet(M.Net):
+    """oracle Net that, while `calibrate`, shifts the parameter in front of every ReLU (see the module docstring) and
+    always records the smallest |ReLU input| it sees."""
+
+    def __init__(self, P, training, calibrate):
+        super().__init__(P, training)
+        self.calibrate, self.margin = calibrate, float("inf")
+
+    def _relu(self, y, shift_param):
+        if self.calibrate:
+            with torch.no_grad():
+                d = _gap_shift(y)
+                shift_param.data += d.to(shift_param.dtype)
+            y = y + d
+        self.margin = min(self.margin, float(y.detach().abs().min()))
+        return torch.relu(y)
+
+    def conv(self, x, filters, k=1, stride=1, dilation=1, relu=False, init="glorot_uniform"):
+        w = self.P.kernel((k, k, x.shape[-1], filters), init)
+        b = self.P.bias(filters)
+        y = T.conv2d(x, w, b, stride, dilation, "same")
+        return self._relu(y, b) if relu else y
+
+    def bn(self, x, relu=False):
+        g, b, m, v = self.P.bn(x.shape[-1])
+        y, nm, nv = T.batch_norm(x, g, b, m, v, self.training)
+        if self.training:
+            self.P._set(2, nm)
+            self.P._set(1, nv)
+        return self._relu(y, b) if relu else y
+
+
+def _randomise(model, seed):
+    """Non-trivial values for every weight kind (the defaults - zero biases, gamma 1, beta 0 - hide whole terms)."""
+    rng = np.random.default_rng(seed)
+    ws = model.get_weights()
+    for i, p in enumerate(model.params):
+        if p.kind in ("bias", "beta"):
+            ws[i] = rng.normal(0, 0.1, p.shape).astype(np.float32)
+        elif p.kind == "gamma":
+            ws[i] = (1 + rng.normal(0, 0.1, p.shape)).astype(np.float32)
+        elif p.kind == "moving_mean":
+            ws[i] = np.zeros(p.shape, np.float32)
+        elif p.kind == "moving_var":
+            ws[i] = np.ones(p.shape, np.float32)
+    return ws
+
+
+def _y_true(n, h, w, seed):
+    from building_detection_amd.data import synthetic_batch
+    return synthetic_batch(n, h, w, seed=seed)[1]
+
+
+BF16_CASES = {}   # name -> the arguments of its _run_case call: the bf16-storage run of the same blocks (end of the file)
+
+
+def _run_case(engine, name, build_engine, build_oracle, in_shape, seed, n=2, policy="float32"):
+    """build_engine(inp KTensor) -> KTensor [N,H,W,2] probabilities; build_oracle(net, x) -> the same on the oracle.
+    policy "mixed_bfloat16": the engine stores every activation as bf16 (BASELINE configs[2]); the comparison is then the
+    tolerance contract of DESIGN.md section 8 on a shallow, flip-free block: per tensor cosine >= 0.99 against fp64."""
+    from building_detection_amd import mixed_precision as MP
+    BF16_CASES.setdefault(name, (build_engine, build_oracle, in_shape, seed, n))
+    MP.set_global_policy(policy)
+    try:
+        return _run_case_(engine, name, build_engine, build_oracle, in_shape, seed, n, policy)
+    finally:
+        MP.set_global_policy("float32")
+
+
+def _run_case_(engine, name, build_engine, build_oracle, in_shape, seed, n, policy):
+    from building_detection_amd import layers as L
+    from building_detection_amd.losses import edge_focal_loss
+    from building_detection_amd.runtime import Model
+    inp = L.Input(shape=in_shape)
+    model = Model(inp, build_engine(inp), name=name)
+    model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
+    ws = _randomise(model, seed)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, *in_shape, generator=g).numpy().astype(np.float32)
+    ho, wo = model.outputs[0].shape[1:3]
+    y = _y_true(n, ho, wo, seed + 1)
+
+    # calibration pass (fp64, training mode): moves the parameters in front of the ReLUs; then round to float32
+    P = M.Params(weights=ws, dtype=D)
+    net = CalNet(P, True, calibrate=True)
+    with torch.no_grad():
+        build_oracle(net, torch.from_numpy(x).to(D))
+    ws = [w.astype(np.float32) for w in P.numpy_weights()]
+    for i, p in enumerate(model.params):   # the calibration pass also moved the BN moving statistics: reset them
+        if p.kind == "moving_mean":
+            ws[i] = np.zeros(p.shape, np.float32)
+        elif p.kind == "moving_var":
+            ws[i] = np.ones(p.shape, np.float32)
+    assert len(ws) == len(model.params), (len(ws), len(model.params))
+    model.set_weights(ws)
+
+    # reference: fp64 autograd on the float32-representable weights
+    P = M.Params(weights=ws, dtype=D)
+    net = CalNet(P, True, calibrate=False)
+    prob = build_oracle(net, torch.from_numpy(x).to(D))
+    loss_ref = M.loss_fn("edge_focal_loss", torch.from_numpy(y).to(D), prob)
+    loss_ref.backward()
+    assert net.margin > 1e-4, f"{name}: a ReLU input lies {net.margin:.1e} from 0 after calibration"
+    tr = P.trainable_tensors()
+    names = [p.name for p in model.params if p.trainable]
+    assert len(tr) == len(names)
+
+    # the yardstick of "rounding level": the same graph evaluated by the CPU oracle in fp32 (a second correct fp32
+    # evaluation; a block with a BatchNormalization over a handful of pooled samples amplifies rounding a little)
+    P32 = M.Params(weights=ws, dtype=torch.float32)
+    prob32 = build_oracle(CalNet(P32, True, calibrate=False), torch.from_numpy(x))
+    M.loss_fn("edge_focal_loss", torch.from_numpy(y), prob32).backward()
+    tr32 = P32.trainable_tensors()
+
+    logs = model.train_on_batch(x, y)
+    got = model.get_gradients()
+    if policy != "float32":
+        return _check_bf16(name, model, logs, got, names, tr, loss_ref.item())
+    assert abs(logs["loss"] - loss_ref.item()) <= 3e-6 * abs(loss_ref.item()), (name, logs["loss"], loss_ref.item())
+    gmax = max(float(t.grad.abs().max()) for t in tr)
+    worst, worst32 = ("", 0.0), ("", 0.0)
+    for nm, a, t, t32 in zip(names, got, tr, tr32):
+        r = t.grad.numpy()
+        a = a.astype(np.float64)
+        scale = float(np.abs(r).max())
+        if scale < 1e-9 * gmax:   # structurally zero (a bias feeding BatchNormalization): held to the noise floor
+            assert float(np.abs(a).max()) <= 1e-6 * gmax, (name, nm, float(np.abs(a).max()), gmax)
+            continue
+        rel = float(np.abs(a - r).max()) / scale
+        rel32 = float(np.abs(t32.grad.double().numpy() - r).max()) / scale
+        worst = max(worst, (nm, rel), key=lambda kv: kv[1])
+        worst32 = max(worst32, (nm, rel32), key=lambda kv: kv[1])
+        # 1e-5 of the tensor's largest entry, as test_backward_chain_exact_multi_op; where the fp32 CPU oracle itself is
+        # further than that from fp64 on this tensor (small-sample BatchNormalization), twice ITS distance
+        assert rel <= max(1e-5, 2.0 * rel32), (name, nm, rel, rel32)
+    print(f"{name}: {len(names)} gradient tensors, loss gpu {logs['loss']:.7f} fp64 {loss_ref.item():.7f}; worst gradient vs fp64: "
+          f"gpu {worst[0]} {worst[1]:.2e}, cpu-fp32 oracle {worst32[0]} {worst32[1]:.2e}; smallest |ReLU input| {net.margin:.2e}")
+    assert worst[1] <= 5e-5, (name, worst)   # whatever the yardstick says, never beyond rounding level
+
+
+def _check_bf16(name, model, logs, got, names, tr, loss_ref):
+    """bf16 storage against fp64 on a block without ReLU flips to amplify anything: the loss within 2e-3, every weight
+    gradient aligned with the true one (cosine >= 0.99, i.e. relative L2 <= ~0.14: bf16's 2^-9 per stored tensor through
+    <= 10 layers gives 1e-3 ... 5e-2, measured and printed) - a mis-scaled, missing or mis-routed bf16 hand-off is O(1)."""
+    assert model.compute_dtype == "bfloat16"
+    assert abs(logs["loss"] - loss_ref) <= 2e-3 * abs(loss_ref), (name, logs["loss"], loss_ref)
+    gmax = max(float(t.grad.abs().max()) for t in tr)
+    rows = []
+    for nm, a, t in zip(names, got, tr):
+        r = t.grad.numpy().astype(np.float64).reshape(-1)
+        a = a.astype(np.float64).reshape(-1)
+        if float(np.abs(r).max()) < 1e-9 * gmax:
+            continue
+        rows.append((nm, float(a @ r / (np.linalg.norm(a) * np.linalg.norm(r))), float(np.linalg.norm(a - r) / np.linalg.norm(r))))
+    wc = min(rows, key=lambda t_: t_[1])
+    wr = max(rows, key=lambda t_: t_[2])
+    print(f"{name} bf16: loss {logs['loss']:.6f} fp64 {loss_ref:.6f}; {len(rows)} tensors, lowest cosine {wc[0]} {wc[1]:.5f}, "
+          f"largest rel-L2 {wr[0]} {wr[2]:.2e}, median rel-L2 {float(np.median([r_[2] for r_ in rows])):.2e}")
+    for nm, c, r in rows:
+        assert c >= 0.99, (name, nm, c, r)
+
+
+def _head_engine(y):
+    from building_detection_amd import layers as L
+    return L.Conv2D(2, 1, activation="softmax")(y)
+
+
+def _head_oracle(net, y):
+    return torch.softmax(net.conv(y, 2, 1), -1)
+
+
+def test_sk_block_chain(engine):
+    """stem 1x1 -> SKNet_block (3x3 entry, {1x1, d6, d12, d18, GAP -> up} branches, squeeze, five heads, branch softmax,
+    weighted sum, BN + ReLU) -> head: the dilated branches' dgrad / wgrad, the GAP round trip and sk_fuse's backward."""
+    from building_detection_amd import layers as L
+    from building_detection_amd.zoo import deeplab as Z
+
+    def eng(inp):
+        return _head_engine(Z._sk_block(L.Conv2D(96, 1)(inp)))
+
+    def ora(net, x):
+        return _head_oracle(net, net.sk_block(net.conv(x, 96, 1)))
+
+    _run_case(engine, "sk_block", eng, ora, (16, 16, 40), seed=3, n=6)
+
+
+def test_bam_block_chain(engine):
+    """stem -> BAM_attention at C = 728 (reduce dim 45): Dense + 2-D BatchNormalization x2 + Dense channel gate, 1x1 ->
+    two 45-channel dilation-4 3x3 convs -> 1x1 spatial gate, fused sigmoid combine -> head."""
+    from building_detection_amd import layers as L
+
+    def eng(inp):
+        return _head_engine(L.bam_block(L.Conv2D(728, 1)(inp)))
+
+    def ora(net, x):
+        return _head_oracle(net, net.bam(net.conv(x, 728, 1)))
+
+    _run_case(engine, "bam_block", eng, ora, (16, 16, 24), seed=5, n=6)
+
+
+@pytest.mark.parametrize("pool", [16, 8], ids=["global_pool", "pool_2x2"])
+def test_aspp_chain(engine, pool):
+    """stem -> ASPP (1x1, three dilated 3x3, AveragePooling2D(pool) -> 1x1 -> UpSampling2D(pool), concat) -> head.  pool 16
+    on a 16 x 16 map is the reference's case (32 on 32 x 32: a global pool); pool 8 leaves a 2 x 2 pooled map (config 5)."""
+    from building_detection_amd import layers as L
+    from building_detection_amd.zoo import deeplab as Z
+
+    def eng(inp):
+        return _head_engine(Z._aspp(L.Conv2D(128, 1)(inp), pool))
+
+    def ora(net, x):
+        return _head_oracle(net, net.aspp(net.conv(x, 128, 1), pool))
+
+    _run_case(engine, f"aspp_pool{pool}", eng, ora, (16, 16, 32), seed=7 + pool, n=6)
+
+
+def test_hrnet_fuse_chain(engine):
+    """three stems (full, 1/2, 1/4 resolution) -> fuse_block_2 (1x1 + nearest up-sampling x2 / x4, stride-2 3x3 chains,
+    three-way adds) -> transition convs -> up-sample, concat -> head."""
+    from building_detection_amd import layers as L
+    from building_detection_amd.zoo import unets as U
+
+    def eng(inp):
+        b0 = L.Conv2D(32, 1)(inp)
+        b1 = L.Conv2D(64, 3, strides=2, padding="same")(inp)
+        b2 = L.Conv2D(128, 3, strides=2, padding="same")(b1)
+        g0, g1, g2 = U._fuse2([b0, b1, b2])
+        t = [U._cbr(g0, 32), U._cbr(g1, 64), U._cbr(g2, 128)]
+        y = L.concatenate([t[0], L.UpSampling2D(size=2)(t[1]), L.UpSampling2D(size=4)(t[2])])
+        return _head_engine(y)
+
+    def ora(net, x):
+        b0 = net.conv(x, 32, 1)
+        b1 = net.conv(x, 64, 3, 2)
+        b2 = net.conv(b1, 128, 3, 2)
+        g0, g1, g2 = net.hr_fuse2(b0, b1, b2)
+        t0, t1, t2 = net.conv_bn_relu(g0, 32, 3), net.conv_bn_relu(g1, 64, 3), net.conv_bn_relu(g2, 128, 3)
+        y = torch.cat([t0, T.upsample_nearest(t1, 2), T.upsample_nearest(t2, 4)], -1)
+        return _head_oracle(net, y)
+
+    _run_case(engine, "hrnet_fuse2", eng, ora, (32, 32, 16), seed=11, n=3)
+
+
+def test_res34_fusion_and_attention_chain(engine):
+    """three stems -> low_to_high_feature (MaxPool 2/2 and 2/4, concat, he_normal 1x1 + ReLU) -> attention_demo on both
+    outputs (GAP -> Dense -> 2-D BN + ReLU -> Dense -> 2-D BN -> sigmoid -> channel multiply) -> up-sample, concat -> head."""
+    from building_detection_amd import layers as L
+    from building_detection_amd.zoo import unets as U
+
+    def eng(inp):
+        fam = U.ResNetFamily((8, 8, 3))
+        low = L.Conv2D(64, 1)(inp)
+        mid = L.Conv2D(128, 3, strides=2, padding="same")(inp)
+        high = L.Conv2D(256, 3, strides=2, padding="same")(mid)
+        md, hi = fam.low_to_high_feature(low, mid, high)
+        md, hi = fam.attention_demo(md), fam.attention_demo(hi)
+        y = L.concatenate([L.UpSampling2D(size=2)(md), L.UpSampling2D(size=4)(hi)])
+        return _head_engine(y)
+
+    def ora(net, x):
+        low = net.conv(x, 64, 1)
+        mid = net.conv(x, 128, 3, 2)
+        high = net.conv(mid, 256, 3, 2)
+        md, hi = net.res34_low_to_high(low, mid, high)
+        md, hi = net.res34_attention(md), net.res34_attention(hi)
+        y = torch.cat([T.upsample_nearest(md, 2), T.upsample_nearest(hi, 4)], -1)
+        return _head_oracle(net, y)
+
+    _run_case(engine, "res34_fusion_attention", eng, ora, (32, 32, 16), seed=13, n=6)
+
+
+BLOCK_TESTS = [("sk_block", test_sk_block_chain), ("bam_block", test_bam_block_chain), ("aspp_pool16", lambda e: test_aspp_chain(e, 16)),
+               ("hrnet_fuse2", test_hrnet_fuse_chain), ("res34_fusion_attention", test_res34_fusion_and_attention_chain)]
+
+
+@pytest.mark.parametrize("name", [b[0] for b in BLOCK_TESTS])
+def test_block_chain_bf16_storage(engine, name, monkeypatch):
+    """VERDICT r2 next #1b: the blocks above with mixed_bfloat16 storage - the well-conditioned bf16 gradient check that CAN
+    fail (the whole-model bf16-vs-fp32 cosine of a random-init BatchNorm net is 0.44-0.58 and says nothing): every
+    hand-off of the real graph (bf16 activations, fp32 statistics / weight gradients / head) inside each block, against
+    fp64 autograd, per-tensor cosine >= 0.99."""
+    if name not in BF16_CASES:   # registered by the fp32 run of the same block; run it here when selected alone
+        dict(BLOCK_TESTS)[name](engine)
+    be, bo, in_shape, seed, n = BF16_CASES[name]
+    _run_case(engine, name, be, bo, in_shape, seed, n, policy="mixed_bfloat16")

@@ -119,3 +119,88 @@ def test_data_parallel_step_world2(engine, comm, tmp_path):
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     _run(2, comm, tmp_path)
+
+
+def _jit_worker(rank, world, port, comm, policy, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from building_detection_amd import mixed_precision as MP, zoo
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.dist import DataParallel
+    from building_detection_amd.losses import edge_focal_loss, PA, IoU
+    from building_detection_amd.runtime import GraphedTrainStep
+    torch.cuda.set_device(rank)
+    backend = "nccl" if comm == "torch" else "gloo"
+    kw = {"device_id": torch.device("cuda", rank)} if backend == "nccl" else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    try:
+        MP.set_global_policy(policy)
+        try:
+            ma = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+            mb = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+        finally:
+            MP.set_global_policy("float32")
+        mb.set_weights(ma.get_weights())
+        ma.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU])
+        mb.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU], jit_compile=True)
+        da = DataParallel(ma, bucket_mb=8.0, comm=comm)
+        db = DataParallel(mb, bucket_mb=8.0, comm=comm)
+        same = True
+        xv, yv = synthetic_batch(3, 64, 64, seed=99 + rank)
+        for i in range(7):
+            x, y = synthetic_batch(2, 64, 64, seed=40 + 10 * rank + i)
+            la, lb = ma.train_on_batch(x, y), mb.train_on_batch(x, y)
+            same = same and la == lb
+            if i == 3:   # another batch size in between (re-keys the runtime's weight planes), and a new learning rate
+                same = same and ma.test_on_batch(xv, yv) == mb.test_on_batch(xv, yv)
+                ma.optimizer.lr = mb.optimizer.lr = 3e-4
+        g = next(iter(mb._train_graphs.values()))
+        weights_equal = all(np.array_equal(a, b) for a, b in zip(ma.get_weights(), mb.get_weights()))
+        q.put(dict(rank=rank, same_logs=same, weights_equal=weights_equal, graphed=isinstance(g, GraphedTrainStep),
+                   segments=len(g.segments), buckets=len(db.buckets), eager_graphs=len(getattr(ma, "_train_graphs", {}) or {})))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_jit(world, comm, policy):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 36500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_jit_worker, args=(r, world, port, comm, policy, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in procs:
+            res.append(q.get(timeout=400))
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    for r in res:
+        assert r["graphed"] and r["eager_graphs"] == 0, r
+        assert r["buckets"] >= 2 and r["segments"] == r["buckets"] + 1, r   # one segment per bucket + the Adam graph
+        assert r["same_logs"] and r["weights_equal"], r
+
+
+@pytest.mark.parametrize("comm,policy", [("sg", "float32"), ("torch", "float32"), ("sg", "mixed_bfloat16")])
+def test_captured_data_parallel_step_is_bit_identical_to_the_eager_one_world1(engine, comm, policy):
+    """compile(jit_compile=True) under DataParallel.  The step is captured as one hipGraph segment per
+    gradient bucket (cut where the backward sweep completes the bucket) plus one graph for Adam; the bucket all-reduces
+    (sg_comm_allreduce_sum / torch.distributed nccl) are issued eagerly between the segment launches, the loss and the
+    confusion counts are reduced as in the eager step.  Seven steps against the eager data-parallel model on the same
+    weights and batches: identical logs at every step and identical weights at the end, to the bit, with a validation batch
+    of another size and a learning-rate change in between."""
+    _run_jit(1, comm, policy)
+
+
+@pytest.mark.parametrize("comm", ["sg", "torch"])
+def test_captured_data_parallel_step_world2(engine, comm):
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    _run_jit(2, comm, "float32")
