@@ -539,7 +539,8 @@ class GraphedTrainStep:
             ready = cuts.pop_ready(index)
             if ready:
                 end(ready)
-                begin()
+                if index > 0:   # node 0 ends the sweep: nothing is left to capture behind it
+                    begin()
 
         saved_hook = rt.on_node_done
         with eng.private_ws(self.ws):
@@ -556,7 +557,8 @@ class GraphedTrainStep:
                                   lr_dev=self.lr)
                     end([])
                 else:
-                    end(cuts.pop_ready(-1))
+                    if state["ctx"] is not None:
+                        end(cuts.pop_ready(-1))
                     assert cuts.done(), "a gradient bucket was never handed over"
                     begin()  # its own graph: it runs after the LAST all-reduce has joined the compute stream
                     eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, 0.0, opt.beta_1, opt.beta_2, opt.epsilon,

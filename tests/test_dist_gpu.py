@@ -184,7 +184,9 @@ def _run_jit(world, comm, policy):
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     for r in res:
         assert r["graphed"] and r["eager_graphs"] == 0, r
-        assert r["buckets"] >= 2 and r["segments"] == r["buckets"] + 1, r   # one segment per bucket + the Adam graph
+        # one cut per point of the sweep that completes buckets (<= one per bucket), a tail segment when the sweep goes on
+        # behind the last cut, and the Adam graph
+        assert r["buckets"] >= 2 and 3 <= r["segments"] <= r["buckets"] + 2, r
         assert r["same_logs"] and r["weights_equal"], r
 
 
