@@ -1053,10 +1053,14 @@ void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false, int eb = 4) 
   p.cb = ((conv_l2(x6) & 2) && ut && ntaps > 1 && spt > cbv && spt % cbv == 0 && img_bytes > (2ll << 20)) ? cbv : 0;
 }
 
+// set while a launch beyond 2 GiB runs as sub-batches of whole images (sg_conv2d_fwd_ws / sg_conv2d_dgrad recursion)
+thread_local bool g_sub_batch = false;
+
 #include "conv_x6.h"
 #include "conv_x6p.h"
 #include "conv_b16.h"
 #include "conv_x6wp.h"
+#include "conv_pw.h"
 
 template <int NPL, typename TA>
 int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
@@ -1125,6 +1129,24 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
   if constexpr (NPL == 3) {
     if (x6p_ok(p, KH, KW)) return run_x6p(p, w, dgrad, Cin, Cout, ws, num_cus, st, prepared);
   }
+  // 1x1 / stride 1 with enough columns for 384-wide tiles (the 728-wide middle flow and the exit flow): conv_pw.h, with its
+  // own k-block-major plane layout
+  if constexpr ((NPL == 3 && std::is_same<TA, float>::value) || (NPL == 1 && !std::is_same<TA, float>::value)) {
+    if (pw_wide_ok(p, EL<TA>::BYTES)) {
+      const int K = p.K, N = p.Nout;
+      p.Kpad = pw_kpad(K, NPL);
+      p.Npad = pw_npad(N);
+      p.wq = (const unsigned short*)ws;
+      p.w_bytes = (uint32_t)pw_planes_bytes(K, N, NPL);
+      if (!prepared) {
+        dim3 grid((unsigned)sg_cdiv(p.Kpad, 32), (unsigned)sg_cdiv(p.Npad, 32));
+        hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, K,
+                           Cin * Cout, dgrad ? 1 : Cout, dgrad ? Cout : 1, NPL, K, pw_kd(NPL));
+        SG_LAUNCH_CHECK("split3_weights_kernel");
+      }
+      return launch_pw_wide<NPL, TA>(p, st);
+    }
+  }
   const int Ck = p.C;
   int Ckp = Ck;
   if (Ck % BK != 0 && p.K != Ck) {  // virtual channel padding (x6_ok admitted the shape): whole slabs inside one tap
@@ -1158,7 +1180,9 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
 // workspace of the weight planes for a launch with `taps` taps of depth C (virtual padding included), N columns
 inline size_t x6_ws_bytes(int taps, int C, int N) {
   const int k = taps > 1 ? taps * x6_vpad_c(C) : C;
-  return x6_planes_bytes(k, N, 3);
+  const size_t rows = x6_planes_bytes(k, N, 3);
+  const size_t wide = taps == 1 ? pw_planes_bytes(C, N, 3) : 0;   // the wide pointwise kernel pads N to 384s
+  return rows > wide ? rows : wide;
 }
 
 int dispatch_igemm(const IgemmParams& p_in, bool vec, int num_cus, hipStream_t st) {
@@ -1787,7 +1811,9 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
         sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
         const char* xs = (const char*)x + (int64_t)n0 * d->H * d->W * xl * eb;
         char* ys = (char*)y + (int64_t)n0 * d->Ho * d->Wo * yl * eb;
+        g_sub_batch = true;   // the weight planes were laid out for the whole batch: no batch-size dependent kernel choice
         int rcs = sg_conv2d_fwd_ws(ctx, stream, dtype, &sub, xs, w, bias, ys, flags, ws, ws_bytes);  // (no statistics)
+        g_sub_batch = false;
         if (rcs) return rcs;
       }
       return 0;
@@ -1886,6 +1912,18 @@ int sg_conv2d_planes_job(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, in
       *bytes = (size_t)3 * p.K * p.Nout * 2;
       return 0;
     }
+  }
+  p.x = (const float*)(uintptr_t)16;
+  if (nb >= d->N && pw_wide_ok(p, eb)) {   // the wide pointwise kernel's k-block-major planes (conv_pw.h); never for sub-batches
+    out->kind = 3;
+    out->npl = npl;
+    out->K = p.K;
+    out->Ckp = pw_kd(npl);
+    out->Kpad = pw_kpad(p.K, npl);
+    out->Npad = pw_npad(p.Nout);
+    out->nblocks = (int32_t)(sg_cdiv(out->Kpad, 32) * sg_cdiv(out->Npad, 32));
+    *bytes = pw_planes_bytes(p.K, p.Nout, npl);
+    return 0;
   }
   int Ckp = Ck, K = p.K;
   if (Ck % BK != 0 && K != Ck) {
@@ -2000,7 +2038,9 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
         sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
         const char* dys = (const char*)dy + (int64_t)n0 * d->Ho * d->Wo * yl * eb;
         char* dxs = (char*)dx + (int64_t)n0 * d->H * d->W * xl * eb;
+        g_sub_batch = true;
         int rcs = sg_conv2d_dgrad(ctx, stream, dtype, &sub, dys, w, bias, dxs, flags, ws, ws_bytes);
+        g_sub_batch = false;
         if (rcs) return rcs;
       }
       return 0;

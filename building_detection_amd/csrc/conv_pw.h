@@ -1,0 +1,520 @@
+// "Wide" pointwise GEMM on the bf16 matrix pipe: included by conv_igemm.hip after conv_x6.h (same namespace, IgemmParams).
+//
+//   Y[M][N] = A[M][K] . B[N][K]^T (+ bias, ReLU, BatchNormalization statistics)      1x1 convolution, stride 1, and its dgrad
+//
+// for the 728-wide middle flow of the Xception encoder (train_model/DeepLabv3plus.py:323-416: 16 x 3 SeparableConv2D(728),
+// M = 16 x 32 x 32 pixels): 50 layers x (forward + dgrad) = 100 of the ~330 GEMM launches of a training step and its
+// largest single share of time.  conv_x6_kernel covers that shape with 768 tiles of 128 x 128 in three rounds of one
+// workgroup per CU: every A element is gathered, split into its three bf16 planes and staged SIX times (once per column
+// tile), a wave's 64 x 32 sub-tile reads 0.75 LDS fragments per MFMA, and each round pays its own prologue and epilogue -
+// 140 TFLOP/s, a third of the bf16 pipe / 6.  Here ONE workgroup per CU owns a 128 x 384 tile (256 tiles = one round):
+//   * 8 waves as 2 (rows) x 4 (columns), 64 x 96 per wave: 15 fragment reads for 36 MFMAs per 16-deep k-step (0.42 / MFMA);
+//   * A is staged twice, not six times: a thread loads 4 fp32 per k-step, splits them (split3_pair) and writes 3 x 8 bytes;
+//   * the weight planes - already bf16, k-contiguous, prepared once per step - go from L2 to LDS by LDS-DMA
+//     (buffer_load ... lds, 16 bytes per lane), no registers, no ds_write; the XOR swizzle of the LDS image is applied to
+//     the per-lane SOURCE address (the DMA writes lane-linearly);
+//   * two 48 KB LDS stages, ONE barrier per k-step: while stage s is multiplied, the A planes of k-step s+1 are written
+//     and the DMA of its B planes is in flight; the wait before the barrier is counted (vmcnt(1): the fp32 load of k-step
+//     s+2 stays in flight across the barrier), raw s_barrier (a __syncthreads would drain the queue).
+// NPL = 1, TA = bf16_t (SG_BF16 storage): the same tile with 64-deep stages, BOTH operands by LDS-DMA, one MFMA per
+// fragment pair, the bf16 tile leaves through LDS as 16-byte row chunks.
+// Rounding order: a pixel's dot product is accumulated k-step by k-step in one fp32 accumulator whatever the batch:
+// batch-slice invariance and run-to-run determinism hold as for conv_x6_kernel (tests/test_fullsize_gpu.py).
+#pragma once
+
+constexpr int PW_BM = 128, PW_BN = 384;
+
+template <int NPL>
+struct PwGeom {
+  static constexpr int KS = NPL == 3 ? 1 : 4;      // 16-deep k-steps per stage
+  static constexpr int BKW = 16 * KS;              // reduction depth of a stage
+  static constexpr int RB = 2 * BKW;               // bytes of one LDS row (bf16)
+  static constexpr int CPR = RB / 16;              // 16-byte chunks per row
+  static constexpr int WSH = RB == 32 ? 3 : (RB == 64 ? 2 : 1);   // log2(rows per 256 bytes)
+  static constexpr int A_PLANE = PW_BM * RB, B_PLANE = PW_BN * RB;
+  static constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
+  // the 16 lanes of a ds_read_b128 group ({0-3,12-15,20-27} / {4-11,16-19,28-31} of 32 rows) hit 16 distinct 16-byte
+  // bank groups when chunk c of row r sits at slot c ^ swz(r)
+  __device__ static __forceinline__ int swz(int row) { return (row >> WSH) & (CPR - 1); }
+};
+
+__device__ __forceinline__ void pw_lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, char* lds_wave_base, unsigned voff, int soff) {
+  // 64 lanes x 16 bytes -> lds_wave_base + 16 * lane (the LDS address is wave-uniform: M0); out-of-range lanes write zeros
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)lds_wave_base, 16, (int)voff, soff, 0, 0);
+}
+
+template <int NPL, typename TA>
+__global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
+  static_assert((NPL == 3 && std::is_same<TA, float>::value) || (NPL == 1 && !std::is_same<TA, float>::value),
+                "x6 on fp32 storage, one plane on bf16 storage");
+  using G = PwGeom<NPL>;
+  constexpr int KS = G::KS, BKW = G::BKW, RB = G::RB, CPR = G::CPR;
+  constexpr int WGM = 2, WGN = 4, WM = 64, WN = 96, TM = 2, TN = 3;
+  constexpr unsigned OOB = 0x80000000u;
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages] x { A planes [NPL][128][RB], B planes [NPL][384][RB] }
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // in an SGPR: LDS-DMA bases and piece numbers are scalar arithmetic
+  const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t ntn = (p.Nout + PW_BN - 1) / PW_BN;
+  const uint32_t tile_m = bid / ntn, tile_n = bid - tile_m * ntn;   // the column tiles of a row tile are neighbours: A from L2
+  const int m0 = tile_m * PW_BM, n0 = tile_n * PW_BN;
+
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wq), 0, (int)p.w_bytes, 0x00020000);
+  const int nk = (p.K + BKW - 1) / BKW;
+
+  // ---- operand delivery ------------------------------------------------------------------------------------------------
+  // B: DMA pieces of 1 KB = (1024 / RB) rows of one plane; piece g -> plane g / PPP, rows (g % PPP) * RPP ...
+  constexpr int RPP = 1024 / RB;                  // rows per piece: 32 (x6) / 8 (bf16)
+  constexpr int PPP = PW_BN / RPP;                // pieces per B plane: 12 / 48
+  constexpr int NBP = NPL * PPP;                  // B pieces per stage: 36 / 48
+  constexpr int NBW = (NBP + 7) / 8;              // per wave: 5 (waves 0-3; 4 for waves 4-7) / 6
+  unsigned b_voff[NBW];
+#pragma unroll
+  for (int i = 0; i < NBW; ++i) {
+    const int g = wave + 8 * i;
+    const int pl = g / PPP, rb = g - pl * PPP;
+    const int row = rb * RPP + lane / CPR, slot = lane % CPR;
+    const int c = slot ^ G::swz(row);
+    const int n = n0 + row;
+    // k-block-major planes [pl][k block][Npad][BKW] (pw_planes_*): the 1 KB of a piece are contiguous in memory - eight full
+    // 128-byte lines.  (From row planes [n][k] a piece of 32 rows x 32 bytes touches 32 lines and uses a quarter of each.)
+    b_voff[i] = (g < NBP && n < p.Npad) ? (unsigned)((((pl * nk) * p.Npad + n) * BKW + 8 * c) * 2) : OOB;
+  }
+  const int b_step = p.Npad * BKW * 2;   // bytes from one k block to the next
+  auto issue_B = [&](int ks, int stage) {
+    char* base = smem + stage * G::STAGE + NPL * G::A_PLANE;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+      const int g = wave + 8 * i;
+      if (NBP % 8 == 0 || g < NBP) {   // wave-uniform
+        const int pl = g / PPP, rb = g - pl * PPP;
+        pw_lds_dma16(rsrc_w, base + pl * G::B_PLANE + rb * 1024, b_voff[i], ks * b_step);
+      }
+    }
+  };
+
+  // A, x6: thread -> row t / 4, floats 4 * (t % 4) .. + 3 of the k-step; one 16-byte load, split, three 8-byte LDS stores
+  // A, bf16: DMA pieces of 8 rows x 128 bytes, 16 pieces per stage, two per wave
+  const int a_row = t >> 2, a_kq = t & 3;
+  unsigned a_voff = OOB;
+  unsigned a16_voff[2] = {OOB, OOB};
+  if constexpr (NPL == 3) {
+    if (m0 + a_row < p.M) a_voff = (unsigned)(((m0 + a_row) * p.x_ld + 4 * a_kq) * 4);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int g = wave + 8 * i;
+      const int row = g * RPP + lane / CPR, slot = lane % CPR;
+      const int c = slot ^ G::swz(row);
+      if (m0 + row < p.M) a16_voff[i] = (unsigned)(((m0 + row) * p.x_ld + 8 * c) * 2);
+    }
+  }
+  const bool ktail = (p.K % BKW) != 0;
+  u32x4_t ra = {0u, 0u, 0u, 0u};
+  auto load_A = [&](int ks) {   // x6: registers
+    ra = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff, ks * BKW * 4, 0);
+  };
+  auto store_A = [&](int stage) {
+    const f32x4 f = __builtin_bit_cast(f32x4, ra);
+    unsigned h0, m0_, l0, h1, m1, l1;
+    split3_pair(f[0], f[1], h0, m0_, l0);
+    split3_pair(f[2], f[3], h1, m1, l1);
+    char* dst = smem + stage * G::STAGE + a_row * RB + (((a_kq >> 1) ^ G::swz(a_row)) << 4) + (a_kq & 1) * 8;
+    *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){h0, h1};
+    *reinterpret_cast<u32x2_t*>(dst + G::A_PLANE) = (u32x2_t){m0_, m1};
+    *reinterpret_cast<u32x2_t*>(dst + 2 * G::A_PLANE) = (u32x2_t){l0, l1};
+  };
+  auto issue_A16 = [&](int ks, int stage) {   // bf16: DMA; chunks past K (a ragged last stage) are written as zeros
+    char* base = smem + stage * G::STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int g = wave + 8 * i;
+      const int row = g * RPP + lane / CPR, slot = lane % CPR;
+      const int c = slot ^ G::swz(row);
+      const bool kv = !ktail || (ks * BKW + 8 * c < p.K);
+      pw_lds_dma16(rsrc_x, base + g * 1024, kv ? a16_voff[i] : OOB, ks * BKW * 2);
+    }
+  };
+
+  // ---- MFMA side ---------------------------------------------------------------------------------------------------------
+  const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int sw = G::swz(lr);   // wm, wn and the 32-row sub-tile offsets are multiples of 32: the swizzle depends on lr only
+  const int a_lane = (wm + lr) * RB, b_lane = NPL * G::A_PLANE + (wn + lr) * RB;
+
+  auto compute = [&](int stage, bool no_mfma = false) {
+    const char* sb = smem + stage * G::STAGE;
+    if constexpr (NPL == 3) {
+      const int ko = (lh ^ sw) << 4;
+      bf16x8_t af[TM][3], bf[TN][3];
+      // reads in the order the MFMAs consume them
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8_t*>(sb + a_lane + pl * G::A_PLANE + ko);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          bf[j][pl] = *reinterpret_cast<const bf16x8_t*>(sb + b_lane + pl * G::B_PLANE + 32 * j * RB + ko);
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) af[1][pl] = *reinterpret_cast<const bf16x8_t*>(sb + a_lane + pl * G::A_PLANE + 32 * RB + ko);
+      if (no_mfma) {   // timing ablation: the reads are kept alive, nothing is multiplied
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          asm volatile("" ::"v"(af[0][pl]), "v"(af[1][pl]));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(bf[j][pl]));
+        }
+        return;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          // smallest terms first (conv_x6_kernel's order)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+        }
+    } else {
+      bf16x8_t af[2][TM], bf[2][TN];
+      auto frags = [&](int ks, bf16x8_t (&a)[TM], bf16x8_t (&b)[TN]) {
+        const int ko = ((2 * ks + lh) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sb + a_lane + 32 * i * RB + ko);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + b_lane + 32 * j * RB + ko);
+      };
+      frags(0, af[0], bf[0]);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) frags(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);   // one k-step of look-ahead
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
+  // ---- x6: one k-step with the staging of the next stage woven between its MFMAs, one small piece per MFMA, every piece
+  // fenced (sched_barrier) so that the stream is exactly: fragment reads, then MFMA / piece / MFMA / piece ...  An MFMA holds
+  // the vector issue for 8 of its 32 cycles; the rest of the gap takes the piece (conv_x6_kernel's fused_step, measured there:
+  // left to itself the scheduler runs the phases back to back).  MODE 2: everything; 1: no fp32 load (last but one k-step);
+  // 0: multiply only (last k-step).
+  auto step3 = [&](int s, auto MODE_) {
+    constexpr int MODE = decltype(MODE_)::value;
+    const int cur = s & 1, nxt = cur ^ 1;
+    const char* sb = smem + cur * G::STAGE;
+    const int ko = (lh ^ sw) << 4;
+    bf16x8_t af[TM][3], bf[TN][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) af[0][pl] = *reinterpret_cast<const bf16x8_t*>(sb + a_lane + pl * G::A_PLANE + ko);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8_t*>(sb + b_lane + pl * G::B_PLANE + 32 * j * RB + ko);
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) af[1][pl] = *reinterpret_cast<const bf16x8_t*>(sb + a_lane + pl * G::A_PLANE + 32 * RB + ko);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned hh[2], mm[2], ll[2];
+    char* adst = smem + nxt * G::STAGE + a_row * RB + (((a_kq >> 1) ^ G::swz(a_row)) << 4) + (a_kq & 1) * 8;
+    char* bbase = smem + nxt * G::STAGE + NPL * G::A_PLANE;
+    auto piece = [&](int w) {
+      if (MODE == 0) return;
+      if (w < 2) {
+        const f32x4 f = __builtin_bit_cast(f32x4, ra);
+        split3_pair(f[2 * w], f[2 * w + 1], hh[w], mm[w], ll[w]);
+      } else if (w == 2) {
+        *reinterpret_cast<u32x2_t*>(adst) = (u32x2_t){hh[0], hh[1]};
+      } else if (w == 3) {
+        *reinterpret_cast<u32x2_t*>(adst + G::A_PLANE) = (u32x2_t){mm[0], mm[1]};
+      } else if (w == 4) {
+        *reinterpret_cast<u32x2_t*>(adst + 2 * G::A_PLANE) = (u32x2_t){ll[0], ll[1]};
+      } else if (w < 5 + NBW) {
+        const int i = w - 5, g = wave + 8 * i;
+        if (i < NBW - 1 || NBP % 8 == 0 || g < NBP) {   // only the last round of pieces is ragged (36 pieces, 8 waves)
+          const int pl = g / PPP, rb = g - pl * PPP;
+          pw_lds_dma16(rsrc_w, bbase + pl * G::B_PLANE + rb * 1024, b_voff[i], (s + 1) * b_step);
+        }
+      } else if (w == 5 + NBW) {
+        if (MODE == 2) ra = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff, (s + 2) * BKW * 4, 0);
+      }
+    };
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first (conv_x6_kernel's order)
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA_[u]], bf[j][PB_[u]], acc[i][j], 0, 0, 0);
+          piece(q);
+          ++q;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    // B(s+1) is older than A(s+2) in the queue: vmcnt(1) retires it and leaves the fp32 load in flight across the barrier
+    if (MODE == 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  };
+
+  // ---- the k loop: one barrier per stage -------------------------------------------------------------------------------------
+  // p.ablate (SG_PW_ABLATE; timing-only diagnostics, results wrong): 1 = no A path (load, split, LDS store), 2 = no B DMA,
+  // 4 = no MFMAs (the fragment reads stay), 8 = no fragment reads and no MFMAs, 16 = no barrier
+  const bool ab_a = (p.ablate & 1) != 0, ab_b = (p.ablate & 2) != 0, ab_mm = (p.ablate & 4) != 0, ab_rd = (p.ablate & 8) != 0;
+  const bool ab_bar = (p.ablate & 16) != 0;
+  if (nk > 0) {
+    if constexpr (NPL == 3) {
+      load_A(0);
+      issue_B(0, 0);
+      store_A(0);                    // (the compiler waits for ra here)
+      if (nk > 1) load_A(1);
+      asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // B(0) has landed; A(1) may still fly
+      if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (p.ablate == 0) {           // the woven step (the plain loop below serves the timing ablations)
+        int s = 0;
+        for (; s + 2 < nk; ++s) step3(s, IC<2>{});
+        if (s + 1 < nk) { step3(s, IC<1>{}); ++s; }
+        step3(s, IC<0>{});
+      } else
+      for (int s = 0; s < nk; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < nk) {            // uniform
+          if (!ab_a) store_A(nxt);   // A(s+1): loaded during the previous k-step
+          __builtin_amdgcn_sched_barrier(0);
+          if (!ab_b) issue_B(s + 1, nxt);       // stage nxt was last read before the previous barrier
+          if (s + 2 < nk && !ab_a) load_A(s + 2);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (!ab_rd) compute(cur, ab_mm);
+        __builtin_amdgcn_sched_barrier(0);
+        // B(s+1) is older than A(s+2) in the queue: vmcnt(1) retires it and leaves the fp32 load in flight
+        if (s + 2 < nk && !ab_a) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!ab_bar) __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      issue_A16(0, 0);
+      issue_B(0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      for (int s = 0; s < nk; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        if (s + 1 < nk) {
+          issue_A16(s + 1, nxt);
+          issue_B(s + 1, nxt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        compute(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------------------------
+  const bool has_bias = (p.flags & SG_EPI_BIAS) != 0;
+  const bool do_relu = (p.flags & SG_EPI_RELU) != 0;
+  if constexpr (NPL == 3) {
+    // Branch-free stores through a buffer descriptor: a lane outside the tensor (column >= Nout, row >= M) carries an
+    // out-of-range offset and the hardware drops its store.  (A per-store `if` is a basic block of its own, and across
+    // block boundaries the compiler's wait insertion falls back to vmcnt(0): 96 stores, each waiting for the one before.)
+    const uint32_t y_bytes = (uint32_t)((((int64_t)p.M - 1) * p.y_ld + p.Nout) * 4);   // < 2^31: pw_wide_ok
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, (int)y_bytes, 0x00020000);
+    const bool full = m0 + PW_BM <= p.M;   // uniform: no row of this tile is past the end
+    const unsigned row0 = (unsigned)(m0 + wm + 4 * lh);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn + 32 * j + lr;
+      const bool cv = col < p.Nout;
+      const float bv = has_bias ? p.bias[cv ? col : p.Nout - 1] : 0.f;
+      const unsigned cterm = cv ? (unsigned)col * 4u : OOB;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+          float v = acc[i][j][r] + bv;
+          v = do_relu ? fmaxf(v, 0.f) : v;
+          unsigned voff = cterm + row * (unsigned)p.y_ld * 4u;
+          if (!full) voff = row < (unsigned)p.M ? voff : OOB;
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_y, (int)voff, 0, 0);
+        }
+    }
+  } else {
+    // the bf16 tile goes through LDS so that it leaves as 16-byte row chunks (conv_b16_kernel's epilogue)
+    bf16_t* __restrict__ py = reinterpret_cast<bf16_t*>(p.y);
+    constexpr int TP = PW_BN * 2 + 16;
+    const bool wide = (p.y_ld % 8 == 0) && (p.Nout % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+    if (wide) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cl = wn + 32 * j + lr;
+        const int col = n0 + cl;
+        const float bv = (has_bias && col < p.Nout) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            float v = acc[i][j][r] + bv;
+            if (do_relu) v = fmaxf(v, 0.f);
+            *reinterpret_cast<unsigned short*>(smem + rl * TP + cl * 2) = f32_to_bf16_bits(v);
+          }
+      }
+      __syncthreads();
+      constexpr int CPT = PW_BN / 8;
+      for (int idx = t; idx < PW_BM * CPT; idx += 512) {
+        const int rl = idx / CPT, c = idx - rl * CPT;
+        const int row = m0 + rl, col = n0 + 8 * c;
+        if (row < p.M && col < p.Nout)
+          *reinterpret_cast<u32x4_t*>(py + (int64_t)row * p.y_ld + col) = *reinterpret_cast<const u32x4_t*>(smem + rl * TP + c * 16);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int col = n0 + wn + 32 * j + lr;
+        const bool cv = col < p.Nout;
+        const float bv = (has_bias && cv) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (cv && row < p.M) {
+              float v = acc[i][j][r] + bv;
+              if (do_relu) v = fmaxf(v, 0.f);
+              st1<bf16_t>(py + (int64_t)row * p.y_ld + col, v);
+            }
+          }
+      }
+    }
+  }
+
+  // ---- BatchNormalization statistics of this 128-row tile (conv_x6_kernel's scheme and layout: stats[tile_m][2][Nout]) ---------
+  if (p.stats) {
+    float* red = reinterpret_cast<float*>(smem);   // [WGM][PW_BN] partials, then [PW_BN] tile means
+    float* tmean = red + WGM * PW_BN;
+    const int wrow = wave / WGN;
+    const int nvalid = (p.M - m0) < PW_BM ? (p.M - m0) : PW_BM;
+    __syncthreads();   // every wave is done with the stage buffers / the staged output tile
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cl = wn + 32 * j + lr;
+        const int col = n0 + cl;
+        const float bv = (has_bias && col < p.Nout) ? p.bias[col] : 0.f;
+        const float mu = pass ? tmean[cl] : 0.f;
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float dlt = acc[i][j][r] + bv - mu;
+            if (row < p.M) sacc += pass ? dlt * dlt : dlt;
+          }
+        sacc += __shfl_xor(sacc, 32, 64);   // lanes l and l + 32 hold the same column
+        if (lh == 0) red[wrow * PW_BN + cl] = sacc;
+      }
+      __syncthreads();
+      for (int cl = t; cl < PW_BN; cl += 512) {
+        float tot = 0.f;
+#pragma unroll
+        for (int wq = 0; wq < WGM; ++wq) tot += red[wq * PW_BN + cl];
+        const int col = n0 + cl;
+        if (pass == 0) tmean[cl] = tot / (float)nvalid;
+        if (col < p.Nout) p.stats[((int64_t)tile_m * 2 + pass) * p.Nout + col] = tot;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <int NPL, typename TA>
+int launch_pw_wide(const IgemmParams& p, hipStream_t st) {
+  using G = PwGeom<NPL>;
+  constexpr size_t stage_lds = 2 * (size_t)G::STAGE;
+  constexpr size_t tile_lds = NPL == 1 ? (size_t)PW_BM * (PW_BN * 2 + 16) : 0;
+  constexpr size_t stat_lds = (size_t)3 * PW_BN * sizeof(float);
+  constexpr size_t m1 = stage_lds > tile_lds ? stage_lds : tile_lds;
+  constexpr size_t lds = m1 > stat_lds ? m1 : stat_lds;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = set_dyn_lds(pw_wide_kernel<NPL, TA>, lds);
+    if (rc) return rc;
+    attr_done = true;
+  }
+  const int64_t tiles = sg_cdiv(p.M, PW_BM) * sg_cdiv(p.Nout, PW_BN);
+  if (tiles <= 0 || tiles > 0x7fffffff) {
+    sg_set_error("pw_wide: bad tile count %lld", (long long)tiles);
+    return SG_EINVAL;
+  }
+  if (p.x_bytes == 0 || (((int64_t)p.M - 1) * p.y_ld + p.Nout) * (int64_t)EL<TA>::BYTES >= (1ll << 31)) {
+    sg_set_error("pw_wide: an operand of %lld rows does not fit one 2 GiB buffer descriptor", (long long)p.M);
+    return SG_EINVAL;
+  }
+  IgemmParams q = p;
+  {
+    static int abl = -1;
+    if (abl < 0) abl = getenv("SG_PW_ABLATE") ? atoi(getenv("SG_PW_ABLATE")) : 0;
+    q.ablate = abl;
+  }
+  hipLaunchKernelGGL((pw_wide_kernel<NPL, TA>), dim3((unsigned)tiles), dim3(512), lds, st, q);
+  SG_LAUNCH_CHECK("pw_wide_kernel");
+  return 0;
+}
+
+// ---- weight planes of the wide kernel: k-block-major [npl][K blocks][Npad][KD] bf16, KD = 16 (x6) / 64 (bf16 storage), Npad a
+// multiple of 384, zero padded; sg_planes_job kind 3 (Ckp carries KD) / split3_weights_kernel(kd) ---------------------------
+inline int pw_kd(int npl) { return npl == 3 ? 16 : 64; }
+inline int pw_kpad(int K, int npl) { return (int)(sg_cdiv(K, pw_kd(npl)) * pw_kd(npl)); }
+inline int pw_npad(int N) { return (int)(sg_cdiv(N, PW_BN) * PW_BN); }
+inline size_t pw_planes_bytes(int K, int N, int npl) { return (size_t)npl * pw_kpad(K, npl) * pw_npad(N) * 2; }
+
+// Shapes the wide kernel takes: one tap (1x1), stride 1, no gather; a reduction deep enough to amortise the 128 x 384 tile's
+// prologue; a column count whose last 384-wide tile is at least three quarters full (728 -> 2 tiles, 1024 -> 3, 1536 -> 4,
+// 2048 -> 6; 256 stays on the 128-wide tiles); at least 6144 rows - 96 workgroups: below that the 128-wide tiles spread the
+// work over more CUs and win (profiles/r03_pw_wide_mscan.txt: 4096 rows 72 vs 47 us, 6144 rows 75 vs 78 us); operands 16-byte
+// aligned.  The weight planes are laid out for one kernel or the other when they are prepared (sg_conv2d_planes_job, which
+// knows the batch), so the same rule must give the same answer at the launch: it reads nothing but the descriptor, and a
+// launch cut into sub-batches (g_sub_batch) never takes the wide kernel.  Both kernels add the same products in the same
+// order (16-deep k-steps ascending, the six x6 terms smallest first, one fp32 accumulator), so a tile's result does not
+// depend on which of them its batch size selected (tests/test_fullsize_gpu.py: batch-slice invariance, bit exact).
+// SG_PW_WIDE=0 switches it off, 2 takes every aligned 1x1 (tests).
+inline bool pw_wide_ok(const IgemmParams& p, int eb) {
+  static int on = -1;
+  if (on < 0) on = getenv("SG_PW_WIDE") ? atoi(getenv("SG_PW_WIDE")) : 1;
+  if (!on) return false;
+  if (p.K != p.C || p.a_mul != 1 || p.div != 1 || p.off_h != 0 || p.off_w != 0) return false;
+  // (both activation tensors of a launch are below 2 GiB by construction: larger batches run as sub-batches of whole images,
+  // images_per_2gib; launch_pw_wide re-checks)
+  if (eb == 2 && (p.K % 8 != 0 || p.x_ld % 8 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0)) return false;
+  if (eb == 4 && (p.x_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0)) return false;
+  if (g_sub_batch) return false;
+  if (on == 2) return true;
+  if (p.K < 256 || p.M < 6144) return false;
+  const int64_t ntn = sg_cdiv(p.Nout, PW_BN);
+  return (double)p.Nout / (double)(ntn * PW_BN) >= 0.75;
+}

@@ -52,9 +52,10 @@ __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, uns
 // npl = 1 writes the bf16 rounding alone (the bf16 paths: one MFMA pass).  Ckp >= Ck is the per-tap depth of the k
 // index: with Ckp > Ck every tap is zero-padded to Ckp channels ("virtual channel padding": the kernel then walks
 // whole 32-deep slabs inside one tap for any channel count and multiplies the surplus A columns by these zeros).
+// kd > 0: k-block-major planes [npl][Kpad / kd][Npad][kd] (the wide pointwise kernel, conv_pw.h) instead of rows [Npad][Kpad].
 __global__ __launch_bounds__(256) void split3_weights_kernel(const float* __restrict__ w, unsigned short* __restrict__ planes,
                                                              int K, int N, int Kpad, int Npad, int Ck, int s_tap, int s_k,
-                                                             int s_n, int npl, int Ckp) {
+                                                             int s_n, int npl, int Ckp, int kd = 0) {
   __shared__ float tile[32][33];
   const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -72,11 +73,12 @@ __global__ __launch_bounds__(256) void split3_weights_kernel(const float* __rest
   __syncthreads();
   const int64_t plane = (int64_t)Npad * Kpad;
   for (int i = ty; i < 32; i += 8) {
-    const int n = n0 + i, k = k0 + tx;  // always inside the padded planes (Kpad, Npad are multiples of 32)
+    const int n = n0 + i, k = k0 + tx;  // inside the padded planes (Kpad, Npad multiples of 32) unless kd says otherwise
+    if (kd > 0 && (k >= Kpad || n >= Npad)) continue;
     const float x = tile[tx][i];
     unsigned h, m, l;
     split3_pair(x, 0.f, h, m, l);
-    const int64_t o = (int64_t)n * Kpad + k;
+    const int64_t o = kd > 0 ? ((int64_t)(k / kd) * Npad + n) * kd + (k % kd) : (int64_t)n * Kpad + k;
     planes[o] = (unsigned short)(h & 0xffffu);
     if (npl == 3) {
       planes[plane + o] = (unsigned short)(m & 0xffffu);

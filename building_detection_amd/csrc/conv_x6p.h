@@ -77,8 +77,9 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(const float* __rest
   if (lb >= j.nblocks) return;
   const float* __restrict__ w = w_arena + j.w_off;
   unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(planes_arena + j.out_off);
-  if (j.kind == 1) {  // row planes [npl][Npad][Kpad]
-    const int gx = j.Kpad / 32;
+  if (j.kind == 1 || j.kind == 3) {  // row planes [npl][Npad][Kpad]; kind 3: k-block-major [npl][Kpad / KD][Npad][KD], KD = Ckp
+    const int kd = j.kind == 3 ? j.Ckp : 0;
+    const int gx = (j.Kpad + 31) / 32;
     const int k0 = (lb % gx) * 32, n0 = (lb / gx) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8) {
@@ -86,7 +87,8 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(const float* __rest
       const int k = k0 + ky, n = n0 + nx;
       float v = 0.f;
       if (k < j.K && n < j.N) {
-        const int tap = k / j.Ckp, kk = k - tap * j.Ckp;
+        const int ckp = kd ? j.K : j.Ckp;   // kind 3 is one tap
+        const int tap = k / ckp, kk = k - tap * ckp;
         if (kk < j.Ck) v = w[(int64_t)tap * j.s_tap + (int64_t)kk * j.s_k + (int64_t)n * j.s_n];
       }
       tile[ky][nx] = v;
@@ -95,9 +97,10 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(const float* __rest
     const int64_t plane = (int64_t)j.Npad * j.Kpad;
     for (int i = ty; i < 32; i += 8) {
       const int n = n0 + i, k = k0 + tx;
+      if (kd && (k >= j.Kpad || n >= j.Npad)) continue;
       unsigned h, m, l;
       split3_pair(tile[tx][i], 0.f, h, m, l);
-      const int64_t o = (int64_t)n * j.Kpad + k;
+      const int64_t o = kd ? ((int64_t)(k / kd) * j.Npad + n) * kd + (k % kd) : (int64_t)n * j.Kpad + k;
       out[o] = (unsigned short)(h & 0xffffu);
       if (j.npl == 3) {
         out[plane + o] = (unsigned short)(m & 0xffffu);

@@ -191,7 +191,8 @@ int sg_dense_fwd(sg_ctx* ctx, void* stream, int dtype, int rows, int in, int out
 #define SG_WS_PREPARED ((size_t)-1)
 typedef struct sg_planes_job {
   int64_t w_off, out_off;
-  int32_t kind; /* 0 none, 1 row planes [npl][Npad][Kpad], 2 fragment-major (patch kernel) */
+  int32_t kind; /* 0 none, 1 row planes [npl][Npad][Kpad], 2 fragment-major (patch kernel), 3 k-block-major
+                 * [npl][Kpad / Ckp][Npad][Ckp] (wide pointwise kernel: Ckp = 16 or 64 is the k-block depth) */
   int32_t K, N, Kpad, Npad, Ck, Ckp, s_tap, s_k, s_n, npl;
   int32_t block0, nblocks;
 } sg_planes_job;

@@ -24,12 +24,13 @@ from building_detection_amd.ops import get_engine  # noqa: E402
 def groups_of(model):
     """trainable-parameter index -> group name, from the creation order of zoo.deeplab.Xception_DeepLabV3_Plus."""
     order = [n for n in model.nodes if n.params]
-    names = [n.name for n in order]
-
-    def pos(nm):
-        return names.index(nm)
-    cuts = [("entry", 0), ("middle", pos("separable_conv2d_8")), ("exit", pos("conv2d_5")), ("sk", pos("conv2d_6")),
-            ("aspp", pos("conv2d_18")), ("neck", pos("conv2d_23")), ("decoder", pos("conv2d_29"))]
+    convs = [i for i, n in enumerate(order) if n.op == "conv2d"]             # k-th Conv2D / SeparableConv2D created, whatever
+    seps = [i for i, n in enumerate(order) if n.op == "separable_conv2d"]    # uid offset the layer names carry
+    assert len(seps) == 62 and len(convs) >= 47, (len(seps), len(convs))
+    # separable 8 opens the middle flow; Conv2D 5 is the exit flow's shortcut, 6-17 the SK block, 18-22 ASPP, 23-28 the neck
+    # (1x1, two 3x3, scSE), 29.. the decoder
+    cuts = [("entry", 0), ("middle", seps[8]), ("exit", convs[5]), ("sk", convs[6]), ("aspp", convs[18]), ("neck", convs[23]),
+            ("decoder", convs[29])]
     out = []
     for i, n in enumerate(order):
         g = [c[0] for c in cuts if c[1] <= i][-1]

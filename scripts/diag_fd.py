@@ -44,6 +44,25 @@ for policy in ("float32", "mixed_bfloat16"):
         return val
 
     print(f"{policy}: loss {float(loss.item()):.6f}  <g,d> = {gd:.5e}", flush=True)
+    # per layer group: the same direction restricted to the group's parameters (h = 3e-5 and 1.5e-5, extrapolated to 0)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dg", os.path.join(os.path.dirname(os.path.abspath(__file__)), "diag_bf16_groups.py"))
+    dg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dg)
+    grp = dg.groups_of(m)
+    tr = [q for q in m.params if q.trainable]
+    for gname in dict.fromkeys(grp):
+        mask = torch.zeros_like(w0)
+        for q, gq in zip(tr, grp):
+            if gq == gname:
+                mask[q.offset:q.offset + q.size] = 1.0
+        dgm = d * mask
+        gdg = float((g.double() * dgm.double()).sum().item())
+        f = []
+        for h in (3e-5, 1.5e-5):
+            f.append((loss_at(w0 + h * dgm) - loss_at(w0 - h * dgm)) / (2 * h))
+        f0 = f[1] + (f[1] - f[0])
+        print(f"   group {gname:8s}: <g,d_g> {gdg:.4e}  fd(3e-5) {f[0]:.4e} fd(1.5e-5) {f[1]:.4e} -> h=0 {f0:.4e}  ratio {f0 / gdg:.4f}", flush=True)
     for h in (1.6e-2, 8e-3, 4e-3, 2e-3, 1e-3, 5e-4, 2.5e-4, 1.25e-4, 6e-5, 3e-5, 1.5e-5):
         lp, lm = loss_at(w0 + h * d), loss_at(w0 - h * d)
         print(f"   h {h:8.2e}: L+ {lp:.7f} L- {lm:.7f}  fd {(lp - lm) / (2 * h):.5e}  ratio to <g,d> {(lp - lm) / (2 * h) / gd:.4f}", flush=True)

@@ -51,6 +51,56 @@ def test_config1_res34_256_bs2_train_step_vs_oracle(engine):
 FULL = [("v3plus", "deeplab_v3plus"), ("scse", "scse_unet"), ("bam", "deeplab_v3plus_bam")]
 
 
+def _diag_groups():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("diag_groups", os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts",
+                                                                               "diag_bf16_groups.py"))
+    dg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(dg)
+    return dg
+
+
+def _param_groups(model, name):
+    """trainable parameter -> group label: DeepLabv3+'s blocks (scripts/diag_bf16_groups.py), else quarters of the list."""
+    tr = [p for p in model.params if p.trainable]
+    if name == "v3plus":
+        return _diag_groups().groups_of(model)
+    return ["q%d" % (1 + 4 * i // len(tr)) for i in range(len(tr))]
+
+
+def _group_directional_derivatives(model, grp, d, g, w0, f0, xd, yd, hs=(3e-5, 1.5e-5)):
+    """Per parameter group: central differences of the training-mode loss along `d` restricted to the group (two steps,
+    extrapolated linearly to h = 0) over <g, d_group>.  1.0 = that group's backward is the gradient of the forward."""
+    rt = model._runtime()
+    tr = [p for p in model.params if p.trainable]
+
+    def loss_at(w):
+        rt.w_train.copy_(w)
+        rt.weights_changed()
+        rt.w_frozen.copy_(f0)
+        pr = rt.forward(xd, training=True)
+        val = float(rt.eng.loss_fwd(model.loss_kind, pr, yd).item())
+        rt.release()
+        return val
+
+    out = {}
+    for gname in dict.fromkeys(grp):
+        mask = torch.zeros_like(w0)
+        for p_, q in zip(tr, grp):
+            if q == gname:
+                mask[p_.offset:p_.offset + p_.size] = 1.0
+        dgm = d * mask
+        gd = float((g.double() * dgm.double()).sum().item())
+        f = [(loss_at(w0 + h * dgm) - loss_at(w0 - h * dgm)) / (2 * h) for h in hs]
+        f0_ = f[1] + (f[1] - f[0]) * hs[1] / (hs[0] - hs[1])
+        out[gname] = f0_ / gd if gd != 0.0 else float("nan")
+    rt.w_train.copy_(w0)
+    rt.weights_changed()
+    rt.w_frozen.copy_(f0)
+    return out
+
+
 @pytest.mark.parametrize("name,oracle_fn", FULL, ids=[f[0] for f in FULL])
 def test_full_size_512_bs16(engine, name, oracle_fn):
     from building_detection_amd import zoo
@@ -122,6 +172,12 @@ def test_full_size_512_bs16(engine, name, oracle_fn):
     print(f"{name} 512x512 bs16: loss {l1:.6f}; directional derivative fd(h=4e-4, 1e-4, 2.5e-5) = "
           f"{fds[0]:.5e}, {fds[1]:.5e}, {fds[2]:.5e} -> h=0: {fd0:.5e} vs <g,d> {gd:.5e}")
     assert abs(fd0 - gd) <= 0.05 * max(abs(gd), abs(fd0)) + 1e-6, (fds, fd0, gd)
+    # (e) the same per parameter group, at steps small enough to resolve it (round 3): every block's backward is the
+    # gradient of the forward on its own - measured 0.9965 ... 1.0006 on DeepLabv3+ (profiles/r03_diag_fd_512.txt)
+    ratios = _group_directional_derivatives(model, _param_groups(model, name), d, g1, w0, f0, xd, yd)
+    print(f"{name} 512x512 bs16: fd / <g,d> per parameter group: " + "  ".join(f"{k} {v:.4f}" for k, v in ratios.items()))
+    for k, v in ratios.items():
+        assert abs(v - 1.0) <= 0.02, (name, k, v)
     del g1, g2, d, w0, f0
     torch.cuda.empty_cache()
 
@@ -193,30 +249,18 @@ def test_config3_deeplab_bf16_512_bs16(engine):
     assert l1 == l2 and torch.equal(g1, g2), "the bf16 training step is not run-to-run deterministic"
     del g2
 
-    # (d)
+    # (d) per parameter group, as for fp32 (same direction, same steps: the fp32 loss has so much curvature along a direction
+    # signed with the gradient that only steps <= 3e-5 resolve it, and the bf16 forward answers such steps without bias -
+    # 64 M weights cross their bf16 rounding boundaries in proportion; profiles/r03_diag_fd_512.txt).  What the ratio shows
+    # in bf16 is how well <g, d> - d is signed with the bf16 gradient's own signs - predicts the real change of the loss:
+    # 1 where the gradient is accurate (decoder), lower where the bf16 gradient is noisy at random init (encoder: (e) below).
     gen = torch.Generator(device="cpu").manual_seed(7)
     d = torch.randn(w0.numel(), generator=gen).abs().cuda()
     d *= (w0.abs() + 1e-3) * torch.sign(g1)
-    gd = float((g1.double() * d.double()).sum().item())
-
-    def loss_at(w):
-        rt.w_train.copy_(w)
-        rt.weights_changed()
-        rt.w_frozen.copy_(f0)
-        pr = rt.forward(xd, training=True)
-        val = float(rt.eng.loss_fwd(model.loss_kind, pr, yd).item())
-        rt.release()
-        return val
-
-    hs = (1.6e-2, 8e-3, 4e-3)
-    fds = [(loss_at(w0 + h * d) - loss_at(w0 - h * d)) / (2 * h) for h in hs]
-    rt.w_train.copy_(w0)
-    rt.weights_changed()
-    rt.w_frozen.copy_(f0)
-    fd0 = fds[2] + (fds[2] - fds[1]) * hs[2] / (hs[1] - hs[2])
-    print(f"config 3 bf16 512x512 bs16: loss {l1:.6f}; directional derivative fd(h=1.6e-2, 8e-3, 4e-3) = "
-          f"{fds[0]:.5e}, {fds[1]:.5e}, {fds[2]:.5e} -> h=0: {fd0:.5e} vs <g,d> {gd:.5e}")
-    assert abs(fd0 - gd) <= 0.10 * max(abs(gd), abs(fd0)) + 1e-6, (fds, fd0, gd)
+    ratios = _group_directional_derivatives(model, _param_groups(model, "v3plus"), d, g1, w0, f0, xd, yd)
+    print("config 3 bf16 512x512 bs16: fd / <g,d> per parameter group: " + "  ".join(f"{k} {v:.4f}" for k, v in ratios.items()))
+    for k, v in ratios.items():
+        assert GROUP_FD[k][0] <= v <= GROUP_FD[k][1], (k, v)
     del g1, d, w0, f0
     torch.cuda.empty_cache()
 
@@ -272,6 +316,10 @@ def test_config3_deeplab_bf16_512_bs16(engine):
 # 1.0000 (at random init: 0.51 / 0.51 / 0.62 / 0.66 / 0.68 / 0.76 / 0.998); the kernels are deterministic, so the
 # head-room only has to cover later changes of summation order.
 GROUP_COS = {"entry": 0.75, "middle": 0.78, "exit": 0.94, "sk": 0.94, "aspp": 0.95, "neck": 0.99, "decoder": 0.9995}
+# accepted range of (finite difference of the bf16 loss) / <g_bf16, d> per group at RANDOM INIT (part (d)); fp32 gives 1.00
+# everywhere.  To be set from the first measured run.
+GROUP_FD = {"entry": (0.2, 1.3), "middle": (0.2, 1.3), "exit": (0.2, 1.3), "sk": (0.2, 1.3), "aspp": (0.2, 1.3),
+            "neck": (0.3, 1.3), "decoder": (0.9, 1.1)}
 
 
 # Convolution kernels at the BASELINE sizes through identities that hold for any size: forward, dgrad and wgrad are the
