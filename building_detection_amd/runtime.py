@@ -440,6 +440,26 @@ class Model:
         return self.fit_generator(gen(), steps_per_epoch=steps, epochs=epochs, **kw)
 
 
+class _CaptureGuard:
+    """Around a stream capture: Python's cyclic garbage collector must not run inside it.  A collection can finalise an
+    unrelated hipGraph (e.g. the captured step of a model dropped earlier, kept alive until now by a reference cycle), and
+    destroying a graph while a stream is capturing is a HIP error that ends the process (hipErrorStreamCaptureUnsupported
+    thrown from a destructor).  Collect first, then keep the collector off until the capture has ended."""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._was = gc.isenabled()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        if self._was:
+            gc.enable()
+        return False
+
+
 class GraphedPredict:
     """Static-shape inference forward captured into a hipGraph (stream capture of the engine's launches)."""
 
@@ -462,7 +482,7 @@ class GraphedPredict:
             # the engine-wide peak stays monotone: a training-step capture that follows sizes its buffer by it
             eng._ws_peak = max(eng._ws_peak, peak_before)
             self.graph = torch.cuda.CUDAGraph()
-            with eng.private_ws(self.ws):
+            with eng.private_ws(self.ws), _CaptureGuard():
                 with torch.cuda.graph(self.graph):
                     self.y = rt.forward(self.x, training=False)
             rt.values = {}
@@ -543,7 +563,7 @@ class GraphedTrainStep:
                     begin()
 
         saved_hook = rt.on_node_done
-        with eng.private_ws(self.ws):
+        with eng.private_ws(self.ws), _CaptureGuard():
             try:
                 rt.on_node_done = node_done if dist is not None else None
                 begin()
