@@ -318,14 +318,17 @@ def main():
                       "exact 3-way bf16 split); the native fp32 MFMA peak is 157.3 TFLOP/s") if x6 else "fp32 MFMA 32x32x2 dense peak")
         # fabric-side bytes of the same kernel set per step, from the committed PMC passes (separate rocprofv3
         # --pmc runs of scripts/dilated_bench.py at this very configuration; scripts/pmc_traffic.py)
-        traffic, traffic_note = None, "PMC passes exist for the 512x512 bs16 configuration only"
-        tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_pmc_traffic.json")
-        if args.batch == 16 and args.size == 512 and os.path.exists(tj) and not b16:
+        traffic, traffic_note = None, "PMC passes exist for the 512x512 bs16 fp32 configuration only"
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        tj = next((os.path.join(pdir, n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n))), None)
+        if args.batch == 16 and args.size == 512 and tj and not b16:
             with open(tj) as f:
                 tr = json.load(f)
             traffic = int(tr["set_bytes_per_step"])
-            traffic_note = ("bytes per step of the kernel set, L2-miss side (FETCH_SIZE x2 + WRITE_SIZE, Infinity-Cache hits "
-                            "included); algorithmic bytes of the set = %d" % int(tr["algorithmic_bytes_per_step"]))
+            traffic_note = ("NOT measured in this run: a committed constant from the separate rocprofv3 --pmc passes of %s "
+                            "(FETCH_SIZE pass x2 for gfx950's 64-B tally + WRITE_SIZE pass, L2-miss side, Infinity-Cache hits "
+                            "included) over the same kernel set at this configuration; algorithmic bytes of the set = %d"
+                            % (os.path.basename(tj), int(tr["algorithmic_bytes_per_step"])))
         # Executed share of the nominal FLOPs: the kernels skip whole padding taps (exact: the skipped products are x0), so
         # the matrix pipe executes fewer bf16 MFMA operations than 6 x nominal.  Counted by SQ_INSTS_VALU_MFMA_MOPS_BF16
         # (x512 FLOP) in a separate rocprofv3 --pmc pass over this kernel set (scripts/pmc_mfma.py); it depends on the
@@ -339,8 +342,9 @@ def main():
             executed = (k["x6_fwd_dgrad"]["bf16_mfma_flops"] * 12 / k["x6_fwd_dgrad"]["launches"]
                         + k["x6_wgrad"]["bf16_mfma_flops"] * 6 / k["x6_wgrad"]["launches"]) / 6.0  # fp32-equivalent
             exec_ratio = executed / (dil_tflop * 1e12)
-            exec_note = ("bf16 MFMA FLOPs executed per step (SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512, profiles/r01_pmc_mfma.json) / 6 "
-                         "/ nominal FLOPs: padding taps of the dilated convs are skipped, not multiplied")
+            exec_note = ("NOT measured in this run: a committed constant from round 1's counter pass (SQ_INSTS_VALU_MFMA_MOPS_BF16 x "
+                         "512, profiles/r01_pmc_mfma.json; it depends on the layer shapes only) / 6 / nominal FLOPs: padding taps "
+                         "of the dilated convs are skipped, not multiplied")
         out = {
             "metric": f"{args.size}x{args.size} tiles/sec fwd+bwd {LABEL.get(args.model, args.model)} (full train step: fwd+loss+bwd+Adam)",
             "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,

@@ -28,7 +28,7 @@ class PlanesJob(C.Structure):
     """Mirror of `sg_planes_job` (include/segengine.h): one weight tensor -> its prepared bf16 operand planes."""
 
     _fields_ = [("w_off", C.c_int64), ("out_off", C.c_int64)] + [(n, C.c_int32) for n in (
-        "kind", "K", "N", "Kpad", "Npad", "Ck", "Ckp", "s_tap", "s_k", "s_n", "npl", "block0", "nblocks")]
+        "kind", "K", "N", "Kpad", "Npad", "Ck", "Ckp", "s_tap", "s_k", "s_n", "npl", "block0", "nblocks", "kd")]
 
 
 SG_WS_PREPARED = C.c_size_t(-1).value

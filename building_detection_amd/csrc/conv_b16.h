@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
   for (int i = 0; i < NB; ++i) {
     const int idx = t + NT * i;
     const int row = idx / CPR, c = idx % CPR;
-    b_voff[i] = idx < NBC ? (unsigned)(((n0 + row) * p.Kpad + c * 8) * 2) : OOB;
+    b_voff[i] = idx < NBC ? (unsigned)(((n0 + row) * BKB + c * 8) * 2) : OOB;   // k-block-major planes [Kpad / BKB][Npad][BKB]
   }
   const int ntaps = p.K / p.C;
   const bool ktail = (p.K % BKB) != 0;
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
 #pragma unroll
     for (int j = 0; j < NA; ++j)
       ra[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
-    const int soff_b = k0 * 2;
+    const int soff_b = (k0 / BKB) * p.Npad * BKB * 2;
 #pragma unroll
     for (int i = 0; i < NB; ++i) rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
   };
@@ -459,4 +459,11 @@ inline int dispatch_b16(const IgemmParams& p_in, int num_cus, hipStream_t st) {
   if (ks == 8) return launch_b16<32, 4, 1, 8>(p, st);
   if (ks == 4) return launch_b16<32, 4, 1, 4>(p, st);
   return launch_b16<32, 4, 1, 2>(p, st);
+}
+
+// k-block depth of the weight planes a launch will read = the slab depth of its kernel: 32 for conv_x6_kernel (both plane
+// counts), 16 * KS for conv_b16_kernel (bf16 storage, SG_B16_DEEP).  `c` is the depth of one tap (after virtual padding).
+inline int x6_plane_kd(bool b16_storage, int c, bool one_tap) {
+  static const bool deep = !(getenv("SG_B16_DEEP") && atoi(getenv("SG_B16_DEEP")) == 0);
+  return (b16_storage && deep) ? 16 * b16_ks(c, one_tap) : 32;
 }

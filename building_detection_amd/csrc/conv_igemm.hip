@@ -60,6 +60,7 @@ struct IgemmParams {
   // x6 path (conv_x6.h): the weights as three bf16 planes [3][Npad][Kpad]; w_bytes then is their extent
   const unsigned short* __restrict__ wq;
   int Kpad, Npad;
+  int kd;  // k-block depth of the plane layout [npl][Kpad / kd][Npad][kd] (= the kernel's slab depth); 0: rows [npl][Npad][Kpad]
   float* __restrict__ stats;  // SG_EPI_BN_STATS: [tiles_m][2][Nout] per-tile (sum, centred sum of squares), else null
 };
 
@@ -1156,18 +1157,19 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
     p.fd_c = make_fastdiv((uint32_t)Ckp);
   }
   const int K = p.K, N = p.Nout;
-  p.Kpad = x6_kpad(K);
+  p.kd = x6_plane_kd(NPL == 1 && !std::is_same<TA, float>::value, p.C, p.K == p.C);
+  p.Kpad = x6_kpad(K, p.kd);
   p.Npad = x6_npad(N);
   p.wq = (const unsigned short*)ws;
-  p.w_bytes = (uint32_t)x6_planes_bytes(K, N, NPL);
+  p.w_bytes = (uint32_t)x6_planes_bytes(K, N, NPL, p.kd);
   if (!prepared) {
     dim3 grid((unsigned)(p.Kpad / 32), (unsigned)(p.Npad / 32));
     if (!dgrad)
       hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Ck,
-                         Cin * Cout, Cout, 1, NPL, Ckp);
+                         Cin * Cout, Cout, 1, NPL, Ckp, p.kd);
     else
       hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Ck,
-                         Cin * Cout, 1, Cout, NPL, Ckp);
+                         Cin * Cout, 1, Cout, NPL, Ckp, p.kd);
     SG_LAUNCH_CHECK("split3_weights_kernel");
   }
   if constexpr (NPL == 1 && !std::is_same<TA, float>::value) {
@@ -1180,7 +1182,7 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
 // workspace of the weight planes for a launch with `taps` taps of depth C (virtual padding included), N columns
 inline size_t x6_ws_bytes(int taps, int C, int N) {
   const int k = taps > 1 ? taps * x6_vpad_c(C) : C;
-  const size_t rows = x6_planes_bytes(k, N, 3);
+  const size_t rows = x6_planes_bytes(k, N, 3, 64);   // (the deepest k-block any kernel asks for)
   const size_t wide = taps == 1 ? pw_planes_bytes(C, N, 3) : 0;   // the wide pointwise kernel pads N to 384s
   return rows > wide ? rows : wide;
 }
@@ -1898,6 +1900,7 @@ int sg_conv2d_planes_job(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, in
   out->s_n = dgrad ? d->Cout : 1;
   out->N = p.Nout;
   out->Ck = Ck;
+  out->kd = 0;
   if (npl == 3) {
     p.x = (const float*)(uintptr_t)16;  // x6p_ok tests the alignment of x
     if (x6p_ok(p, d->KH, d->KW)) {
@@ -1918,7 +1921,8 @@ int sg_conv2d_planes_job(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, in
     out->kind = 3;
     out->npl = npl;
     out->K = p.K;
-    out->Ckp = pw_kd(npl);
+    out->Ckp = p.K;
+    out->kd = pw_kd(npl);
     out->Kpad = pw_kpad(p.K, npl);
     out->Npad = pw_npad(p.Nout);
     out->nblocks = (int32_t)(sg_cdiv(out->Kpad, 32) * sg_cdiv(out->Npad, 32));
@@ -1934,10 +1938,11 @@ int sg_conv2d_planes_job(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, in
   out->npl = npl;
   out->K = K;
   out->Ckp = Ckp;
-  out->Kpad = x6_kpad(K);
+  out->kd = x6_plane_kd(b16 && npl == 1, Ckp, K == Ckp);
+  out->Kpad = x6_kpad(K, out->kd);
   out->Npad = x6_npad(p.Nout);
   out->nblocks = (out->Kpad / 32) * (out->Npad / 32);
-  *bytes = x6_planes_bytes(K, p.Nout, npl);
+  *bytes = x6_planes_bytes(K, p.Nout, npl, out->kd);
   return 0;
 }
 

@@ -87,9 +87,9 @@ __global__ __launch_bounds__(256) void split3_weights_kernel(const float* __rest
   }
 }
 
-inline int x6_kpad(int K) { return (int)(sg_cdiv(K, 32) * 32); }
+inline int x6_kpad(int K, int kd = 32) { return (int)(sg_cdiv(K, kd) * kd); }
 inline int x6_npad(int N) { return (int)(sg_cdiv(N, 128) * 128); }
-inline size_t x6_planes_bytes(int K, int N, int npl = 3) { return (size_t)npl * x6_kpad(K) * x6_npad(N) * 2; }
+inline size_t x6_planes_bytes(int K, int N, int npl = 3, int kd = 32) { return (size_t)npl * x6_kpad(K, kd) * x6_npad(N) * 2; }
 // K of a launch under virtual channel padding: ntaps * roundup(C, 32)
 inline int x6_vpad_c(int C) { return (int)(sg_cdiv(C, 32) * 32); }
 
@@ -190,7 +190,10 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     const int idx = t + NT * i;
     const int pl = idx / (BN * 4), rem = idx - pl * (BN * 4);
     const int row = rem >> 2, c = rem & 3;
-    b_voff[i] = idx < NBC ? (unsigned)(((pl * p.Npad + n0 + row) * p.Kpad + c * 8) * 2) : OOB;
+    // k-block-major planes [pl][Kpad / 32][Npad][32]: the 64 bytes of a row's slab and the rows of a tile are contiguous - a
+    // slab of B is BN x 64 bytes of whole cache lines.  (Row planes [n][k] gave each row half a line per slab: the other half
+    // was fetched again for the next slab unless it had survived in L1; round 3.)
+    b_voff[i] = idx < NBC ? (unsigned)((((pl * (p.Kpad >> 5)) * p.Npad + n0 + row) * 32 + c * 8) * 2) : OOB;
   }
   const int ntaps = p.K / p.C;
   const bool ktail = (p.K % BK) != 0;
@@ -220,7 +223,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
 #pragma unroll
     for (int j = 0; j < NA; ++j)
       ra[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(kvalid ? tap_voff[j] : OOB), soff_a, 0);
-    const int soff_b = k0 * 2;
+    const int soff_b = (k0 >> 5) * p.Npad * 64;
 #pragma unroll
     for (int i = 0; i < NB; ++i) rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
   };
@@ -371,7 +374,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
           if (ks == 0 && i == 0) __builtin_amdgcn_sched_barrier(0);  // keep the first tile's operands first in the queue
         }
     __builtin_amdgcn_sched_barrier(0);
-    const int soff_a = (k0 - cur_tap * p.C) * EB, soff_b = k0 * 2;
+    const int soff_a = (k0 - cur_tap * p.C) * EB, soff_b = (k0 >> 5) * p.Npad * 64;
     const bool kvalid = !ktail || (k0 + CH * kc < p.K);
     unsigned hs[NA][2], ms[NA][2], ls[NA][2];
     constexpr int P_SPLIT = 2 * NA;            // pieces: 2*NA splits, NA A-writes, NB B-writes, NA + NB loads
@@ -433,7 +436,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
       if (ks == 0) __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    const int soff_a = (k0 - cur_tap * p.C) * EB, soff_b = k0 * 2;
+    const int soff_a = (k0 - cur_tap * p.C) * EB, soff_b = (k0 >> 5) * p.Npad * 64;
     const bool kvalid = !ktail || (k0 + CH * kc < p.K);
     constexpr int P_AW = NA, P_BW = P_AW + NB, P_LA = P_BW + NA, P_LB = P_LA + NB;
     auto piece = [&](int w) {

@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(const float* __rest
   const float* __restrict__ w = w_arena + j.w_off;
   unsigned short* __restrict__ out = reinterpret_cast<unsigned short*>(planes_arena + j.out_off);
   if (j.kind == 1 || j.kind == 3) {  // row planes [npl][Npad][Kpad]; kind 3: k-block-major [npl][Kpad / KD][Npad][KD], KD = Ckp
-    const int kd = j.kind == 3 ? j.Ckp : 0;
+    const int kd = j.kd;
     const int gx = (j.Kpad + 31) / 32;
     const int k0 = (lb % gx) * 32, n0 = (lb / gx) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -87,8 +87,7 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(const float* __rest
       const int k = k0 + ky, n = n0 + nx;
       float v = 0.f;
       if (k < j.K && n < j.N) {
-        const int ckp = kd ? j.K : j.Ckp;   // kind 3 is one tap
-        const int tap = k / ckp, kk = k - tap * ckp;
+        const int tap = k / j.Ckp, kk = k - tap * j.Ckp;
         if (kk < j.Ck) v = w[(int64_t)tap * j.s_tap + (int64_t)kk * j.s_k + (int64_t)n * j.s_n];
       }
       tile[ky][nx] = v;

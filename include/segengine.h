@@ -191,10 +191,13 @@ int sg_dense_fwd(sg_ctx* ctx, void* stream, int dtype, int rows, int in, int out
 #define SG_WS_PREPARED ((size_t)-1)
 typedef struct sg_planes_job {
   int64_t w_off, out_off;
-  int32_t kind; /* 0 none, 1 row planes [npl][Npad][Kpad], 2 fragment-major (patch kernel), 3 k-block-major
-                 * [npl][Kpad / Ckp][Npad][Ckp] (wide pointwise kernel: Ckp = 16 or 64 is the k-block depth) */
+  int32_t kind; /* 0 none, 1 bf16 operand planes of the 128-wide-tile kernels, 2 fragment-major (patch kernel), 3 planes of the
+                 * wide pointwise kernel (Npad a multiple of 384); layout of 1 and 3: see kd */
   int32_t K, N, Kpad, Npad, Ck, Ckp, s_tap, s_k, s_n, npl;
   int32_t block0, nblocks;
+  int32_t kd; /* kinds 1 and 3: k-block depth of the layout [npl][Kpad / kd][Npad][kd] (32 / 64 for the 128-wide tiles, 16 / 64
+               * for the wide pointwise kernel): the kd reduction indices a kernel stages per row are contiguous, and so are the
+               * rows, so a staged slab is one contiguous range of whole cache lines; 0 = row-major [npl][Npad][Kpad] */
 } sg_planes_job;
 int sg_get_conv_x6(void);
 int sg_conv2d_planes_job(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, int dgrad, sg_planes_job* out, size_t* bytes);

@@ -258,7 +258,16 @@ def test_config3_deeplab_bf16_512_bs16(engine):
     d = torch.randn(w0.numel(), generator=gen).abs().cuda()
     d *= (w0.abs() + 1e-3) * torch.sign(g1)
     ratios = _group_directional_derivatives(model, _param_groups(model, "v3plus"), d, g1, w0, f0, xd, yd)
-    print("config 3 bf16 512x512 bs16: fd / <g,d> per parameter group: " + "  ".join(f"{k} {v:.4f}" for k, v in ratios.items()))
+    n_tr = sum(1 for p_ in model.params if p_.trainable)
+    whole = _group_directional_derivatives(model, ["all"] * n_tr, d, g1, w0, f0, xd, yd)["all"]
+    print(f"config 3 bf16 512x512 bs16: fd / <g,d> over all parameters {whole:.4f}; per group: " +
+          "  ".join(f"{k} {v:.4f}" for k, v in ratios.items()))
+    # Measured (profiles/r03_diag_fd_512.txt and the first run of this test): all parameters 0.66; groups 0.54 ... 1.31.  The
+    # bf16 loss is a staircase at these step sizes (a weight moves its bf16 plane only when it crosses a rounding boundary):
+    # over 64 M parameters the crossings average out, over a group of 1-2 M they leave +-30 % of scatter, and where the bf16
+    # gradient is noisy (random init, (e)) <g, d> overstates the real slope.  So this part only excludes a wrong sign or
+    # scale of a whole group; the discriminating gradient checks are (e) and tests/test_block_chains_gpu.py.
+    assert 0.5 <= whole <= 1.1, whole
     for k, v in ratios.items():
         assert GROUP_FD[k][0] <= v <= GROUP_FD[k][1], (k, v)
     del g1, d, w0, f0
@@ -316,10 +325,9 @@ def test_config3_deeplab_bf16_512_bs16(engine):
 # 1.0000 (at random init: 0.51 / 0.51 / 0.62 / 0.66 / 0.68 / 0.76 / 0.998); the kernels are deterministic, so the
 # head-room only has to cover later changes of summation order.
 GROUP_COS = {"entry": 0.75, "middle": 0.78, "exit": 0.94, "sk": 0.94, "aspp": 0.95, "neck": 0.99, "decoder": 0.9995}
-# accepted range of (finite difference of the bf16 loss) / <g_bf16, d> per group at RANDOM INIT (part (d)); fp32 gives 1.00
-# everywhere.  To be set from the first measured run.
-GROUP_FD = {"entry": (0.2, 1.3), "middle": (0.2, 1.3), "exit": (0.2, 1.3), "sk": (0.2, 1.3), "aspp": (0.2, 1.3),
-            "neck": (0.3, 1.3), "decoder": (0.9, 1.1)}
+# accepted range of (finite difference of the bf16 loss) / <g_bf16, d> per group at RANDOM INIT (part (d)); fp32 gives 1.00 in
+# every group.  First measured run: entry 1.01, middle 0.62, exit 1.00, sk 1.05, aspp 0.54, neck 1.04, decoder 1.31.
+GROUP_FD = {k: (0.3, 1.7) for k in ("entry", "middle", "exit", "sk", "aspp", "neck", "decoder")}
 
 
 # Convolution kernels at the BASELINE sizes through identities that hold for any size: forward, dgrad and wgrad are the
