@@ -1544,6 +1544,7 @@ struct WgradPlan {
   int chunks = 1;  // > 1: activations beyond 2 GiB are reduced as sub-batches of nb whole images, each with S splits
   int nb = 0;
   int patch = 0;   // the patch form (conv_x6wp.h): S = its workgroup count, every workgroup writes one partial slab
+  int wide = 0;    // the wide pointwise form (conv_pw.h): slabs_per_split counts 16-pixel k-steps
 };
 
 // Split of the pixel reduction over S workgroups per tile.  Modelled time = MFMA work / (fraction of the
@@ -1570,6 +1571,13 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d, bool b16 = false) {
     pl.S = 1;
     pl.slabs_per_split = 0;
     pl.dw_part_bytes = thin_part_bytes(num_cus, d);
+    pl.bias_part_bytes = colsum_ws_bytes(num_cus, P, d->Cout);
+    return pl;
+  }
+  if (!b16 && x6_mode() == 1 && wgrad_pw_wide_geom(d)) {   // 1x1, stride 1, wide enough: 128 x 384 tiles of dw (conv_pw.h)
+    pl.wide = 1;
+    wgrad_pw_wide_plan(num_cus, d, pl.S, pl.slabs_per_split);
+    pl.dw_part_bytes = pl.S > 1 ? (size_t)pl.S * K * d->Cout * 4 : 0;
     pl.bias_part_bytes = colsum_ws_bytes(num_cus, P, d->Cout);
     return pl;
   }
@@ -2174,6 +2182,20 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
       p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
       p.dy_bytes = yb < (1ll << 31) ? (uint32_t)yb : 0;
     }
+    if (pl.wide) {
+      const bool al = aligned16(xs) && aligned16(dys) && p.x_bytes != 0 && p.dy_bytes != 0 && !head32;
+      if (al) {
+        int Sw, kps;   // re-planned for THIS part: a last, smaller sub-batch has fewer k-steps
+        wgrad_pw_wide_plan(ctx->num_cus, &dd, Sw, kps);
+        if (Sw > S) {  // never more partial slabs than the workspace was sized for
+          kps = (int)sg_cdiv(sg_cdiv((int64_t)p.P, 16), S);
+          Sw = (int)sg_cdiv(sg_cdiv((int64_t)p.P, 16), kps);
+        }
+        p.slabs_per_split = kps;
+        parts = Sw;
+        return launch_wgrad_pw_wide(p, Sw, st);
+      }
+    }
     if (pl.patch) {
       const bool al = aligned16(xs) && aligned16(dys) && p.x_bytes != 0 && p.dy_bytes != 0 && !head32;
       if (al) {
@@ -2183,6 +2205,13 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
         if (b16) return launch_x6wp<1, bf16_t>(p, grid, st);
         return x6_mode() == 2 ? launch_x6wp<1, float>(p, grid, st) : launch_x6wp<3, float>(p, grid, st);
       }
+      const int nslab = (int)sg_cdiv((int64_t)p.P, BK);
+      sps = (int)sg_cdiv(nslab, S);
+      p.slabs_per_split = sps;
+      S = (int)sg_cdiv(nslab, sps);
+      parts = S;
+    }
+    if (pl.wide) {  // unaligned operands: the slab kernels, with the plan's share count
       const int nslab = (int)sg_cdiv((int64_t)p.P, BK);
       sps = (int)sg_cdiv(nslab, S);
       p.slabs_per_split = sps;

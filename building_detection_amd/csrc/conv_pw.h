@@ -518,3 +518,238 @@ inline bool pw_wide_ok(const IgemmParams& p, int eb) {
   const int64_t ntn = sg_cdiv(p.Nout, PW_BN);
   return (double)p.Nout / (double)(ntn * PW_BN) >= 0.75;
 }
+
+// =====================================================================================================================
+// The filter gradient of the same layers: dw[ci][co] = sum over pixels x[p][ci] * dy[p][co]   (1x1, stride 1; fp32, x6)
+//
+// wgrad_x6_kernel walks 128 x 128 tiles of dw: six row tiles x six column tiles for 728 -> 728, every element of x AND of dy
+// split into its planes six times, 0.75 fragment reads per MFMA.  Here a workgroup owns 128 input channels x 384 output
+// channels of dw (12 tiles) for a share of the pixels (21 splits: 252 workgroups, one per CU): x is split twice, dy six
+// times - four 16-byte chunks per thread and 36 MFMAs per 16-pixel k-step instead of four per 24 - and a wave's 64 x 96
+// sub-tile reads 15 fragments per 36 MFMAs.  Both operands are activations, [pixel][channel] in memory as in LDS; the
+// fragments (8 consecutive pixels of one channel per lane) come from the transposed LDS read, exactly as in
+// wgrad_x6_kernel (tr_frag, pitch = channel bytes + 64).  Two LDS stages of one k-step, one barrier per k-step, the
+// split + LDS store of k-step s+1 and the loads of k-step s+2 woven between the MFMAs of k-step s.  Partial slabs
+// [split][Cin][Cout] are summed by reduce_splits_kernel in fixed order, as for every other filter gradient.
+constexpr int WPW_PA = 2 * PW_BM + 64;   // 320: LDS pitch of an A' pixel row (128 channels of bf16 + 64)
+constexpr int WPW_PB = 2 * PW_BN + 64;   // 832
+constexpr int WPW_STAGE = 3 * 16 * (WPW_PA + WPW_PB);   // 55296
+
+__global__ __launch_bounds__(512, 2) void wgrad_pw_wide_kernel(const WgradParams p) {
+  constexpr int WGN = 4, WM = 64, WN = 96, TM = 2, TN = 3;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages] x { A' [3][16][PA], B [3][16][PB] }
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const uint32_t ntn = (p.Cout + PW_BN - 1) / PW_BN;
+  uint32_t bid, split;
+  {
+    const uint32_t lin = blockIdx.z * gridDim.x + blockIdx.x;
+    const uint32_t o = xcd_remap(lin, gridDim.x * gridDim.z);
+    split = o / gridDim.x;
+    bid = o - split * gridDim.x;
+  }
+  const uint32_t tile_r = bid / ntn, tile_n = bid - tile_r * ntn;
+  const int rbase = tile_r * PW_BM, n0 = tile_n * PW_BN;
+  const int nks_total = (p.P + 15) / 16;
+  const int ks_begin = (int)split * p.slabs_per_split;   // (k-steps of 16 pixels per split for this kernel)
+  int ks_end = ks_begin + p.slabs_per_split;
+  if (ks_end > nks_total) ks_end = nks_total;
+  const int nk = ks_end - ks_begin;
+
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+  // chunks of a k-step: A' 16 pixels x 32 chunks (one per thread), B 16 pixels x 96 chunks (three per thread)
+  const int pa = t >> 5, ca = t & 31;
+  const unsigned a_voff = (rbase + 4 * ca) < p.Cin ? (unsigned)((pa * p.x_ld + rbase + 4 * ca) * 4) : OOB;
+  int pb[3], cb[3];
+  unsigned b_voff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = t + 512 * i;
+    pb[i] = idx / 96;
+    cb[i] = idx - pb[i] * 96;
+    b_voff[i] = (n0 + 4 * cb[i]) < p.Cout ? (unsigned)((pb[i] * p.y_ld + n0 + 4 * cb[i]) * 4) : OOB;
+  }
+  const bool ptail = (p.P & 15) != 0;
+  u32x4_t ra, rb[3];
+  auto load_piece = [&](int ks, int w) {   // w = 0: the A' chunk, 1..3: the B chunks of k-step ks (absolute)
+    const int p0 = ks * 16;
+    if (w == 0) {
+      const bool v = !ptail || (p0 + pa < p.P);
+      ra = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voff : OOB), p0 * p.x_ld * 4, 0);
+    } else {
+      const bool v = !ptail || (p0 + pb[w - 1] < p.P);
+      rb[w - 1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)(v ? b_voff[w - 1] : OOB), p0 * p.y_ld * 4, 0);
+    }
+  };
+  unsigned hh[2], mm[2], ll[2];
+  auto split_piece = [&](const u32x4_t v, int half) {
+    const f32x4 f = __builtin_bit_cast(f32x4, v);
+    split3_pair(f[2 * half], f[2 * half + 1], hh[half], mm[half], ll[half]);
+  };
+  auto write_piece = [&](char* dst, int pitch) {   // the three planes of one chunk: 4 channels of one pixel, 8 bytes each
+    *reinterpret_cast<u32x2_t*>(dst) = (u32x2_t){hh[0], hh[1]};
+    *reinterpret_cast<u32x2_t*>(dst + 16 * pitch) = (u32x2_t){mm[0], mm[1]};
+    *reinterpret_cast<u32x2_t*>(dst + 32 * pitch) = (u32x2_t){ll[0], ll[1]};
+  };
+  auto a_dst = [&](int stage) { return smem + stage * WPW_STAGE + pa * WPW_PA + ca * 8; };
+  auto b_dst = [&](int stage, int i) { return smem + stage * WPW_STAGE + 3 * 16 * WPW_PA + pb[i] * WPW_PB + cb[i] * 8; };
+
+  // ---- MFMA side (wgrad_x6_kernel's transposed reads): lane = 16 g + i supplies pixel row 8 (g >> 1) + (i >> 2) [+ 4 for
+  // the second read], channels 16 (g & 1) + 4 (i & 3) .. + 3 of its 32-channel block
+  const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int tg = lane >> 4, ti = lane & 15;
+  const int tr_row = 8 * (tg >> 1) + (ti >> 2), tr_col = 16 * (tg & 1) + 4 * (ti & 3);
+  const int a_lane = tr_row * WPW_PA + (wm + tr_col) * 2;
+  const int b_lane = 3 * 16 * WPW_PA + tr_row * WPW_PB + (wn + tr_col) * 2;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // one k-step; MODE 2: stage k-step s+1 and load s+2; 1: stage s+1; 0: multiply only
+  auto step = [&](int s, auto MODE_) {
+    constexpr int MODE = decltype(MODE_)::value;
+    const int cur = s & 1, nxt = cur ^ 1;
+    const char* sb = smem + cur * WPW_STAGE;
+    bf16x8_t af[TM][3], bf[TN][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const char* a = sb + a_lane + pl * 16 * WPW_PA;
+      af[0][pl] = tr_frag(a, a + 4 * WPW_PA);
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const char* b = sb + b_lane + pl * 16 * WPW_PB + 64 * j;
+        bf[j][pl] = tr_frag(b, b + 4 * WPW_PB);
+      }
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+      const char* a = sb + a_lane + pl * 16 * WPW_PA + 64;
+      af[1][pl] = tr_frag(a, a + 4 * WPW_PA);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // pieces: chunk c (0 = A', 1..3 = B): split half 0, split half 1, write; then its reload - 4 pieces per chunk
+    auto piece = [&](int w) {
+      if (MODE == 0 || w >= 16) return;
+      const int c = w >> 2, sub = w & 3;
+      if (sub < 2) {
+        split_piece(c == 0 ? ra : rb[c - 1 < 0 ? 0 : c - 1], sub);
+      } else if (sub == 2) {
+        if (c == 0) write_piece(a_dst(nxt), WPW_PA);
+        else write_piece(b_dst(nxt, c - 1), WPW_PB);
+      } else {
+        if (MODE == 2) load_piece(ks_begin + s + 2, c);
+      }
+    };
+    int q = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][PA_[u]], bf[j][PB_[u]], acc[i][j], 0, 0, 0);
+          if ((q & 1) == 1) piece(q >> 1);   // one piece per two MFMAs: 16 pieces over 36 MFMAs
+          ++q;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // raw: the loads of k-step s+2 stay in flight across it
+  };
+
+  if (nk > 0) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) load_piece(ks_begin, w);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      split_piece(c == 0 ? ra : rb[c - 1 < 0 ? 0 : c - 1], 0);
+      split_piece(c == 0 ? ra : rb[c - 1 < 0 ? 0 : c - 1], 1);
+      if (c == 0) write_piece(a_dst(0), WPW_PA);
+      else write_piece(b_dst(0, c - 1), WPW_PB);
+    }
+    if (nk > 1) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) load_piece(ks_begin + 1, w);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int s = 0;
+    for (; s + 2 < nk; ++s) step(s, IC<2>{});
+    if (s + 1 < nk) { step(s, IC<1>{}); ++s; }
+    step(s, IC<0>{});
+  }
+
+  // ---- the partial slab of this split: out[split][ci][co], branch-free buffer stores ---------------------------------------
+  float* outp = p.out + (int64_t)split * p.K * p.Cout;
+  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)((uint32_t)p.K * (uint32_t)p.Cout * 4u), 0x00020000);
+  const unsigned row0 = (unsigned)(rbase + wm + 4 * lh);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn + 32 * j + lr;
+    const unsigned cterm = col < p.Cout ? (unsigned)col * 4u : OOB;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+        unsigned voff = cterm + row * (unsigned)p.Cout * 4u;
+        voff = row < (unsigned)p.K ? voff : OOB;
+        const float v = acc[i][j][r];   // (a named float: __builtin_bit_cast applied to the vector element itself reads lane 0 of
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_o, (int)voff, 0, 0);   // the vector)
+      }
+  }
+}
+
+// plan of the wide filter gradient: tiles of 128 x 384, the pixel reduction cut into S shares of whole 16-pixel k-steps so
+// that tiles x S fills the CUs once
+inline bool wgrad_pw_wide_geom(const sg_conv_desc* d) {
+  static int on = -1;
+  if (on < 0) on = getenv("SG_PW_WIDE") ? atoi(getenv("SG_PW_WIDE")) : 1;
+  if (!on) return false;
+  if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad_t != 0 || d->pad_l != 0) return false;
+  const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+  if (xl % 4 != 0 || yl % 4 != 0 || d->Cin % 4 != 0 || d->Cout % 4 != 0) return false;
+  if (on == 2) return true;
+  const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
+  if (P < 6144 || d->Cin < 256) return false;
+  const int64_t ntn = sg_cdiv(d->Cout, PW_BN), ntr = sg_cdiv(d->Cin, PW_BM);
+  return (double)d->Cout / (double)(ntn * PW_BN) >= 0.75 && (double)d->Cin / (double)(ntr * PW_BM) >= 0.75;
+}
+
+inline void wgrad_pw_wide_plan(int num_cus, const sg_conv_desc* d, int& S, int& ksteps_per_split) {
+  const int64_t tiles = sg_cdiv(d->Cin, PW_BM) * sg_cdiv(d->Cout, PW_BN);
+  const int64_t nks = sg_cdiv((int64_t)d->N * d->Ho * d->Wo, 16);
+  int64_t s = (int64_t)num_cus / tiles;
+  if (s < 1) s = 1;
+  if (s > nks / 8) s = nks / 8 > 0 ? nks / 8 : 1;   // at least 8 k-steps per share
+  ksteps_per_split = (int)sg_cdiv(nks, s);
+  S = (int)sg_cdiv(nks, ksteps_per_split);
+}
+
+inline int launch_wgrad_pw_wide(const WgradParams& p, int S, hipStream_t st) {
+  constexpr size_t lds = 2 * (size_t)WPW_STAGE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = set_dyn_lds(wgrad_pw_wide_kernel, lds);
+    if (rc) return rc;
+    attr_done = true;
+  }
+  const int64_t tiles = sg_cdiv(p.Cin, PW_BM) * sg_cdiv(p.Cout, PW_BN);
+  if (tiles <= 0 || tiles > 65535 || S < 1 || S > 65535 || (int64_t)p.K * p.Cout * 4 >= (1ll << 31)) {
+    sg_set_error("wgrad_pw_wide: bad grid (%lld tiles, %d splits)", (long long)tiles, S);
+    return SG_EINVAL;
+  }
+  hipLaunchKernelGGL(wgrad_pw_wide_kernel, dim3((unsigned)tiles, 1, (unsigned)S), dim3(512), lds, st, p);
+  SG_LAUNCH_CHECK("wgrad_pw_wide_kernel");
+  return 0;
+}

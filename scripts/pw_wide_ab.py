@@ -55,4 +55,10 @@ for (n, h, cin, cout) in SHAPES:
     tf_ = timed(lambda: e.conv2d_fwd(x, w, b, desc=d, out=y))
     td = timed(lambda: e.conv2d_dgrad(dy, w, d, out=dx))
     fl = 2.0 * n * h * h * cin * cout / 1e6
-    print(f"  M {n * h * h:6d} {cin:5d}->{cout:5d}: fwd {tf_:7.1f} us {fl / tf_:6.1f} TF err {ey:.1e} | dgrad {td:7.1f} us {fl / td:6.1f} TF err {ed:.1e}", flush=True)
+    dw, _ = e.conv2d_wgrad(x, dy, d, want_bias=False)
+    cols = torch.randint(0, cout, (48,), generator=g).cuda()
+    refw = x.view(-1, cin).double().t() @ dy.view(-1, cout)[:, cols].double()
+    ew = float((dw.view(cin, cout)[:, cols].double() - refw).abs().max() / refw.abs().max())
+    tw = timed(lambda: e.conv2d_wgrad(x, dy, d, want_bias=False, dw=dw))
+    print(f"  M {n * h * h:6d} {cin:5d}->{cout:5d}: fwd {tf_:7.1f} us {fl / tf_:6.1f} TF err {ey:.1e} | dgrad {td:7.1f} us {fl / td:6.1f} TF err {ed:.1e}"
+          f" | wgrad {tw:7.1f} us {fl / tw:6.1f} TF err {ew:.1e}", flush=True)
