@@ -1100,7 +1100,13 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
     if (bn == 64) return (var & 1) ? launch_x6<64, 4, 2, 2, 1, TA>(p, st) : launch_x6<64, 4, 2, 1, 1, TA>(p, st);
     return (var & 1) ? launch_x6<32, 4, 1, 2, 1, TA>(p, st) : launch_x6<32, 4, 1, 1, 1, TA>(p, st);
   } else {
+  // 16x16x32 products for the multi-tap convolutions (conv_x6_kernel, MF): a property of the layer, never of the batch.
+  // SG_X6_MF16=0 keeps every launch on 32x32x16 (A/B runs).
+  static const bool mf16_on = !(getenv("SG_X6_MF16") && atoi(getenv("SG_X6_MF16")) == 0);
+  const bool mf = mf16_on && p.K != p.C;
   if (bn == 128) {
+    if (mf && var == 0) return launch_x6<128, 2, 4, 1, 3, float, 1>(p, st);
+    if (mf && var == 1) return launch_x6<128, 2, 4, 2, 3, float, 1>(p, st);
     switch (var) {
       case 0: return launch_x6<128, 2, 4, 1>(p, st);
       case 1: return launch_x6<128, 2, 4, 2>(p, st);
@@ -1109,6 +1115,8 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
     }
   }
   if (bn == 64) {
+    if (mf && var == 0) return launch_x6<64, 4, 2, 1, 3, float, 1>(p, st);
+    if (mf && var == 1) return launch_x6<64, 4, 2, 2, 3, float, 1>(p, st);
     switch (var) {
       case 0: return launch_x6<64, 4, 2, 1>(p, st);
       case 1: return launch_x6<64, 4, 2, 2>(p, st);
@@ -1116,6 +1124,7 @@ int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
       default: return launch_x6<64, 2, 2, 2>(p, st);
     }
   }
+  if (mf) return (var & 1) ? launch_x6<32, 4, 1, 2, 3, float, 1>(p, st) : launch_x6<32, 4, 1, 1, 3, float, 1>(p, st);
   return (var & 1) ? launch_x6<32, 4, 1, 2>(p, st) : launch_x6<32, 4, 1, 1>(p, st);
   }
 }

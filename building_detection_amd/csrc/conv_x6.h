@@ -31,8 +31,12 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 // slot (chunk ^ xswz(r)).  Reads: the 16 lanes of a ds_read_b128 group (rows {0-3,12-15,20-27} or {4-11,16-19,28-31})
 // then hit 16 distinct 16-byte bank groups; writes: two consecutive rows fill the 32 write banks exactly once
 // (the padded 80-byte rows this replaces cost 28 % of the LDS-active cycles in bank conflicts, SQ_LDS_BANK_CONFLICT).
+// Round 3: the row group (row >> 2) & 3 is sent through the bijection (0, 2, 3, 1) instead of the identity.  Any bijection keeps the
+// 32-row pattern above conflict-free (a lane group's four 4-row groups are distinct and share one chunk); this one also serves
+// the 16x16x32 fragments (lane -> row lane & 15, chunk lane >> 4: a lane group then holds rows 0-3 and 12-15 with chunk c and rows
+// 4-11 with chunk c ^ 1, and {g0, g3, 1 ^ g1, 1 ^ g2} must be four different slots).
 constexpr int XPITCH = 64;
-__device__ __forceinline__ int xswz(int row) { return (row >> 2) & 3; }
+__device__ __forceinline__ int xswz(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }
 
 // (x0, x1) -> three packed bf16 pairs (element 0 in the low half), x = h + m + l up to 2^-25 |x|
 __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
@@ -105,9 +109,17 @@ inline int x6_vpad_c(int C) { return (int)(sg_cdiv(C, 32) * 32); }
 // and tile (bf16 products, fp32 accumulation) - with TA = float the fp32 activations are rounded to bf16 on their way
 // into LDS, with TA = bf16_t (SG_BF16 storage) a thread's 16-byte chunk holds 8 k and goes to LDS as it is (no
 // arithmetic at all between the global load and the MFMA); the output is stored as TA.
-template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float>
+// MF = 1 (NPL = 3 only): the products on v_mfma_f32_16x16x32_bf16 - one 32-deep k-step per slab, 2 TM x 2 TN blocks of 16 x 16 per
+// wave - instead of 32x32x16 (two 16-deep k-steps, TM x TN blocks).  Same cycles per FLOP, same LDS fragment traffic (18 reads per
+// slab at TM = 2, TN = 1), but the chip holds a higher clock on this shape under load: the bare x6 loop runs 1.10-1.125x faster
+// (scripts/exp_x6_shape.hip, profiles/r03_exp_x6_shape.txt).  A 32-deep instruction adds its products in another order than two
+// 16-deep ones, so MF is a property of the LAYER, never of the batch: the multi-tap convolutions take it (dispatch_x6); 1x1
+// convolutions, which the wide pointwise kernel (16-deep stages) may serve at another batch size, stay on 32x32x16.
+template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float, int MF = 0>
 __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM * WGN / 2) void conv_x6_kernel(const IgemmParams p) {
   static_assert(NPL == 3 || NPL == 1, "planes");
+  static_assert(MF == 0 || NPL == 3, "the 16x16x32 form exists for the six-pass product");
+  constexpr bool MF16 = MF != 0;
   static_assert(NPL == 1 || std::is_same<TA, float>::value, "the three-plane split is the fp32 path");
   constexpr bool A16 = !std::is_same<TA, float>::value;  // bf16 storage
   constexpr int EB = EL<TA>::BYTES, CH = EL<TA>::CH;
@@ -266,16 +278,24 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   // ---- MFMA side --------------------------------------------------------------------------------------------
   const int wave = t >> 6, lane = t & 63;
   const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
-  const int lr = lane & 31, lh = lane >> 5;
-  f32x16 acc[TM][TN];
+  // 32x32x16: lane -> row lane & 31 of a 32-row block, k half lane >> 5 of a 16-deep k-step; 16 result registers.
+  // 16x16x32: lane -> row lane & 15 of a 16-row block, 8-k chunk lane >> 4 of the 32-deep slab; 4 result registers.
+  constexpr int TMB = MF16 ? 2 * TM : TM, TNB = MF16 ? 2 * TN : TN, RB_ = MF16 ? 16 : 32, NR = MF16 ? 4 : 16;
+  const int lr = MF16 ? (lane & 15) : (lane & 31), lh = MF16 ? (lane >> 4) : (lane >> 5);
+  typedef float accv_t __attribute__((ext_vector_type(NR)));
+  accv_t acc[TMB][TNB];
 #pragma unroll
-  for (int i = 0; i < TM; ++i)
+  for (int i = 0; i < TMB; ++i)
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TNB; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+      for (int r = 0; r < NR; ++r) acc[i][j][r] = 0.f;
+  // result element r of block (i, j) in this lane: local row / column inside the wave's sub-tile
+  auto acc_row = [&](int i, int r) { return MF16 ? 16 * i + 4 * lh + r : 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh; };
+  auto acc_col = [&](int j) { return RB_ * j + lr; };
   const char* a_lane = Ap + (wm + lr) * XPITCH;
   const char* b_lane = Bp + (wn + lr) * XPITCH;
+  const int koff16 = (lh ^ xswz(lr)) << 4;   // MF16: this lane's 16-byte chunk (k = 8 lh ..) of a row, after the swizzle
   // byte offset of this lane's 16-byte chunk (k = 16 ks + 8 lh ..) inside its row, after the swizzle; wm, wn and the
   // 32-row sub-tile offsets are multiples of 32, so the swizzle depends on lr only
   const int koff[2] = {((0 + lh) ^ xswz(lr)) << 4, ((2 + lh) ^ xswz(lr)) << 4};
@@ -289,6 +309,39 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   auto compute = [&](int buf) {
     const char* a_lane_b = a_lane + buf * BUFSZ;
     const char* b_lane_b = b_lane + buf * BUFSZ;
+    if constexpr (MF16) {
+      // the B fragments of the slab once, the A fragments in groups of IH row blocks (all of them where the registers allow:
+      // KH == 2; half of them in the 8-wave two-workgroups-per-CU form, which runs at the 128-register cap)
+      constexpr int IH = (KH == 2 || TMB == 1) ? TMB : TMB / 2;
+      bf16x8_t bf[TNB][3];
+#pragma unroll
+      for (int j = 0; j < TNB; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (pl * BN + 16 * j) * XPITCH + koff16);
+#pragma unroll
+      for (int i0 = 0; i0 < TMB; i0 += IH) {
+        bf16x8_t af[IH][3];
+#pragma unroll
+        for (int i = 0; i < IH; ++i)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            af[i][pl] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (pl * BM + 16 * (i0 + i)) * XPITCH + koff16);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < IH; ++i)
+#pragma unroll
+          for (int j = 0; j < TNB; ++j) {
+            auto& c = acc[i0 + i][j];
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][2], bf[j][0], c, 0, 0, 0);   // smallest terms first
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][2], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][1], bf[j][0], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][1], c, 0, 0, 0);
+            c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i][0], bf[j][0], c, 0, 0, 0);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
 #pragma unroll
     for (int k0s = 0; k0s < 2; k0s += KH) {
       bf16x8_t af[KH][TM][NPL], bf[KH][TN][NPL];
@@ -329,6 +382,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    }
   };
 
   // ---- hand-interleaved step (p.stagger == 2): the MFMAs of slab s with, woven into their gaps in a fixed order,
@@ -357,19 +411,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     const char* b_lane_b = b_lane + cbuf * BUFSZ;
     // fragment reads in the order the MFMAs consume them (a3,b1 | a1,b3 | a2,b2 of the first tile, ...): LDS
     // returns in order, so the first MFMA waits for two reads, not for all eighteen
-    bf16x8_t af[2][TM][3], bf[2][TN][3];
+    constexpr int FK = MF16 ? 1 : 2, FM = MF16 ? TMB : TM, FN = MF16 ? TNB : TN, FR = MF16 ? 16 : 32;
+    bf16x8_t af[FK][FM][3], bf[FK][FN][3];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < FK; ++ks)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < FM; ++i)
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
           constexpr int APL[3] = {2, 0, 1}, BPL[3] = {0, 2, 1};
-          af[ks][i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (APL[u] * BM + 32 * i) * XPITCH + koff[ks]);
+          const int ko = MF16 ? koff16 : koff[ks];
+          af[ks][i][APL[u]] = *reinterpret_cast<const bf16x8_t*>(a_lane_b + (APL[u] * BM + FR * i) * XPITCH + ko);
           if (i == 0) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              bf[ks][j][BPL[u]] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (BPL[u] * BN + 32 * j) * XPITCH + koff[ks]);
+            for (int j = 0; j < FN; ++j)
+              bf[ks][j][BPL[u]] = *reinterpret_cast<const bf16x8_t*>(b_lane_b + (BPL[u] * BN + FR * j) * XPITCH + ko);
           }
           if (ks == 0 && i == 0) __builtin_amdgcn_sched_barrier(0);  // keep the first tile's operands first in the queue
         }
@@ -406,6 +462,21 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, (int)b_voff[i], soff_b, 0);
       }
     };
+    if constexpr (MF16) {
+      // 24 TM TN instructions of 16 cycles: one piece behind every SECOND one keeps the piece density per matrix-pipe cycle
+      constexpr int NM16 = 6 * TMB * TNB;
+#pragma unroll
+      for (int q = 0; q < NM16; ++q) {
+        const int tile = q / 6, term = q % 6;
+        const int i = tile / TNB, j = tile % TNB;
+        constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[0][i][PA_[term]], bf[0][j][PB_[term]], acc[i][j], 0, 0, 0);
+        if (q & 1) piece(q >> 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int w = NM16 / 2; w < P_LB; ++w) piece(w);
+    } else {
 #pragma unroll
     for (int q = 0; q < NM; ++q) {
       const int ks = q / (6 * TM * TN), r = q % (6 * TM * TN), tile = r / 6, term = r % 6;
@@ -417,6 +488,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     }
 #pragma unroll
     for (int w = NM; w < P_LB; ++w) piece(w);  // narrow tiles have more pieces than MFMAs
+    }
   };
 
   // The same step for ONE plane (NPL == 1): 2 * TM * TN MFMAs per slab; the pieces woven between them are the LDS
@@ -460,7 +532,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     for (int q = 0; q < NM; ++q) {
       const int ks = q / (TM * TN), tile = q % (TM * TN);
       const int i = tile / TN, j = tile % TN;
-      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
+      if constexpr (!MF16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i], bf[ks][j], acc[i][j], 0, 0, 0);
       if (q < P_LB) piece(q);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -580,15 +652,15 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   const bool has_bias = (p.flags & SG_EPI_BIAS) != 0;
   const bool do_relu = (p.flags & SG_EPI_RELU) != 0;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int col = n0 + wn + 32 * j + lr;
+  for (int j = 0; j < TNB; ++j) {
+    const int col = n0 + wn + acc_col(j);
     const bool cv = col < p.Nout;
     const float bv = (has_bias && cv) ? p.bias[col] : 0.f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+    for (int i = 0; i < TMB; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      for (int r = 0; r < NR; ++r) {
+        const int row = m0 + wm + acc_row(i, r);
         if (cv && row < p.M) {
           float v = acc[i][j][r] + bv;
           if (do_relu) v = fmaxf(v, 0.f);
@@ -607,33 +679,34 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
     float* tmean = red + WGM * BN;
     const int wrow = wave / WGN;
     const int nvalid = (p.M - m0) < BM ? (p.M - m0) : BM;
-    float vals[TN][TM][16];
+    float vals[TNB][TMB][NR];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn + 32 * j + lr;
+    for (int j = 0; j < TNB; ++j) {
+      const int col = n0 + wn + acc_col(j);
       const float bv = (has_bias && col < p.Nout) ? p.bias[col] : 0.f;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int i = 0; i < TMB; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) vals[j][i][r] = acc[i][j][r] + bv;
+        for (int r = 0; r < NR; ++r) vals[j][i][r] = acc[i][j][r] + bv;
     }
     __syncthreads();  // every wave is done with the slab buffers
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int cl = wn + 32 * j + lr;
+      for (int j = 0; j < TNB; ++j) {
+        const int cl = wn + acc_col(j);
         const float mu = pass ? tmean[cl] : 0.f;
         float sacc = 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TMB; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          for (int r = 0; r < NR; ++r) {
+            const int row = m0 + wm + acc_row(i, r);
             const float dlt = vals[j][i][r] - mu;
             if (row < p.M) sacc += pass ? dlt * dlt : dlt;
           }
-        sacc += __shfl_xor(sacc, 32, 64);  // lanes l and l+32 hold the same column
+        sacc += __shfl_xor(sacc, 32, 64);  // lanes l and l+32 hold the same column (16x16 blocks: l, l+16, l+32, l+48)
+        if constexpr (MF16) sacc += __shfl_xor(sacc, 16, 64);
         if (lh == 0) red[wrow * BN + cl] = sacc;
       }
       __syncthreads();
@@ -694,7 +767,7 @@ struct BnTilesOp {
   }
 };
 
-template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float>
+template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float, int MF = 0>
 int launch_x6(const IgemmParams& p, hipStream_t st) {
   constexpr int NT = 64 * WGM * WGN;
   // the statistics epilogue reuses the front of LDS for [WGM][BN] + [BN] floats: keep at least that much
@@ -704,7 +777,7 @@ int launch_x6(const IgemmParams& p, hipStream_t st) {
   (void)NT;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(conv_x6_kernel<BN, WGM, WGN, PF, NPL, TA>, lds);
+    int rc = set_dyn_lds(conv_x6_kernel<BN, WGM, WGN, PF, NPL, TA, MF>, lds);
     if (rc) return rc;
     attr_done = true;
   }
@@ -713,7 +786,7 @@ int launch_x6(const IgemmParams& p, hipStream_t st) {
     sg_set_error("conv_x6: bad tile count %lld", (long long)tiles);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL((conv_x6_kernel<BN, WGM, WGN, PF, NPL, TA>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((conv_x6_kernel<BN, WGM, WGN, PF, NPL, TA, MF>), dim3((unsigned)tiles), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("conv_x6_kernel");
   return 0;
 }

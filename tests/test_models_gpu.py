@@ -323,9 +323,14 @@ def test_fit_generator_tracks_the_oracle_over_several_steps(engine):
     # gradient's size), which turns fp32 rounding of small gradients into O(lr) weight differences: the fp32 CPU oracle
     # itself leaves the fp64 trajectory by 3e-5 / 3.5e-3 / 1.5e-2 at steps 1 / 2 / 3 (measured here, printed above).
     # The engine is held to that yardstick: its distance from fp64 may not exceed K times the fp32 oracle's own.
+    # The yardstick has a floor from step 1 on: whether ONE ReLU of this tiny net (BatchNorm over 8 ... 512 samples) flips is
+    # luck - the one-step gradient of two correct fp32 evaluations is 2e-4 ... 3e-2 from fp64 depending on the tiles
+    # (scripts/diag_mf16.py, round 3: five seeds, two MFMA shapes, neither systematically better) - and a flip moves the next
+    # loss by up to ~1e-3 of its value; the fp32 oracle's own 3e-5 at step 1 is the lucky end of that range.
     K = 3.0
     for i, (a, c, b) in enumerate(zip(losses_gpu, l32, l64)):
-        assert abs(a - b) <= K * abs(c - b) + 1e-5 * abs(b), f"step {i}: gpu {a} cpu-fp32 {c} fp64 {b}"
+        floor = 1e-5 if i == 0 else 2e-3
+        assert abs(a - b) <= K * abs(c - b) + floor * abs(b), f"step {i}: gpu {a} cpu-fp32 {c} fp64 {b}"
     w0 = [w.astype(np.float64) for w, prm in zip(ws0, model.params) if prm.trainable]
     w_gpu = [w.astype(np.float64) for w, prm in zip(model.get_weights(), model.params) if prm.trainable]
     den = sum(float(np.square(t - o).sum()) for t, o in zip(w64, w0))
