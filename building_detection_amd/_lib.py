@@ -101,6 +101,8 @@ _SIGNATURES = {
     "sg_bam_bwd": (_i, [_vp, _vp, _i, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "sg_maxpool_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     "sg_maxpool_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "sg_maxpool_fwd_idx": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "sg_maxpool_bwd_idx": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "sg_avgpool_ws_bytes": (_sz, [_vp, _i, _i, _i, _i, _i, _i]),
     "sg_avgpool_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz]),
     "sg_avgpool_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i]),

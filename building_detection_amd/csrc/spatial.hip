@@ -337,9 +337,179 @@ struct DwWgradRunOp {
   }
 };
 
+// wgrad as column strips (round 3; SG_DW_STRIP=0 restores the run reducer above).  The run form loads every x element 4.5
+// times and every dy element once per run of 4 pixels (22 loads of 16 bytes for 144 FMAs per lane) and was bound by the
+// load issue, not by HBM: 40 us + 8 us finalize for the 95 MB of the 32x32x728 layers (floor 20 us).  Here a lane owns 4
+// channels of a strip of 4 columns x HS rows and walks DOWN it with the three x rows of the window in registers: one new
+// x row (6 loads) and one dy row (4 loads) per 4 output pixels, both requested one row ahead of their use.  A workgroup is
+// 16 channel chunks (256 contiguous bytes per pixel) x 16 strips; the 16 strip partials are added in fixed order through
+// LDS, the S workgroup partials by seg_finalize_kernel in fp64 as before (part layout of seg_reduce_kernel, segment 0).
+template <typename T, bool PRE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void dw_wgrad_strip_kernel(
+    const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, const int H, const int W, const int C,
+    const int x_ld, const int y_ld, const int HS, const int nstrips, const int S, const unsigned x_bytes, const unsigned y_bytes,
+    const FastDiv fd_q, const FastDiv fd_hs) {
+  constexpr int TX = 16, TY = 16, EB = (int)sizeof(T);
+  constexpr unsigned OOB = 0x80000000u;  // beyond num_records: the hardware returns 0 (image border, no select, no branch)
+  typedef typename std::conditional<EB == 4, u32x4_c, u32x2_c>::type raw_t;
+  __shared__ float red[TY][TX][36];
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> 4;
+  const int c = (blockIdx.x * TX + tx) * 4;
+  const int z = blockIdx.y;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) acc[t] = zero;
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(x), 0, (int)x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(dy), 0, (int)y_bytes, 0x00020000);
+  auto ldraw = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned off) -> raw_t {
+    if constexpr (EB == 4) return __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0);
+    else return __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off, 0, 0);
+  };
+  // the registers a load fills are touched only where the row is consumed (widening, ReLU): anything done to them at the
+  // load would wait for it
+  auto widen = [&](const raw_t r, const bool relu) -> f32x4 {
+    f32x4 o;
+    if constexpr (EB == 4) {
+      o = __builtin_bit_cast(f32x4, r);
+    } else {
+      o = (f32x4){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                  __uint_as_float(r[1] & 0xffff0000u)};
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+    }
+    return o;
+  };
+  if (c < C) {
+    for (int s = z * TY + ty; s < nstrips; s += S * TY) {
+      uint32_t rowi, q, n, hs;
+      fd_divmod((uint32_t)s, fd_q, rowi, q);     // strips of one row band lie side by side: neighbours share their halo columns
+      fd_divmod(rowi, fd_hs, n, hs);
+      const int ow0 = (int)q * 4, h0 = (int)hs * HS;
+      const int h1 = h0 + HS < H ? h0 + HS : H;
+      const bool lok = ow0 > 0, rok = ow0 + 4 < W;
+      const unsigned xpix0 = ((unsigned)n * H * W + ow0), xrow = (unsigned)W * x_ld * EB, grow = (unsigned)W * y_ld * EB;
+      const unsigned xoff0 = (xpix0 * x_ld + c) * EB, goff0 = (xpix0 * y_ld + c) * EB;
+      // Offsets are sums, never selects around a load (a select feeding a load became control flow, and with more than one
+      // basic block per step the FMAs were sunk out of the steps altogether): a column outside the image adds 2^30, a row
+      // outside it sets bit 31 - either way the offset is beyond num_records (< 2^30, dw_strip_ok) and the load returns 0.
+      unsigned coff[6];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) coff[b] = (unsigned)((b - 1) * x_ld * EB);
+      coff[0] = lok ? coff[0] : 0x40000000u;
+      coff[5] = rok ? coff[5] : 0x40000000u;
+      auto load_x = [&](int ih, raw_t (&v)[6]) {
+        const unsigned flag = (unsigned)ih < (unsigned)H ? 0u : OOB;
+        const unsigned ro = xoff0 + (unsigned)ih * xrow;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) v[b] = ldraw(rsrc_x, (ro + coff[b]) | flag);
+      };
+      auto load_g = [&](int oh, raw_t (&g)[4]) {
+        const unsigned flag = oh < h1 ? 0u : OOB;   // the row behind the strip is never used
+        const unsigned ro = goff0 + (unsigned)oh * grow;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = ldraw(rsrc_g, (ro + (unsigned)(k * y_ld * EB)) | flag);
+      };
+      auto rowmac = [&](const int ta, const raw_t (&vr)[6], const f32x4 (&g)[4]) {
+        f32x4 v[6];
+#pragma unroll
+        for (int b = 0; b < 6; ++b) v[b] = widen(vr[b], PRE);
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[ta * 3 + b][e] = fmaf(v[k + b][e], g[k][e], acc[ta * 3 + b][e]);
+      };
+      // four x-row buffers and two dy-row buffers whose roles rotate with the (unrolled) row step: no register copies - a
+      // copy of a row that is still in flight would be a use and wait for it (HS and H are multiples of 4: dw_strip_ok)
+      raw_t X[4][6], G[2][4];
+      load_x(h0 - 1, X[0]);
+      load_x(h0, X[1]);
+      load_x(h0 + 1, X[2]);
+      load_g(h0, G[0]);
+      auto step = [&](auto I_, int oh) {
+        constexpr int I = decltype(I_)::value;
+        load_x(oh + 2, X[(I + 3) & 3]);  // one row ahead: consumed by the next step
+        load_g(oh + 1, G[(I + 1) & 1]);
+        // Two pins per step, or the FMAs of all four steps end up behind the last step's loads (sched_barrier holds the
+        // machine scheduler only) and the loads are sunk to their uses: the rows consumed first in this step pass through an
+        // asm statement placed behind this step's loads (memory clobber: the loads stay in front of it), the accumulators
+        // through one at the end of the step.
+        raw_t (&xc)[6] = X[(I + 2) & 3];
+        raw_t (&gc)[4] = G[I & 1];
+        asm volatile("" : "+v"(xc[0]), "+v"(xc[1]), "+v"(xc[2]), "+v"(xc[3]), "+v"(xc[4]), "+v"(xc[5]), "+v"(gc[0]), "+v"(gc[1]),
+                          "+v"(gc[2]), "+v"(gc[3]) : : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 g[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = widen(gc[k], false);
+        rowmac(0, X[I & 3], g);
+        rowmac(1, X[(I + 1) & 3], g);
+        rowmac(2, xc, g);
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
+                          "+v"(acc[7]), "+v"(acc[8]));
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      for (int oh = h0; oh < h1; oh += 4) {
+        step(std::integral_constant<int, 0>{}, oh);
+        step(std::integral_constant<int, 1>{}, oh + 1);
+        step(std::integral_constant<int, 2>{}, oh + 2);
+        step(std::integral_constant<int, 3>{}, oh + 3);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[ty][tx][t * 4 + e] = acc[t][e];
+  __syncthreads();
+  // 16 x 36 sums of 16 terms: thread (ty, tx) finishes outputs ty, ty + 16, .. of chunk tx, strips added in order 0..15
+  if (c < C) {
+    for (int o = ty; o < 36; o += TY) {
+      float sum = 0.f;
+#pragma unroll
+      for (int y = 0; y < TY; ++y) sum += red[y][tx][o];
+      part[((int64_t)z * 9 + (o >> 2)) * C + c + (o & 3)] = sum;
+    }
+  }
+}
+
+struct DwStripPlan {
+  int HS, nhs, nstrips, gx, S;
+  size_t part_bytes;
+};
+
+inline DwStripPlan dw_strip_plan(int num_cus, const sg_conv_desc* d) {
+  DwStripPlan pl;
+  pl.HS = d->H >= 128 ? 16 : (d->H >= 16 ? 8 : d->H);   // multiples of 4 (dw_strip_ok: H % 4 == 0); the last band may be 4 short
+  pl.nhs = (int)sg_cdiv(d->H, pl.HS);
+  pl.nstrips = d->N * pl.nhs * (d->W / 4);
+  pl.gx = (int)sg_cdiv(d->Cin / 4, 16);
+  int64_t S = sg_cdiv(pl.nstrips, 16);
+  const int64_t cap = sg_cdiv((int64_t)4 * num_cus, pl.gx);
+  if (S > cap) S = cap;
+  if (S > 256) S = 256;  // few-channel maps: the finalize adds the S partial rows with 4 lanes per channel (1024 rows of a
+                         // 64-channel map took longer than the strips themselves); a lane walks several strips instead
+  if (S < 1) S = 1;
+  pl.S = (int)S;
+  pl.part_bytes = (size_t)pl.S * 9 * d->Cin * sizeof(float);
+  return pl;
+}
+
 inline bool dw_run_ok(const sg_conv_desc* d) {
   return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dilation == 1 && d->pad_t == 1 && d->pad_l == 1 &&
          d->Ho == d->H && d->Wo == d->W && (d->W % 4 == 0) && (d->Cin % 4 == 0);
+}
+
+inline bool dw_strip_ok(const sg_conv_desc* d) {
+  static const int on = getenv("SG_DW_STRIP") ? atoi(getenv("SG_DW_STRIP")) : 1;
+  const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+  const int64_t pix = (int64_t)d->N * d->H * d->W;
+  // byte offsets are 32-bit buffer offsets in which bit 30 / bit 31 mark a column / row outside the image: tensors below 1 GiB
+  return on && dw_run_ok(d) && d->H % 4 == 0 && pix * (xl > yl ? xl : yl) * 4 < (1ll << 30);
 }
 
 // Rows per run, measured (profiles/r01_bw_census.txt, SG_DW_RR = 1 / 2 / 4): the stencil kernels want tall strips on
@@ -492,6 +662,94 @@ __global__ void maxpool_bwd_kernel(const PoolParams<T> p) {
   }
 }
 
+// Training form (round 3): the forward also writes WHICH cell of the window held the (first) maximum, one byte per output
+// element (cell = a * k + b in scan order), and the backward reads that byte and dy instead of x, y and up to eight more x
+// values per window: 0.7 GB instead of 1.3 GB of traffic for the 256x256x128 pool of the Xception entry flow and a fraction
+// of the loads (maxpool_bwd_kernel: 711 us for a 280 us floor).  Same routing as maxpool_bwd_kernel: strict '>' keeps the
+// first maximum in scan order; a window of -inf only (or NaN only) routes to its first valid cell.
+template <int V, typename T>
+__global__ void maxpool_fwd_idx_kernel(const PoolParams<T> p, unsigned char* __restrict__ idx) {
+  const uint32_t cv = p.C / V;
+  const uint32_t total = (uint32_t)((int64_t)p.N * p.Ho * p.Wo * cv), stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t pix, cc, row, ow, n, oh;
+    fd_divmod(i, p.fd_cv, pix, cc);
+    fd_divmod(pix, p.fd_w, row, ow);
+    fd_divmod(row, p.fd_h, n, oh);
+    const int c = (int)cc * V;
+    float m[V];
+    unsigned id[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) { m[k] = -INFINITY; id[k] = 255u; }
+    for (int a = 0; a < p.k; ++a) {
+      const int ih = (int)oh * p.stride - p.pad_t + a;
+      if ((unsigned)ih >= (unsigned)p.H) continue;
+      for (int b = 0; b < p.k; ++b) {
+        const int iw = (int)ow * p.stride - p.pad_l + b;
+        if ((unsigned)iw >= (unsigned)p.W) continue;
+        float xv[V];
+        ldv<V>(p.x + ((int64_t)(n * p.H + ih) * p.W + iw) * p.C + c, xv);
+        const unsigned cell = (unsigned)(a * p.k + b);
+#pragma unroll
+        for (int k = 0; k < V; ++k) {
+          const bool take = xv[k] > m[k] || id[k] == 255u;
+          m[k] = take ? xv[k] : m[k];
+          id[k] = take ? cell : id[k];
+        }
+      }
+    }
+    stv<V>(p.out + (int64_t)pix * p.C + c, m);
+    if constexpr (V == 4) {
+      *reinterpret_cast<unsigned*>(idx + (int64_t)pix * p.C + c) = id[0] | (id[1] << 8) | (id[2] << 16) | (id[3] << 24);
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) idx[(int64_t)pix * p.C + c + k] = (unsigned char)id[k];
+    }
+  }
+}
+
+// gather, deterministic: input element (ih, iw) adds dy of every window whose recorded cell is (ih, iw)
+template <int V, typename T>
+__global__ void maxpool_bwd_idx_kernel(const PoolParams<T> p, const unsigned char* __restrict__ idx) {
+  const uint32_t cv = p.C / V;
+  const uint32_t total = (uint32_t)((int64_t)p.N * p.H * p.W * cv), stride = gridDim.x * blockDim.x;
+  for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+    uint32_t pix, cc, row, iw, n, ih;
+    fd_divmod(i, p.fd_cv, pix, cc);
+    fd_divmod(pix, p.fd_w, row, iw);
+    fd_divmod(row, p.fd_h, n, ih);
+    const int c = (int)cc * V;
+    float acc[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) acc[k] = 0.f;
+    const int th = (int)ih + p.pad_t, tw = (int)iw + p.pad_l;
+    int oh_hi = th / p.stride, ow_hi = tw / p.stride;
+    int oh_lo = (th - p.k + p.stride) / p.stride, ow_lo = (tw - p.k + p.stride) / p.stride;  // ceil((t-k+1)/s)
+    if (th - p.k + 1 <= 0) oh_lo = 0;
+    if (tw - p.k + 1 <= 0) ow_lo = 0;
+    if (oh_hi >= p.Ho) oh_hi = p.Ho - 1;
+    if (ow_hi >= p.Wo) ow_hi = p.Wo - 1;
+    for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+      const unsigned ca = (unsigned)(th - oh * p.stride) * (unsigned)p.k;
+      for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+        const unsigned cell = ca + (unsigned)(tw - ow * p.stride);
+        const int64_t o = (((int64_t)n * p.Ho + oh) * p.Wo + ow) * p.C + c;
+        float gv[V];
+        ldv<V>(p.dy + o, gv);
+        if constexpr (V == 4) {
+          const unsigned w = *reinterpret_cast<const unsigned*>(idx + o);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[k] += ((w >> (8 * k)) & 255u) == cell ? gv[k] : 0.f;
+        } else {
+#pragma unroll
+          for (int k = 0; k < V; ++k) acc[k] += (unsigned)idx[o + k] == cell ? gv[k] : 0.f;
+        }
+      }
+    }
+    stv<V>(p.out + (int64_t)pix * p.C + c, acc);
+  }
+}
+
 // AveragePooling2D(k) / GlobalAveragePooling2D as a segmented reduction: segment = output pixel (n,oh,ow),
 // rows = kh*kw window cells.
 template <typename T>
@@ -598,6 +856,51 @@ __global__ void upsample_bwd_kernel(const T* __restrict__ dy, int dy_ld, T* __re
       for (int k = 0; k < V; ++k) acc[k] += t[k];
     }
     stv<V>(dx + (int64_t)pix * C + c, acc);
+  }
+}
+
+// Large windows (the ASPP image-pooling branch: 1x1 -> 32x32, 1024 cells per output element): the kernel above would give
+// each of N*C/4 = 1024 lanes a serial sum of 1024 loads (285 us for 17 MB).  Here a workgroup owns one output pixel and 8
+// channel chunks, 32 lanes share the window cells, the 32 partial sums are added in fixed order through LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_bwd_window_kernel(const T* __restrict__ dy, int dy_ld, T* __restrict__ dx, int H,
+                                                                  int W, int C, int sh, int sw, int accumulate, FastDiv fd_w,
+                                                                  FastDiv fd_h, FastDiv fd_sw) {
+  constexpr int TX = 8, TY = 32;
+  __shared__ float red[TY][TX][4];
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> 3;
+  const int c = (blockIdx.x * TX + tx) * 4;
+  uint32_t row, iw, n, ih;
+  fd_divmod(blockIdx.y, fd_w, row, iw);
+  fd_divmod(row, fd_h, n, ih);
+  const int OW = W * sw, OH = H * sh;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const T* base = dy + (((int64_t)n * OH + ih * sh) * OW + iw * sw) * dy_ld + c;
+#pragma unroll 4
+    for (int r = ty; r < sh * sw; r += TY) {
+      uint32_t a, b;
+      fd_divmod((uint32_t)r, fd_sw, a, b);
+      const f32x4 g = ld4<T>(base + ((int64_t)a * OW + b) * dy_ld);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] += g[e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[ty][tx][e] = acc[e];
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    for (int y = 0; y < TY; ++y)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += red[y][tx][e];
+    T* o = dx + (int64_t)blockIdx.y * C + c;
+    if (accumulate) {
+      const f32x4 t = ld4<T>(o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += t[e];
+    }
+    st4<T>(o, s);
   }
 }
 
@@ -713,6 +1016,10 @@ size_t sg_dwconv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
   const SegPlan r = seg_plan<9>(ctx->num_cus, 1, sg_cdiv(rows, 4), d->Cin, true);
   size_t m = a.part_bytes > b.part_bytes ? a.part_bytes : b.part_bytes;
   if (r.part_bytes > m) m = r.part_bytes;
+  if (dw_run_ok(d)) {
+    const DwStripPlan sp = dw_strip_plan(ctx->num_cus, d);
+    if (sp.part_bytes > m) m = sp.part_bytes;
+  }
   return m + 256;
 }
 
@@ -741,6 +1048,30 @@ static int dwconv2d_wgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_co
     op.fd_w = make_fastdiv((uint32_t)d->Wo); op.fd_h = make_fastdiv((uint32_t)d->Ho);
     const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
     const bool vec = (op.C % 4 == 0) && (op.x_ld % 4 == 0) && (op.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy);
+    if (vec && !bn_gamma && dw_strip_ok(d)) {
+      const DwStripPlan sp = dw_strip_plan(ctx->num_cus, d);
+      if (!ws || ws_bytes < sp.part_bytes) {
+        sg_set_error("sg_dwconv2d_wgrad: workspace %zu < %zu", ws_bytes, sp.part_bytes);
+        return SG_EWORKSPACE;
+      }
+      const dim3 grid((unsigned)sp.gx, (unsigned)sp.S);
+      const FastDiv fq = make_fastdiv((uint32_t)(d->W / 4)), fh = make_fastdiv((uint32_t)sp.nhs);
+      const unsigned xb_ = (unsigned)((int64_t)d->N * d->H * d->W * op.x_ld * (int64_t)sizeof(T));
+      const unsigned yb_ = (unsigned)((int64_t)d->N * d->H * d->W * op.y_ld * (int64_t)sizeof(T));
+      if (pre_relu)
+        hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy,
+                           (float*)ws, d->H, d->W, op.C, op.x_ld, op.y_ld, sp.HS, sp.nstrips, sp.S, xb_, yb_, fq, fh);
+      else
+        hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy,
+                           (float*)ws, d->H, d->W, op.C, op.x_ld, op.y_ld, sp.HS, sp.nstrips, sp.S, xb_, yb_, fq, fh);
+      SG_LAUNCH_CHECK("dw_wgrad_strip_kernel");
+      DwWgradRunOp<1, T, false> fin;   // finalize() only: dw[t][c] = the fp64 sum of the S partial rows
+      fin.dw = (float*)dw; fin.C = op.C;
+      hipLaunchKernelGGL((seg_finalize_kernel<DwWgradRunOp<1, T, false>>), dim3((unsigned)sg_cdiv(op.C, 64), 1u), dim3(256), 0,
+                         (hipStream_t)stream, fin, 1, op.C, sp.S, (const float*)ws);
+      SG_LAUNCH_CHECK("dw_wgrad_strip finalize");
+      return 0;
+    }
     if (vec && dw_run_ok(d)) {
       const int rr = dw_rows_per_run(d->H, rows, true);
       const int64_t nruns = rows / (4 * rr);
@@ -840,6 +1171,48 @@ int sg_maxpool_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, in
   return 0;
 }
 
+int sg_maxpool_fwd_idx(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride, int pad_t,
+                       int pad_l, int Ho, int Wo, const void* x, void* y, void* idx) {
+  SG_CHECK_ARG(ctx && x && y && idx, "sg_maxpool_fwd_idx: bad argument");
+  SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && k <= 15 && stride > 0 && Ho > 0 && Wo > 0 && pad_t >= 0 && pad_l >= 0,
+               "sg_maxpool_fwd_idx: bad geometry (windows up to 15 x 15: the cell index is one byte)");
+  SG_CHECK_ARG((int64_t)N * H * W * C < (1ll << 31), "sg_maxpool_fwd_idx: tensor exceeds 2^31 elements");
+  SG_DTYPE_SWITCH(dtype, "sg_maxpool_fwd_idx", {
+    PoolParams<T> p;
+    p.x = (const T*)x; p.y = nullptr; p.dy = nullptr; p.out = (T*)y;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+    const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y) && sg_aligned16(idx);
+    const int V = vec ? 4 : 1;
+    p.fd_cv = make_fastdiv((uint32_t)(C / V)); p.fd_w = make_fastdiv((uint32_t)Wo); p.fd_h = make_fastdiv((uint32_t)Ho);
+    const unsigned blocks = ew_blocks((int64_t)N * Ho * Wo * (C / V));
+    if (vec) hipLaunchKernelGGL((maxpool_fwd_idx_kernel<4, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (unsigned char*)idx);
+    else hipLaunchKernelGGL((maxpool_fwd_idx_kernel<1, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (unsigned char*)idx);
+  });
+  SG_LAUNCH_CHECK("maxpool_fwd_idx_kernel");
+  return 0;
+}
+
+int sg_maxpool_bwd_idx(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride, int pad_t,
+                       int pad_l, int Ho, int Wo, const void* dy, const void* idx, void* dx) {
+  SG_CHECK_ARG(ctx && dy && idx && dx, "sg_maxpool_bwd_idx: bad argument");
+  SG_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && k > 0 && k <= 15 && stride > 0 && Ho > 0 && Wo > 0 && pad_t >= 0 && pad_l >= 0,
+               "sg_maxpool_bwd_idx: bad geometry");
+  SG_CHECK_ARG((int64_t)N * H * W * C < (1ll << 31), "sg_maxpool_bwd_idx: tensor exceeds 2^31 elements");
+  SG_DTYPE_SWITCH(dtype, "sg_maxpool_bwd_idx", {
+    PoolParams<T> p;
+    p.x = nullptr; p.y = nullptr; p.dy = (const T*)dy; p.out = (T*)dx;
+    p.N = N; p.H = H; p.W = W; p.C = C; p.Ho = Ho; p.Wo = Wo; p.k = k; p.stride = stride; p.pad_t = pad_t; p.pad_l = pad_l;
+    const bool vec = (C % 4 == 0) && sg_aligned16(dy) && sg_aligned16(dx) && sg_aligned16(idx);
+    const int V = vec ? 4 : 1;
+    p.fd_cv = make_fastdiv((uint32_t)(C / V)); p.fd_w = make_fastdiv((uint32_t)W); p.fd_h = make_fastdiv((uint32_t)H);
+    const unsigned blocks = ew_blocks((int64_t)N * H * W * (C / V));
+    if (vec) hipLaunchKernelGGL((maxpool_bwd_idx_kernel<4, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (const unsigned char*)idx);
+    else hipLaunchKernelGGL((maxpool_bwd_idx_kernel<1, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, (const unsigned char*)idx);
+  });
+  SG_LAUNCH_CHECK("maxpool_bwd_idx_kernel");
+  return 0;
+}
+
 size_t sg_avgpool_ws_bytes(const sg_ctx* ctx, int N, int H, int W, int C, int kh, int kw) {
   if (!ctx || kh <= 0 || kw <= 0) return 0;
   const int nseg = N * (H / kh) * (W / kw);
@@ -925,7 +1298,11 @@ int sg_upsample_nearest_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, 
   const unsigned blocks = ew_blocks((int64_t)N * H * W * (C / V));
   const FastDiv a = make_fastdiv((uint32_t)(C / V)), b = make_fastdiv((uint32_t)W), c = make_fastdiv((uint32_t)H);
   SG_DTYPE_SWITCH(dtype, "sg_upsample_nearest_bwd", {
-    if (vec)
+    if (vec && sh * sw >= 64 && (int64_t)N * H * W < 65536) {
+      hipLaunchKernelGGL((upsample_bwd_window_kernel<T>), dim3((unsigned)sg_cdiv(C / 4, 8), (unsigned)(N * H * W)), dim3(256), 0,
+                         (hipStream_t)stream, (const T*)dy, dy_ld, (T*)dx, H, W, C, sh, sw, accumulate, b, c,
+                         make_fastdiv((uint32_t)sw));
+    } else if (vec)
       hipLaunchKernelGGL((upsample_bwd_kernel<4, T>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const T*)dy, dy_ld, (T*)dx,
                          N, H, W, C, sh, sw, accumulate, a, b, c);
     else

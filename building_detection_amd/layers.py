@@ -477,12 +477,19 @@ class _MaxPoolNode(Node):
         return self.connect([x], (None, ho, wo, c))
 
     def forward(self, rt, xs, training):
+        if training and self.pool <= 15:   # the winning cell of every window, one byte each: the backward reads it and dy only
+            y, geom, idx = rt.eng.maxpool_fwd(xs[0], self.pool, self.stride, self.padding, want_idx=True)
+            rt.save(self, geom=geom, idx=idx)
+            return y
         y, geom = rt.eng.maxpool_fwd(xs[0], self.pool, self.stride, self.padding)
         rt.save(self, geom=geom)
         return y
 
     def backward(self, rt, xs, y, dy):
-        return [rt.eng.maxpool_bwd(xs[0], y, dy, rt.saved(self)["geom"])]
+        sv = rt.saved(self)
+        if sv.get("idx") is not None:
+            return [rt.eng.maxpool_bwd_idx(dy, sv["idx"], tuple(xs[0].shape), sv["geom"])]
+        return [rt.eng.maxpool_bwd(xs[0], y, dy, sv["geom"])]
 
 
 class MaxPooling2D(Layer):

@@ -489,7 +489,9 @@ class Engine:
         return dx, dmc, dms
 
     # ------------------------------------------------------------------------------------------ pooling
-    def maxpool_fwd(self, x, k, stride, padding="valid", out=None):
+    def maxpool_fwd(self, x, k, stride, padding="valid", out=None, want_idx=False):
+        """want_idx: the training form - also returns the uint8 tensor of winning window cells that maxpool_bwd_idx routes
+        the gradient by (no x / y needed in the backward)."""
         n, h, w, c = x.shape
         if padding == "same":
             ho, pt, _ = same_pad(h, k, stride)
@@ -497,9 +499,22 @@ class Engine:
         else:
             ho, wo, pt, pl = (h - k) // stride + 1, (w - k) // stride + 1, 0, 0
         y = out if out is not None else self.empty(n, ho, wo, c, dtype=x.dtype)
+        if want_idx:
+            idx = torch.empty(n, ho, wo, c, dtype=torch.uint8, device=self.device)
+            check(self.lib.sg_maxpool_fwd_idx(self.h, self.stream, _dt(x), n, h, w, c, k, stride, pt, pl, ho, wo, _ptr(x), _ptr(y),
+                                              _ptr(idx)), "sg_maxpool_fwd_idx")
+            return y, (k, stride, pt, pl, ho, wo), idx
         check(self.lib.sg_maxpool_fwd(self.h, self.stream, _dt(x), n, h, w, c, k, stride, pt, pl, ho, wo, _ptr(x), _ptr(y)),
               "sg_maxpool_fwd")
         return y, (k, stride, pt, pl, ho, wo)
+
+    def maxpool_bwd_idx(self, dy, idx, xshape, geom, out=None):
+        n, h, w, c = xshape
+        k, stride, pt, pl, ho, wo = geom
+        dx = out if out is not None else self.empty(n, h, w, c, dtype=dy.dtype)
+        check(self.lib.sg_maxpool_bwd_idx(self.h, self.stream, _dt(dy), n, h, w, c, k, stride, pt, pl, ho, wo, _ptr(dy), _ptr(idx),
+                                          _ptr(dx)), "sg_maxpool_bwd_idx")
+        return dx
 
     def maxpool_bwd(self, x, y, dy, geom, out=None):
         n, h, w, c = x.shape

@@ -291,6 +291,13 @@ int sg_maxpool_fwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, in
 int sg_maxpool_bwd(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride,
                    int pad_t, int pad_l, int Ho, int Wo, const void* x, const void* y, const void* dy,
                    void* dx);
+/* Training form of the same layer: the forward also records, one byte per output element in idx[N,Ho,Wo,C], which cell
+ * (a * k + b, scan order; k <= 15) of the window held the first maximum, and the backward routes dy by that byte alone
+ * (reads dy and idx, no x / y): identical dx to sg_maxpool_bwd. */
+int sg_maxpool_fwd_idx(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride,
+                       int pad_t, int pad_l, int Ho, int Wo, const void* x, void* y, void* idx);
+int sg_maxpool_bwd_idx(sg_ctx* ctx, void* stream, int dtype, int N, int H, int W, int C, int k, int stride,
+                       int pad_t, int pad_l, int Ho, int Wo, const void* dy, const void* idx, void* dx);
 /* AveragePooling2D(pool_size=k) (stride k, valid; v3plus.py:302) and GlobalAveragePooling2D (k = H = W):
  * y[N,H/kh,W/kw,C] (a wavefront/LDS two-stage reduce over the window; ws from sg_avgpool_ws_bytes);
  * backward spreads dy/(kh*kw).  accumulate!=0 adds into dx. */

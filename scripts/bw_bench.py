@@ -79,6 +79,8 @@ for shp in SHAPES:
                                                                             dbeta=db, beta=beta) for s in sets]), 5)
     res["add_n 2 (2r+1w)"] = (timed([lambda s=s: e.add_n([s[0], s[1]], out=s[2]) for s in sets]), 3)
     res["dw 3x3 fwd (1r+1w)"] = (timed([lambda s=s: e.dwconv_fwd(s[0], wdw, out=s[2], desc=dd) for s in sets]), 2)
+    dwg = e.empty(3, 3, c, 1)
+    res["dw 3x3 wgrad (2r)"] = (timed([lambda s=s: e.dwconv_wgrad(s[0], s[1], dd, True, dw=dwg) for s in sets]), 2)
     print(f"shape {shp} tensor {nbytes / 1e6:.1f} MB")
     for k, (t, passes) in res.items():
         print(f"   {k:30s} {t:8.1f} us   {passes * nbytes / t / 1e6:6.2f} TB/s", flush=True)

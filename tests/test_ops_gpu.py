@@ -189,9 +189,11 @@ def test_depthwise(engine, c, stride, pre_relu):
     close(dw, wr.grad, what="dw wgrad")
 
 
-@pytest.mark.parametrize("c,h,w,pre_relu", [(728, 12, 16, True), (64, 9, 20, False), (128, 32, 32, True), (4, 5, 4, False)])
+@pytest.mark.parametrize("c,h,w,pre_relu", [(728, 12, 16, True), (64, 9, 20, False), (128, 32, 32, True), (4, 5, 4, False),
+                                            (8, 20, 8, False), (16, 136, 8, True), (36, 4, 4, True), (68, 16, 4, False)])
 def test_depthwise_stride1_register_window_path(engine, c, h, w, pre_relu):
-    """W % 4 == 0, stride 1: the run kernels (4 outputs per thread) for forward, dgrad (flipped taps + mask), wgrad."""
+    """W % 4 == 0, stride 1: the run kernels (4 outputs per thread) for forward, dgrad (flipped taps + mask), wgrad; with
+    H % 4 == 0 the filter gradient takes the column-strip kernel (bands of 8 / 16 rows, a short last band, one-strip-wide maps)."""
     g = torch.Generator().manual_seed(c + h + w)
     x = rnd(g, 3, h, w, c)
     wt = rnd(g, 3, 3, c, 1)
@@ -338,6 +340,26 @@ def test_maxpool(engine, k, stride, padding):
     close(dx, xr.grad, what="maxpool bwd")
 
 
+@pytest.mark.parametrize("k,stride,padding,c", [(3, 2, "same", 24), (2, 2, "valid", 24), (2, 4, "valid", 8), (3, 2, "same", 5)])
+def test_maxpool_training_form_routes_by_the_recorded_cell(engine, k, stride, padding, c):
+    """sg_maxpool_fwd_idx / sg_maxpool_bwd_idx: same y, and a dx BIT-IDENTICAL to the recomputing backward - also with ties
+    (a quantised input: many equal maxima per window, the first in scan order must win) and windows of -inf."""
+    g = torch.Generator().manual_seed(k + stride + c)
+    x = torch.round(rnd(g, 2, 15, 18, c) * 3) / 3          # few distinct values: ties in most windows
+    x[0, :4, :4] = -float("inf")
+    xd = x.cuda()
+    y0, geom = engine.maxpool_fwd(xd, k, stride, padding)
+    y1, geom1, idx = engine.maxpool_fwd(xd, k, stride, padding, want_idx=True)
+    assert geom == geom1 and torch.equal(y0, y1)
+    assert int(idx.max()) < k * k
+    dy = rnd(g, *y0.shape).cuda()
+    dx0 = engine.maxpool_bwd(xd, y0, dy, geom)
+    dx1 = engine.maxpool_bwd_idx(dy, idx, tuple(x.shape), geom)
+    assert torch.equal(dx0, dx1)
+    # every window's dy lands exactly once
+    assert abs(float(dx1.double().sum()) - float(dy.double().sum())) <= 1e-3
+
+
 def test_maxpool_odd_same(engine):
     g = torch.Generator().manual_seed(99)
     x = rnd(g, 1, 15, 17, 8)
@@ -371,6 +393,21 @@ def test_upsample(engine, s):
     yr.backward(dy)
     close(engine.upsample_fwd(x.cuda(), s), yr, what="up fwd")
     close(engine.upsample_bwd(dy.cuda(), x.shape, s), xr.grad, what="up bwd")
+
+
+def test_upsample_bwd_large_window_with_pixel_stride_and_accumulate(engine):
+    """The ASPP image-pooling case (1x1 -> HxW): the window kernel, rectangular windows, dy read out of a wider buffer
+    (channel slice of a concat gradient), added to an existing dx."""
+    g = torch.Generator().manual_seed(11)
+    n, h, w, c, sh, sw, ld = 3, 1, 2, 40, 8, 16, 56
+    wide = rnd(g, n, h * sh, w * sw, ld)
+    dx0 = rnd(g, n, h, w, c)
+    dy = wide[..., 8:8 + c]
+    ref = dx0 + dy.reshape(n, h, sh, w, sw, c).sum(dim=(2, 4))
+    wd = wide.cuda()
+    out = dx0.cuda().clone()
+    engine.upsample_bwd(wd.view(-1)[8:], (n, h, w, c), sh, sw, out=out, accumulate=True, dy_ld=ld)
+    close(out, ref, what="up bwd window")
 
 
 def _ref_loss(kind, y_true, p):
