@@ -75,9 +75,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
   for (int j = 0; j < NA; ++j) {
     const int m = m0 + r0 + RS * j;
     if (m < p.M) {
-      uint32_t n, rem, oh, ow;
-      fd_divmod((uint32_t)m, p.fd_ohow, n, rem);
-      fd_divmod(rem, p.fd_ow, oh, ow);
+      uint32_t n, oh, ow;
+      row_to_pixel(p, (uint32_t)m, n, oh, ow);
       const int ohs = (int)oh * p.a_mul + p.off_h, ows = (int)ow * p.a_mul + p.off_w;
       row_lin_lds[j * NT + t] = (int)n * p.H * p.W + ohs * p.W + ows;
       row_hw[j] = (ohs << 16) | (ows & 0xffff);
@@ -203,7 +202,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
   const int spt = p.C / BKB;
   int nslab = (p.K + BKB - 1) / BKB;
   bool use_map = false;
-  if (p.skip_taps && ntaps > 1) {  // uniform
+  if (p.skip_taps && (ntaps > 1 || p.perm2)) {  // uniform
     int nact = 0;
     for (int tap = 0; tap < ntaps; ++tap) {
       uint32_t kh, kw;
@@ -221,8 +220,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
       }
     }
     __syncthreads();
-    nslab = __builtin_amdgcn_readfirstlane(nact) * spt;
-    use_map = true;
+    if (ntaps > 1) {
+      nslab = __builtin_amdgcn_readfirstlane(nact) * spt;
+      use_map = true;
+    } else if (__builtin_amdgcn_readfirstlane(nact) == 0) {
+      nslab = 0;  // a 1x1 stride-2 dgrad tile of a parity class no tap reaches: bias / zeros only
+    }
   }
   const int last = nslab - 1;
   const bool it_lin = ntaps <= 1;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
       const int rl = idx / CPT, c = idx - rl * CPT;
       const int row = m0 + rl, col = n0 + 8 * c;
       if (row < p.M && col < p.Nout)
-        *reinterpret_cast<u32x4_t*>(py + (int64_t)row * p.y_ld + col) = *reinterpret_cast<const u32x4_t*>(smem + rl * TP + c * 16);
+        *reinterpret_cast<u32x4_t*>(py + row_to_yoff(p, row) + col) = *reinterpret_cast<const u32x4_t*>(smem + rl * TP + c * 16);
     }
   } else {
 #pragma unroll
@@ -345,7 +348,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
           if (cv && row < p.M) {
             float v = acc[i][j][r] + bv;
             if (do_relu) v = fmaxf(v, 0.f);
-            st1<bf16_t>(py + (int64_t)row * p.y_ld + col, v);
+            st1<bf16_t>(py + row_to_yoff(p, row) + col, v);
           }
         }
       }

@@ -62,9 +62,40 @@ struct IgemmParams {
   int Kpad, Npad;
   int kd;  // k-block depth of the plane layout [npl][Kpad / kd][Npad][kd] (= the kernel's slab depth); 0: rows [npl][Npad][Kpad]
   float* __restrict__ stats;  // SG_EPI_BN_STATS: [tiles_m][2][Nout] per-tile (sum, centred sum of squares), else null
+  // Stride-2 dgrad (and Conv2DTranspose forward) with rows in PARITY-CLASS order (conv_x6_kernel / conv_b16_kernel only):
+  // GEMM row m = ((cls * N + n) * OH/2 + i) * OW/2 + j is output pixel (n, 2i + (cls >> 1), 2j + (cls & 1)).  Of the KH x KW
+  // taps only those of matching parity reach a pixel of class cls; in raster order a 128-row tile mixes the column
+  // parities, so every tap had a valid row and the tile multiplied all of them (3/4 of the products masked to zero).
+  // Class-pure tiles let the existing padding-tap elimination drop the taps of the other parities: a 3x3 kernel runs 1 / 2 /
+  // 2 / 4 taps instead of 9 four times, a 1x1 kernel one tap for a quarter of the tiles and none for the rest.
+  int perm2;
+  FastDiv fd_mc, fd_hcwc, fd_wc;
 };
 
 __device__ __forceinline__ int spt_of(const IgemmParams& p) { return p.C / BK; }  // slabs per tap (UT)
+
+// GEMM row -> output pixel coordinates (image, row, column); see IgemmParams::perm2
+__device__ __forceinline__ void row_to_pixel(const IgemmParams& p, uint32_t m, uint32_t& n, uint32_t& oh, uint32_t& ow) {
+  if (p.perm2) {
+    uint32_t cls, r, rem, i, j;
+    fd_divmod(m, p.fd_mc, cls, r);
+    fd_divmod(r, p.fd_hcwc, n, rem);
+    fd_divmod(rem, p.fd_wc, i, j);
+    oh = 2 * i + (cls >> 1);
+    ow = 2 * j + (cls & 1);
+  } else {
+    uint32_t rem;
+    fd_divmod(m, p.fd_ohow, n, rem);
+    fd_divmod(rem, p.fd_ow, oh, ow);
+  }
+}
+// element offset of GEMM row `row` in y
+__device__ __forceinline__ int64_t row_to_yoff(const IgemmParams& p, int row) {
+  if (!p.perm2) return (int64_t)row * p.y_ld;
+  uint32_t n, oh, ow;
+  row_to_pixel(p, (uint32_t)row, n, oh, ow);
+  return ((int64_t)(n * p.OH + oh) * p.OW + ow) * p.y_ld;
+}
 
 // UT ("uniform tap"): Cin % 32 == 0 or a 1x1 kernel, so every 32-deep slab lies inside ONE filter tap.  The
 // per-row source offsets and bounds flags then change only when the slab stream crosses a tap boundary (every
@@ -1040,6 +1071,7 @@ void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false, int eb = 4) 
   if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;  // A/B switch for the padding-tap elimination
   const int ntaps = p.K / p.C, spt = p.C / BK;
   p.skip_taps = (!noskip && (p.k_mul > 1 || p.k_mul < -1) && ntaps > 1 && ntaps <= 64) ? 1 : 0;
+  if (p.perm2) p.skip_taps = 1;  // parity-pure tiles: taps of the other parities have no valid row (also a lone 1x1 tap)
   // L2 locality (A/B switch SG_CONV_L2: bit 0 grouped tile order, bit 1 channel-block K order, bit 2 wgrad order).
   // An XCD owns 1/8 of the tiles and with them about 1/8 of the A operand's pixels.
   const int64_t ntn = sg_cdiv(p.Nout, bn);
@@ -1663,6 +1695,7 @@ void fill_fwd_params(IgemmParams& p, const sg_conv_desc* d, const void* x, const
   p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
   p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
   p.stats = nullptr;
+  p.perm2 = 0;
 }
 
 void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, const void* wt, const void* bias, void* dx,
@@ -1686,6 +1719,7 @@ void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, co
   p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
   p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
   p.stats = nullptr;
+  p.perm2 = 0;
 }
 
 // any-shape fallback for bf16 storage: the native fp32-MFMA kernel with widening loads (TA) and a rounding store (TY).
@@ -2090,6 +2124,13 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   const bool vec = (d->Cout % ch == 0) && (p.x_ld % ch == 0) && (d->Cin % 4 == 0) && aligned16(dy);
   const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);
   if (vpad_safe && x6_ok(p, vec, b16)) {
+    static const int perm_on = getenv("SG_DGRAD_PERM2") ? atoi(getenv("SG_DGRAD_PERM2")) : 1;
+    if (perm_on && d->stride == 2 && d->dilation == 1 && d->H % 2 == 0 && d->W % 2 == 0 && d->KH * d->KW <= 64) {
+      p.perm2 = 1;  // rows in parity-class order: see IgemmParams::perm2
+      p.fd_mc = make_fastdiv((uint32_t)(p.M / 4));
+      p.fd_hcwc = make_fastdiv((uint32_t)((d->H / 2) * (d->W / 2)));
+      p.fd_wc = make_fastdiv((uint32_t)(d->W / 2));
+    }
     if (b16) return run_x6<1, bf16_t>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
     if (x6_mode() == 2) return run_x6<1, float>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
     return run_x6<3, float>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);

@@ -163,9 +163,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   for (int j = 0; j < NA; ++j) {
     const int m = m0 + r0 + RS * j;
     if (m < p.M) {
-      uint32_t n, rem, oh, ow;
-      fd_divmod((uint32_t)m, p.fd_ohow, n, rem);
-      fd_divmod(rem, p.fd_ow, oh, ow);
+      uint32_t n, oh, ow;
+      row_to_pixel(p, (uint32_t)m, n, oh, ow);
       const int ohs = (int)oh * p.a_mul + p.off_h, ows = (int)ow * p.a_mul + p.off_w;
       row_lin_lds[j * NT + t] = (int)n * p.H * p.W + ohs * p.W + ows;
       row_hw[j] = (ohs << 16) | (ows & 0xffff);
@@ -544,7 +543,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   const int spt = p.C / BK;
   int nslab = (p.K + BK - 1) / BK;
   bool use_map = false;
-  if (p.skip_taps && ntaps > 1) {  // uniform
+  if (p.skip_taps && (ntaps > 1 || p.perm2)) {  // uniform
     int nact = 0;
     for (int tap = 0; tap < ntaps; ++tap) {
       uint32_t kh, kw;
@@ -562,8 +561,12 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
       }
     }
     __syncthreads();
-    nslab = __builtin_amdgcn_readfirstlane(nact) * spt;
-    use_map = true;
+    if (ntaps > 1) {
+      nslab = __builtin_amdgcn_readfirstlane(nact) * spt;
+      use_map = true;
+    } else if (__builtin_amdgcn_readfirstlane(nact) == 0) {
+      nslab = 0;  // a 1x1 stride-2 dgrad tile of a parity class no tap reaches: bias / zeros only
+    }
   }
   const int last = nslab - 1;
   const bool it_lin = ntaps <= 1;
@@ -664,7 +667,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         if (cv && row < p.M) {
           float v = acc[i][j][r] + bv;
           if (do_relu) v = fmaxf(v, 0.f);
-          st1<TA>(reinterpret_cast<TA*>(p.y) + (int64_t)row * p.y_ld + col, v);
+          st1<TA>(reinterpret_cast<TA*>(p.y) + row_to_yoff(p, row) + col, v);
         }
       }
     }

@@ -344,11 +344,15 @@ struct DwWgradRunOp {
 // x row (6 loads) and one dy row (4 loads) per 4 output pixels, both requested one row ahead of their use.  A workgroup is
 // 16 channel chunks (256 contiguous bytes per pixel) x 16 strips; the 16 strip partials are added in fixed order through
 // LDS, the S workgroup partials by seg_finalize_kernel in fp64 as before (part layout of seg_reduce_kernel, segment 0).
-template <typename T, bool PRE>
+// BN: x is the raw output of the producing convolution and the training-mode BatchNormalization (+ ReLU = PRE) in front of
+// this depthwise convolution is applied where a row is consumed, with bn_apply_kernel's expression (SG_BN_DEFER, as
+// DwWgradRunOp<.., BN = true>); the zero padding then has to be put back by masks, since BN(0) != 0.
+template <typename T, bool PRE, bool BN>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void dw_wgrad_strip_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, const int H, const int W, const int C,
     const int x_ld, const int y_ld, const int HS, const int nstrips, const int S, const unsigned x_bytes, const unsigned y_bytes,
-    const FastDiv fd_q, const FastDiv fd_hs) {
+    const FastDiv fd_q, const FastDiv fd_hs, const float* __restrict__ bn_gamma, const float* __restrict__ bn_beta,
+    const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd) {
   constexpr int TX = 16, TY = 16, EB = (int)sizeof(T);
   constexpr unsigned OOB = 0x80000000u;  // beyond num_records: the hardware returns 0 (image border, no select, no branch)
   typedef typename std::conditional<EB == 4, u32x4_c, u32x2_c>::type raw_t;
@@ -382,6 +386,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
     }
     return o;
   };
+  f32x4 gm = zero, bt = zero, mv = zero, iv = zero;
+  if constexpr (BN) {
+    if (c < C) { gm = ld4<float>(bn_gamma + c); bt = ld4<float>(bn_beta + c); mv = ld4<float>(bn_mean + c); iv = ld4<float>(bn_invstd + c); }
+  }
   if (c < C) {
     for (int s = z * TY + ty; s < nstrips; s += S * TY) {
       uint32_t rowi, q, n, hs;
@@ -412,10 +420,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = ldraw(rsrc_g, (ro + (unsigned)(k * y_ld * EB)) | flag);
       };
-      auto rowmac = [&](const int ta, const raw_t (&vr)[6], const f32x4 (&g)[4]) {
+      auto rowmac = [&](const int ta, const raw_t (&vr)[6], const f32x4 (&g)[4], const int ih) {
         f32x4 v[6];
+        if constexpr (BN) {
+          const bool rowok = (unsigned)ih < (unsigned)H;
 #pragma unroll
-        for (int b = 0; b < 6; ++b) v[b] = widen(vr[b], PRE);
+          for (int b = 0; b < 6; ++b) {
+            f32x4 t = widen(vr[b], false);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              t[e] = fmaf((t[e] - mv[e]) * iv[e], gm[e], bt[e]);
+              if (PRE) t[e] = fmaxf(t[e], 0.f);
+            }
+            v[b] = (rowok && (b == 0 ? lok : (b == 5 ? rok : true))) ? t : zero;
+          }
+        } else {
+#pragma unroll
+          for (int b = 0; b < 6; ++b) v[b] = widen(vr[b], PRE);
+        }
 #pragma unroll
         for (int b = 0; b < 3; ++b)
 #pragma unroll
@@ -446,9 +468,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
         f32x4 g[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) g[k] = widen(gc[k], false);
-        rowmac(0, X[I & 3], g);
-        rowmac(1, X[(I + 1) & 3], g);
-        rowmac(2, xc, g);
+        rowmac(0, X[I & 3], g, oh - 1);
+        rowmac(1, X[(I + 1) & 3], g, oh);
+        rowmac(2, xc, g, oh + 1);
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]),
                           "+v"(acc[7]), "+v"(acc[8]));
         __builtin_amdgcn_sched_barrier(0);
@@ -1048,7 +1070,7 @@ static int dwconv2d_wgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_co
     op.fd_w = make_fastdiv((uint32_t)d->Wo); op.fd_h = make_fastdiv((uint32_t)d->Ho);
     const int64_t rows = (int64_t)d->N * d->Ho * d->Wo;
     const bool vec = (op.C % 4 == 0) && (op.x_ld % 4 == 0) && (op.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy);
-    if (vec && !bn_gamma && dw_strip_ok(d)) {
+    if (vec && dw_strip_ok(d)) {
       const DwStripPlan sp = dw_strip_plan(ctx->num_cus, d);
       if (!ws || ws_bytes < sp.part_bytes) {
         sg_set_error("sg_dwconv2d_wgrad: workspace %zu < %zu", ws_bytes, sp.part_bytes);
@@ -1058,12 +1080,17 @@ static int dwconv2d_wgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_co
       const FastDiv fq = make_fastdiv((uint32_t)(d->W / 4)), fh = make_fastdiv((uint32_t)sp.nhs);
       const unsigned xb_ = (unsigned)((int64_t)d->N * d->H * d->W * op.x_ld * (int64_t)sizeof(T));
       const unsigned yb_ = (unsigned)((int64_t)d->N * d->H * d->W * op.y_ld * (int64_t)sizeof(T));
-      if (pre_relu)
-        hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, true>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy,
-                           (float*)ws, d->H, d->W, op.C, op.x_ld, op.y_ld, sp.HS, sp.nstrips, sp.S, xb_, yb_, fq, fh);
-      else
-        hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, false>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy,
-                           (float*)ws, d->H, d->W, op.C, op.x_ld, op.y_ld, sp.HS, sp.nstrips, sp.S, xb_, yb_, fq, fh);
+      auto strip = [&](auto pre_, auto bn_) {
+        constexpr bool PRE_ = decltype(pre_)::value, BN_ = decltype(bn_)::value;
+        hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, PRE_, BN_>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy,
+                           (float*)ws, d->H, d->W, op.C, op.x_ld, op.y_ld, sp.HS, sp.nstrips, sp.S, xb_, yb_, fq, fh,
+                           (const float*)bn_gamma, (const float*)bn_beta, (const float*)bn_mean, (const float*)bn_invstd);
+      };
+      if (bn_gamma) {
+        if (pre_relu) strip(std::true_type{}, std::true_type{});
+        else strip(std::false_type{}, std::true_type{});
+      } else if (pre_relu) strip(std::true_type{}, std::false_type{});
+      else strip(std::false_type{}, std::false_type{});
       SG_LAUNCH_CHECK("dw_wgrad_strip_kernel");
       DwWgradRunOp<1, T, false> fin;   // finalize() only: dw[t][c] = the fp64 sum of the S partial rows
       fin.dw = (float*)dw; fin.C = op.C;

@@ -144,9 +144,11 @@ def test_conv2d_into_concat_slice(engine, hw):
 
 
 @pytest.mark.parametrize("k,tag,hw", [(3, "convT3", (9, 11)), (2, "convT2", (9, 11)), (3, "convT3_w32", (16, 32)),
-                                      (2, "convT2_w32", (8, 32))])
+                                      (2, "convT2_w32", (8, 32)), (3, "convT3_class_pure_tiles", (32, 64))])
 def test_conv2d_transpose(engine, k, tag, hw):
-    """(…_w32: the kernel gradient is a stride-2 filter gradient with OW % 32 == 0, i.e. the bf16-pipe slab kernel)"""
+    """(…_w32: the kernel gradient is a stride-2 filter gradient with OW % 32 == 0, i.e. the bf16-pipe slab kernel)
+    The forward is a stride-2 dgrad: rows in parity-class order (IgemmParams::perm2) - 9 x 11 maps have 128-row tiles that
+    straddle the classes, 32 x 64 maps tiles of one class each (taps of the other parities dropped per tile)."""
     g = torch.Generator().manual_seed(11 + k)
     n, (h, w), cin, cout = 2, hw, 64, 32
     x = rnd(g, n, h, w, cin)
