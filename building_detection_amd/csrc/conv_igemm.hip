@@ -1615,9 +1615,9 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d, bool b16 = false) {
     pl.bias_part_bytes = colsum_ws_bytes(num_cus, P, d->Cout);
     return pl;
   }
-  if (!b16 && x6_mode() == 1 && wgrad_pw_wide_geom(d)) {   // 1x1, stride 1, wide enough: 128 x 384 tiles of dw (conv_pw.h)
+  if ((b16 || x6_mode() == 1) && wgrad_pw_wide_geom(d, b16 ? 2 : 4)) {   // 1x1, stride 1, wide enough: 128 x 384 tiles of dw (conv_pw.h)
     pl.wide = 1;
-    wgrad_pw_wide_plan(num_cus, d, pl.S, pl.slabs_per_split);
+    wgrad_pw_wide_plan(num_cus, d, pl.S, pl.slabs_per_split, b16 ? WPB_KP : 16);
     pl.dw_part_bytes = pl.S > 1 ? (size_t)pl.S * K * d->Cout * 4 : 0;
     pl.bias_part_bytes = colsum_ws_bytes(num_cus, P, d->Cout);
     return pl;
@@ -2236,14 +2236,15 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
       const bool al = aligned16(xs) && aligned16(dys) && p.x_bytes != 0 && p.dy_bytes != 0 && !head32;
       if (al) {
         int Sw, kps;   // re-planned for THIS part: a last, smaller sub-batch has fewer k-steps
-        wgrad_pw_wide_plan(ctx->num_cus, &dd, Sw, kps);
+        const int kp = b16 ? WPB_KP : 16;
+        wgrad_pw_wide_plan(ctx->num_cus, &dd, Sw, kps, kp);
         if (Sw > S) {  // never more partial slabs than the workspace was sized for
-          kps = (int)sg_cdiv(sg_cdiv((int64_t)p.P, 16), S);
-          Sw = (int)sg_cdiv(sg_cdiv((int64_t)p.P, 16), kps);
+          kps = (int)sg_cdiv(sg_cdiv((int64_t)p.P, kp), S);
+          Sw = (int)sg_cdiv(sg_cdiv((int64_t)p.P, kp), kps);
         }
         p.slabs_per_split = kps;
         parts = Sw;
-        return launch_wgrad_pw_wide(p, Sw, st);
+        return b16 ? launch_wgrad_pw_wide_b16(p, Sw, st) : launch_wgrad_pw_wide(p, Sw, st);
       }
     }
     if (pl.patch) {

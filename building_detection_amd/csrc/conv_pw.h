@@ -710,15 +710,168 @@ __global__ __launch_bounds__(512, 2) void wgrad_pw_wide_kernel(const WgradParams
   }
 }
 
+// bf16 storage: the same 128 x 384 tile of dw and the same wave layout, but both operands ARE their single plane - no split, a
+// thread's four 16-byte chunks (8 channels of one pixel each: one of x, three of dy) go from the buffer load to LDS unchanged.
+// k-steps of 32 pixels (two MFMA k-blocks, 12 MFMAs per wave), two stages of 36 KB, one raw barrier per k-step, the four LDS
+// stores of k-step s+1 and the four loads of k-step s+2 woven between the MFMAs.  wgrad_x6_kernel<128, .., bf16> reads x and dy
+// six times each for the 728-wide layers (36 tiles of 128 x 128), this one twice and six times.
+constexpr int WPB_KP = 32;                                      // pixels per k-step
+constexpr int WPB_STAGE = WPB_KP * (WPW_PA + WPW_PB);           // 36864
+__global__ __launch_bounds__(512, 2) void wgrad_pw_wide_b16_kernel(const WgradParams p) {
+  constexpr int WGN = 4, WM = 64, WN = 96, TM = 2, TN = 3;
+  constexpr unsigned OOB = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages] x { A' [32][PA], B [32][PB] }
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const uint32_t ntn = (p.Cout + PW_BN - 1) / PW_BN;
+  uint32_t bid, split;
+  {
+    const uint32_t lin = blockIdx.z * gridDim.x + blockIdx.x;
+    const uint32_t o = xcd_remap(lin, gridDim.x * gridDim.z);
+    split = o / gridDim.x;
+    bid = o - split * gridDim.x;
+  }
+  const uint32_t tile_r = bid / ntn, tile_n = bid - tile_r * ntn;
+  const int rbase = tile_r * PW_BM, n0 = tile_n * PW_BN;
+  const int nks_total = (p.P + WPB_KP - 1) / WPB_KP;
+  const int ks_begin = (int)split * p.slabs_per_split;   // (k-steps of 32 pixels per split for this kernel)
+  int ks_end = ks_begin + p.slabs_per_split;
+  if (ks_end > nks_total) ks_end = nks_total;
+  const int nk = ks_end - ks_begin;
+
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_dy = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.dy), 0, (int)p.dy_bytes, 0x00020000);
+  // chunks of a k-step: A' 32 pixels x 16 chunks of 8 channels (one per thread), B 32 pixels x 48 chunks (three per thread)
+  const int pa = t >> 4, ca = t & 15;
+  const unsigned a_voff = (rbase + 8 * ca) < p.Cin ? (unsigned)((pa * p.x_ld + rbase + 8 * ca) * 2) : OOB;
+  int pb[3], cb[3];
+  unsigned b_voff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int idx = t + 512 * i;
+    pb[i] = idx / 48;
+    cb[i] = idx - pb[i] * 48;
+    b_voff[i] = (n0 + 8 * cb[i]) < p.Cout ? (unsigned)((pb[i] * p.y_ld + n0 + 8 * cb[i]) * 2) : OOB;
+  }
+  const bool ptail = (p.P & (WPB_KP - 1)) != 0;
+  u32x4_t rr[4];
+  auto load_piece = [&](int ks, int w) {   // w = 0: the A' chunk, 1..3: the B chunks of k-step ks (absolute)
+    const int p0 = ks * WPB_KP;
+    if (w == 0) {
+      const bool v = !ptail || (p0 + pa < p.P);
+      rr[0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voff : OOB), p0 * p.x_ld * 2, 0);
+    } else {
+      const bool v = !ptail || (p0 + pb[w - 1] < p.P);
+      rr[w] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)(v ? b_voff[w - 1] : OOB), p0 * p.y_ld * 2, 0);
+    }
+  };
+  auto write_piece = [&](int stage, int w) {
+    char* dst = smem + stage * WPB_STAGE + (w == 0 ? pa * WPW_PA + ca * 16 : WPB_KP * WPW_PA + pb[w - 1] * WPW_PB + cb[w - 1] * 16);
+    *reinterpret_cast<u32x4_t*>(dst) = rr[w];
+  };
+
+  const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int tg = lane >> 4, ti = lane & 15;
+  const int tr_row = 8 * (tg >> 1) + (ti >> 2), tr_col = 16 * (tg & 1) + 4 * (ti & 3);
+  const int a_lane = tr_row * WPW_PA + (wm + tr_col) * 2;
+  const int b_lane = WPB_KP * WPW_PA + tr_row * WPW_PB + (wn + tr_col) * 2;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // one k-step; MODE 2: stage k-step s+1 and load s+2; 1: stage s+1; 0: multiply only
+  auto step = [&](int s, auto MODE_) {
+    constexpr int MODE = decltype(MODE_)::value;
+    const int cur = s & 1, nxt = cur ^ 1;
+    const char* sb = smem + cur * WPB_STAGE;
+    bf16x8_t af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const char* a = sb + a_lane + kb * 16 * WPW_PA + 64 * i;
+        af[kb][i] = tr_frag(a, a + 4 * WPW_PA);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const char* b = sb + b_lane + kb * 16 * WPW_PB + 64 * j;
+        bf[kb][j] = tr_frag(b, b + 4 * WPW_PB);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    auto piece = [&](int w) {   // 0..3: LDS stores of k-step s+1, 4..7: loads of k-step s+2 into the registers just stored
+      if (MODE == 0 || w >= 8) return;
+      if (w < 4) write_piece(nxt, w);
+      else if (MODE == 2) load_piece(ks_begin + s + 2, w - 4);
+    };
+    int q = 0;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kb][i], bf[kb][j], acc[i][j], 0, 0, 0);
+          if (q < 8) piece(q);
+          ++q;
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // raw: the loads of k-step s+2 stay in flight across it
+  };
+
+  if (nk > 0) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) load_piece(ks_begin, w);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) write_piece(0, w);
+    if (nk > 1) {
+#pragma unroll
+      for (int w = 0; w < 4; ++w) load_piece(ks_begin + 1, w);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int s = 0;
+    for (; s + 2 < nk; ++s) step(s, IC<2>{});
+    if (s + 1 < nk) { step(s, IC<1>{}); ++s; }
+    step(s, IC<0>{});
+  }
+
+  float* outp = p.out + (int64_t)split * p.K * p.Cout;
+  const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)((uint32_t)p.K * (uint32_t)p.Cout * 4u), 0x00020000);
+  const unsigned row0 = (unsigned)(rbase + wm + 4 * lh);
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn + 32 * j + lr;
+    const unsigned cterm = col < p.Cout ? (unsigned)col * 4u : OOB;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+        unsigned voff = cterm + row * (unsigned)p.Cout * 4u;
+        voff = row < (unsigned)p.K ? voff : OOB;
+        const float v = acc[i][j][r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_o, (int)voff, 0, 0);
+      }
+  }
+}
+
 // plan of the wide filter gradient: tiles of 128 x 384, the pixel reduction cut into S shares of whole 16-pixel k-steps so
 // that tiles x S fills the CUs once
-inline bool wgrad_pw_wide_geom(const sg_conv_desc* d) {
+inline bool wgrad_pw_wide_geom(const sg_conv_desc* d, int eb = 4) {
   static int on = -1;
   if (on < 0) on = getenv("SG_PW_WIDE") ? atoi(getenv("SG_PW_WIDE")) : 1;
   if (!on) return false;
   if (d->KH != 1 || d->KW != 1 || d->stride != 1 || d->pad_t != 0 || d->pad_l != 0) return false;
   const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
-  if (xl % 4 != 0 || yl % 4 != 0 || d->Cin % 4 != 0 || d->Cout % 4 != 0) return false;
+  const int ch = eb == 2 ? 8 : 4;   // channels per 16-byte chunk
+  if (xl % ch != 0 || yl % ch != 0 || d->Cin % ch != 0 || d->Cout % ch != 0) return false;
   if (on == 2) return true;
   const int64_t P = (int64_t)d->N * d->Ho * d->Wo;
   if (P < 6144 || d->Cin < 256) return false;
@@ -726,9 +879,9 @@ inline bool wgrad_pw_wide_geom(const sg_conv_desc* d) {
   return (double)d->Cout / (double)(ntn * PW_BN) >= 0.75 && (double)d->Cin / (double)(ntr * PW_BM) >= 0.75;
 }
 
-inline void wgrad_pw_wide_plan(int num_cus, const sg_conv_desc* d, int& S, int& ksteps_per_split) {
+inline void wgrad_pw_wide_plan(int num_cus, const sg_conv_desc* d, int& S, int& ksteps_per_split, int kp = 16) {
   const int64_t tiles = sg_cdiv(d->Cin, PW_BM) * sg_cdiv(d->Cout, PW_BN);
-  const int64_t nks = sg_cdiv((int64_t)d->N * d->Ho * d->Wo, 16);
+  const int64_t nks = sg_cdiv((int64_t)d->N * d->Ho * d->Wo, kp);
   int64_t s = (int64_t)num_cus / tiles;
   if (s < 1) s = 1;
   if (s > nks / 8) s = nks / 8 > 0 ? nks / 8 : 1;   // at least 8 k-steps per share
@@ -751,5 +904,23 @@ inline int launch_wgrad_pw_wide(const WgradParams& p, int S, hipStream_t st) {
   }
   hipLaunchKernelGGL(wgrad_pw_wide_kernel, dim3((unsigned)tiles, 1, (unsigned)S), dim3(512), lds, st, p);
   SG_LAUNCH_CHECK("wgrad_pw_wide_kernel");
+  return 0;
+}
+
+inline int launch_wgrad_pw_wide_b16(const WgradParams& p, int S, hipStream_t st) {
+  constexpr size_t lds = 2 * (size_t)WPB_STAGE;
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = set_dyn_lds(wgrad_pw_wide_b16_kernel, lds);
+    if (rc) return rc;
+    attr_done = true;
+  }
+  const int64_t tiles = sg_cdiv(p.Cin, PW_BM) * sg_cdiv(p.Cout, PW_BN);
+  if (tiles <= 0 || tiles > 65535 || S < 1 || S > 65535 || (int64_t)p.K * p.Cout * 4 >= (1ll << 31)) {
+    sg_set_error("wgrad_pw_wide_b16: bad grid (%lld tiles, %d splits)", (long long)tiles, S);
+    return SG_EINVAL;
+  }
+  hipLaunchKernelGGL(wgrad_pw_wide_b16_kernel, dim3((unsigned)tiles, 1, (unsigned)S), dim3(512), lds, st, p);
+  SG_LAUNCH_CHECK("wgrad_pw_wide_b16_kernel");
   return 0;
 }
