@@ -420,11 +420,14 @@ int launch_b16_pd(const IgemmParams& p, hipStream_t st) {
   return 0;
 }
 
-// SG_B16_PD = 2: two register sets of prefetched slabs (A/B switch), default 1
+// SG_B16_PD = 1 / 2: one / two register sets of prefetched slabs for every launch (A/B switch); default 0 = by shape: two
+// sets for the long-K multi-tap FORWARD launches (the ASPP convolutions, K = 18432: 308 -> 280 us, 225 -> 195 us), one
+// everywhere else (the same convolutions' dgrad loses 10 - 18 % with two, the short-K layers 8 %: profiles/r02_b16_prefetch_ab.txt)
 template <int BN, int WGM, int WGN, int KS>
 int launch_b16(const IgemmParams& p, hipStream_t st) {
-  static const int pd = getenv("SG_B16_PD") ? atoi(getenv("SG_B16_PD")) : 1;
-  return pd == 2 ? launch_b16_pd<BN, WGM, WGN, KS, 2>(p, st) : launch_b16_pd<BN, WGM, WGN, KS, 1>(p, st);
+  static const int pd = getenv("SG_B16_PD") ? atoi(getenv("SG_B16_PD")) : 0;
+  const bool two = pd == 2 || (pd == 0 && p.k_mul > 0 && p.K != p.C && p.K >= 8192 && p.div == 1);
+  return two ? launch_b16_pd<BN, WGM, WGN, KS, 2>(p, st) : launch_b16_pd<BN, WGM, WGN, KS, 1>(p, st);
 }
 
 // slab depth (k-steps of 16) for a launch whose taps are `c` channels deep: the deepest of 8 / 4 / 2 that keeps every slab

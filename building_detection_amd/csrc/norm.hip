@@ -175,6 +175,138 @@ __global__ void bn_bwd_apply_kernel(const T* __restrict__ x, const T* __restrict
   }
 }
 
+// Column-block forms of the two kernels above (round 3): a thread keeps ONE chunk of V channels and walks down the rows, so
+// the per-channel parameters are loaded once per thread instead of once per element.  With bf16 storage a 16-byte access is
+// 8 channels and the flat kernels issued 10 (apply) / 14 (backward) 16-byte parameter loads per 16 bytes of tensor: 20.8 /
+// 29.8 us for the 24 MB tensors of the middle flow against a copy's 11.8 us (profiles/r03_bw_bench.txt) - bound by the
+// load issue, not by bytes.  The flat index space is kept (a wave touches 1 KB of consecutive addresses: 16 chunk lanes x 16
+// row lanes with 256-byte runs measured 3.4 instead of 4.6 TB/s in fp32), but the number of threads is a multiple of the
+// chunks per row, so a thread's grid stride is a whole number of rows and its channel chunk never changes.  Four (backward:
+// two) rows in flight per thread, taken from consecutive periods so that the workgroups in flight sweep one window of the tensor.  Same per-element expressions, so results are bit-identical to the flat kernels.
+template <int V, typename T>
+__global__ __launch_bounds__(256) void bn_apply_cols_kernel(const T* __restrict__ x, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, T* __restrict__ y, int64_t rows,
+                                                            int C, int relu, float eps, int infer, int prow, FastDiv fd_cv) {
+  // blockIdx.x: block within a period of prow whole rows; blockIdx.y: group of four consecutive periods
+  const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, cv = (uint32_t)(C / V);
+  const uint32_t r0 = fd_div(i0, fd_cv);
+  const int c = (int)(i0 - r0 * cv) * V;
+  float mv[V], is[V], gv[V], bv[V];
+  ldv<V>(mean + c, mv);
+  ldv<V>(invstd + c, is);  // inference: this is the moving variance
+  ldv<V>(gamma + c, gv);
+  ldv<V>(beta + c, bv);
+  if (infer) {
+#pragma unroll
+    for (int k = 0; k < V; ++k) is[k] = rsqrtf(is[k] + eps);
+  }
+  auto one = [&](const float (&xv)[V], int64_t r) {
+    float o[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      float t = fmaf((xv[k] - mv[k]) * is[k], gv[k], bv[k]);  // the backward re-evaluates exactly this for the ReLU mask
+      if (relu) t = fmaxf(t, 0.f);
+      o[k] = t;
+    }
+    stv<V>(y + r * C + c, o);
+  };
+  const int64_t stride = prow, gstep = (int64_t)gridDim.y * 4 * prow;
+  for (int64_t r = (int64_t)blockIdx.y * 4 * prow + r0; r < rows; r += gstep) {
+    if (r + 3 * stride < rows) {
+      float x0[V], x1[V], x2[V], x3[V];
+      ldv<V>(x + r * C + c, x0);
+      ldv<V>(x + (r + stride) * C + c, x1);
+      ldv<V>(x + (r + 2 * stride) * C + c, x2);
+      ldv<V>(x + (r + 3 * stride) * C + c, x3);
+      one(x0, r); one(x1, r + stride); one(x2, r + 2 * stride); one(x3, r + 3 * stride);
+    } else {
+      for (int64_t q = r; q < rows; q += stride) {
+        float x0[V];
+        ldv<V>(x + q * C + c, x0);
+        one(x0, q);
+      }
+    }
+  }
+}
+
+template <int V, typename T, int MODE>
+__global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(const T* __restrict__ x, const T* __restrict__ y,
+                                                                const T* __restrict__ dy, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, const float* __restrict__ dgamma,
+                                                                const float* __restrict__ dbeta, T* __restrict__ dx, int64_t rows,
+                                                                int C, int prow, FastDiv fd_cv) {
+  const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, cv = (uint32_t)(C / V);
+  const uint32_t r0 = fd_div(i0, fd_cv);
+  const int c = (int)(i0 - r0 * cv) * V;
+  float mv[V], iv[V], gam[V], dg[V], db[V], bt[V];
+  ldv<V>(mean + c, mv);
+  ldv<V>(invstd + c, iv);
+  ldv<V>(gamma + c, gam);
+  ldv<V>(dgamma + c, dg);
+  ldv<V>(dbeta + c, db);
+  if constexpr (MODE == 2) ldv<V>(beta + c, bt);
+  const float inv_n = 1.0f / (float)rows;
+  auto one = [&](const float (&xv)[V], float (&gv)[V], const float (&yv)[V], int64_t r) {
+    float o[V];
+    if constexpr (MODE == 2) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) gv[k] = fmaf((xv[k] - mv[k]) * iv[k], gam[k], bt[k]) > 0.f ? gv[k] : 0.f;
+    } else if constexpr (MODE == 1) {
+#pragma unroll
+      for (int k = 0; k < V; ++k) gv[k] = yv[k] > 0.f ? gv[k] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float xh = (xv[k] - mv[k]) * iv[k];
+      o[k] = gam[k] * iv[k] * (gv[k] - db[k] * inv_n - xh * dg[k] * inv_n);
+    }
+    stv<V>(dx + r * C + c, o);
+  };
+  // (two rows a whole grid apart: measured 2 - 5 % faster here than two adjacent periods, the opposite of the forward kernel)
+  const int64_t stride = (int64_t)gridDim.y * prow, gstep = 2 * stride;
+  for (int64_t r = (int64_t)blockIdx.y * prow + r0; r < rows; r += gstep) {
+    if (r + stride < rows) {
+      float x0[V], x1[V], g0[V], g1[V], y0[V], y1[V];
+      ldv<V>(x + r * C + c, x0);
+      ldv<V>(x + (r + stride) * C + c, x1);
+      ldv<V>(dy + r * C + c, g0);
+      ldv<V>(dy + (r + stride) * C + c, g1);
+      if constexpr (MODE == 1) {
+        ldv<V>(y + r * C + c, y0);
+        ldv<V>(y + (r + stride) * C + c, y1);
+      }
+      one(x0, g0, y0, r);
+      one(x1, g1, y1, r + stride);
+    } else {
+      float x0[V], g0[V], y0[V];
+      ldv<V>(x + r * C + c, x0);
+      ldv<V>(dy + r * C + c, g0);
+      if constexpr (MODE == 1) ldv<V>(y + r * C + c, y0);
+      one(x0, g0, y0, r);
+    }
+  }
+}
+
+// grid of the column-stationary kernels: x = the blocks of one period (b0 x 256 threads = prow whole rows), y = groups of
+// `unroll` consecutive periods; a thread walks groups gridDim.y apart.  Returns false when no such grid of a sensible size
+// exists (the flat kernels take the launch).
+inline bool bn_cols_grid(int num_cus, int64_t rows, int cv, int unroll, int& prow, dim3& grid) {
+  int g = 256, a = cv;
+  while (a) { const int t_ = g % a; g = a; a = t_; }   // g = gcd(256, cv)
+  const int64_t b0 = cv / g;
+  if (b0 > 16384) return false;
+  prow = 256 / g;
+  int64_t k = sg_cdiv((int64_t)8 * num_cus, b0);
+  const int64_t maxk = sg_cdiv(rows, (int64_t)unroll * prow);
+  if (k > maxk) k = maxk;
+  if (k > 65535) k = 65535;
+  if (k < 1) k = 1;
+  grid = dim3((unsigned)b0, (unsigned)k);
+  return true;
+}
+
 inline unsigned ew_blocks(int64_t total) {
   int64_t b = sg_cdiv(total, 256);
   if (b > 8192) b = 8192;
@@ -184,9 +316,23 @@ inline unsigned ew_blocks(int64_t total) {
 
 template <typename T>
 int launch_bn_apply(hipStream_t st, bool vec, const T* x, const float* mean, const float* invstd, const float* gamma,
-                    const float* beta, T* y, int64_t rows, int C, int relu, float eps, int infer) {
+                    const float* beta, T* y, int64_t rows, int C, int relu, float eps, int infer, int num_cus) {
   const bool wide = vec && sizeof(T) == 2 && C % 8 == 0;  // bf16: 8 channels = one 16-byte access
   const int V = wide ? 8 : (vec ? 4 : 1);
+  static const int cols_on = getenv("SG_BN_COLS") ? atoi(getenv("SG_BN_COLS")) : 1;
+  int prow = 0;
+  dim3 cgrid;
+  if (vec && cols_on && bn_cols_grid(num_cus, rows, C / V, 4, prow, cgrid)) {
+    const FastDiv fd = make_fastdiv((uint32_t)(C / V));
+    if (wide)
+      hipLaunchKernelGGL((bn_apply_cols_kernel<8, T>), cgrid, dim3(256), 0, st, x, mean, invstd, gamma, beta, y, rows, C, relu, eps,
+                         infer, prow, fd);
+    else
+      hipLaunchKernelGGL((bn_apply_cols_kernel<4, T>), cgrid, dim3(256), 0, st, x, mean, invstd, gamma, beta, y, rows, C, relu, eps,
+                         infer, prow, fd);
+    SG_LAUNCH_CHECK("bn_apply_cols_kernel");
+    return 0;
+  }
   const unsigned blocks = ew_blocks(rows * (C / V));
   if (wide)
     hipLaunchKernelGGL((bn_apply_kernel<8, T>), dim3(blocks), dim3(256), 0, st, x, mean, invstd, gamma, beta, y, rows, C, relu, eps,
@@ -240,7 +386,7 @@ int sg_bn_train_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
     int rc = seg_reduce_launch(op, pl, 1, rows, C, (float*)ws, st, "bn_stats");
     if (rc) return rc;
     return launch_bn_apply<T>(st, vec, (const T*)x, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
-                              (const float*)beta, (T*)y, rows, C, relu, eps, 0);
+                              (const float*)beta, (T*)y, rows, C, relu, eps, 0, ctx->num_cus);
   });
   return 0;
 }
@@ -274,8 +420,20 @@ int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
     const int V = wide ? 8 : (vec ? 4 : 1);
     const unsigned blocks = ew_blocks(rows * (C / V));
     const int mode = !relu ? 0 : (beta ? 2 : 1);
+    static const int cols_on = getenv("SG_BN_COLS") ? atoi(getenv("SG_BN_COLS")) : 1;
     auto apply = [&](auto vt, auto mt) {
       constexpr int V_ = decltype(vt)::value, M_ = decltype(mt)::value;
+      if constexpr (V_ > 1) {
+        int prow = 0;
+        dim3 cgrid;
+        if (cols_on && bn_cols_grid(ctx->num_cus, rows, C / V_, 1, prow, cgrid)) {
+          hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<V_, T, M_>), cgrid, dim3(256), 0, st, (const T*)x, (const T*)y,
+                             (const T*)dy, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
+                             (const float*)beta, (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, prow,
+                             make_fastdiv((uint32_t)(C / V_)));
+          return;
+        }
+      }
       hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, T, M_>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
                          (const float*)save_mean, (const float*)save_invstd, (const float*)gamma, (const float*)beta,
                          (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, make_fastdiv((uint32_t)(C / V)));
@@ -301,7 +459,7 @@ int sg_bn_apply(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const
   const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
   SG_DTYPE_SWITCH(dtype, "sg_bn_apply", {
     return launch_bn_apply<T>((hipStream_t)stream, vec, (const T*)x, (const float*)mean, (const float*)invstd, (const float*)gamma,
-                              (const float*)beta, (T*)y, rows, C, relu, 0.f, 0);
+                              (const float*)beta, (T*)y, rows, C, relu, 0.f, 0, ctx->num_cus);
   });
   return 0;
 }
@@ -314,7 +472,7 @@ int sg_bn_infer(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const
   const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(y);
   SG_DTYPE_SWITCH(dtype, "sg_bn_infer", {
     return launch_bn_apply<T>((hipStream_t)stream, vec, (const T*)x, (const float*)moving_mean, (const float*)moving_var,
-                              (const float*)gamma, (const float*)beta, (T*)y, rows, C, relu, eps, 1);
+                              (const float*)gamma, (const float*)beta, (T*)y, rows, C, relu, eps, 1, ctx->num_cus);
   });
   return 0;
 }

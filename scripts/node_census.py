@@ -17,6 +17,9 @@ from building_detection_amd.losses import edge_focal_loss  # noqa: E402
 name = sys.argv[1] if len(sys.argv) > 1 else "v3plus"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 size = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+if os.environ.get("DTYPE", "f32") == "bf16":   # DTYPE=bf16: the mixed_bfloat16 policy (bf16 storage of the activations)
+    from building_detection_amd import mixed_precision as MP  # noqa: E402
+    MP.set_global_policy("mixed_bfloat16")
 model = zoo.BUILDERS[name]((size, size, 3))
 model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
 x, y = synthetic_batch(N, size, size, seed=1)
