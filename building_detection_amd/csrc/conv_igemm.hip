@@ -1077,6 +1077,8 @@ void plan_common(IgemmParams& p, bool vec, int bn, bool x6 = false, int eb = 4) 
   const int64_t ntn = sg_cdiv(p.Nout, bn);
   const int64_t a_per_xcd = p.x_bytes ? (int64_t)p.x_bytes / 8 : (1ll << 40);
   p.group_m = ((conv_l2(x6) & 1) && ntn >= 4) ? (a_per_xcd <= (2ll << 20) ? 16 : 8) : 1;
+  static const int gm_force = getenv("SG_CONV_GM") ? atoi(getenv("SG_CONV_GM")) : 0;   // experiment: row tiles per group
+  if (gm_force > 0 && ntn >= 2) p.group_m = gm_force;
   const bool ut = vec && (p.C % BK == 0) && p.x_bytes != 0 && p.w_bytes != 0;
   // decided from ONE image's footprint, never from the batch: the K order fixes the rounding order, and
   // inference must not depend on how many tiles travel together (tests/test_fullsize_gpu.py)
