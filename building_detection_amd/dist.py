@@ -233,6 +233,10 @@ class BucketReducer:
             self.fired.append((node_index, s))
             self.next += 1
 
+    def will_fire(self, node_index: int) -> bool:
+        """Will node_done(node_index) launch an all-reduce?  (The runtime joins its side stream first.)"""
+        return self.next < len(self.buckets) and self.buckets[self.next][2] >= node_index
+
     def finish(self):
         self.node_done(-1)
         self.tp.join()
@@ -260,6 +264,7 @@ class DataParallel:
         self.buckets = plan_buckets(param_ranges(model), rt.g_train.numel(), self.bucket_elems)
         self.reducer = BucketReducer(rt.g_train, self.buckets, self.tp)
         rt.on_node_done = self.reducer.node_done
+        rt.node_done_fires = self.reducer.will_fire
 
     def allreduce_grads(self, rt) -> float:
         self.reducer.finish()

@@ -122,9 +122,12 @@ class _ConvNode(Node):
         d = self.desc(rt, x)
         with e.timed(self._tag):
             want_b = self.b is not None and not getattr(self, "bias_grad_zero", False)
-            e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=rt.grad(self.w), db=rt.grad(self.b) if want_b else None)
+            # the input gradient first: the chain goes on with it, the filter gradient follows on the side stream beside the
+            # bandwidth-bound kernels of the next node (two MFMA kernels side by side only share the matrix pipe)
             dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype, planes=rt.planes(self, "d")) \
                 if rt.needs_grad(self.inputs[0]) else None
+            with e.side(self._tag, x, dz):
+                e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=rt.grad(self.w), db=rt.grad(self.b) if want_b else None)
         return [dx]
 
     def flops(self, batch):
@@ -192,11 +195,13 @@ class _SepConvNode(Node):
         dz = e.act_bwd(y, dy, _lib.SG_ACT_RELU) if self.activation == "relu" else dy
         dpw = e.conv_desc(tuple(t.shape), self.filters, 1, 1)
         want_b = not getattr(self, "bias_grad_zero", False)
-        e.conv2d_wgrad(t, dz, dpw, want_b, dw=rt.grad(self.pw), db=rt.grad(self.b) if want_b else None)
         dt = e.conv2d_dgrad(dz, rt.param(self.pw), dpw, planes=rt.planes(self, "d"))
+        with e.side(None, t, dz):
+            e.conv2d_wgrad(t, dz, dpw, want_b, dw=rt.grad(self.pw), db=rt.grad(self.b) if want_b else None)
         ddw = e.conv_desc(tuple(x.shape), x.shape[-1], 3, 3, self.stride, 1, "same")
-        e.dwconv_wgrad(x, dt, ddw, self.pre_relu, dw=rt.grad(self.dw), bn=rt.saved(self).get("bn"))
         dx = e.dwconv_dgrad(dt, rt.param(self.dw), ddw, x=x, pre_relu=self.pre_relu) if rt.needs_grad(self.inputs[0]) else None
+        with e.side(None, x, dt):
+            e.dwconv_wgrad(x, dt, ddw, self.pre_relu, dw=rt.grad(self.dw), bn=rt.saved(self).get("bn"))
         return [dx]
 
     def flops(self, batch):
@@ -254,8 +259,9 @@ class _ConvTNode(Node):
         dz = e.act_bwd(y, dy, _lib.SG_ACT_RELU) if self.activation == "relu" else dy
         d = self.fdesc(rt, x)
         # dw_F = wgrad_F(x_F = dz, dy_F = x); the bias gradient is the column sum of dz
-        e.conv2d_wgrad(dz, x, d, want_bias=False, dw=rt.grad(self.w))
-        e.bias_grad(dz, rt.grad(self.b))
+        with e.side(None, dz, x):
+            e.conv2d_wgrad(dz, x, d, want_bias=False, dw=rt.grad(self.w))
+            e.bias_grad(dz, rt.grad(self.b))
         dx = e.conv2d_fwd(dz, rt.param(self.w), None, desc=d, planes=rt.planes(self, "f")) if rt.needs_grad(self.inputs[0]) else None
         return [dx]
 

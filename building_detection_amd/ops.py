@@ -97,6 +97,7 @@ class _Timed:
 
     def __enter__(self):
         if getattr(self.eng, "_prof", None) is not None and self.tag:
+            self.eng.join_side()   # a bracketed section runs alone: no filter gradient of an earlier layer beside it
             if _TRACE_MARK and self.tag in _MARK_TAGS:  # named marker kernels for a rocprofv3 kernel trace
                 self.eng.lib.sg_trace_mark(self.eng.h, self.eng.stream, _MARK_TAGS[self.tag], 0)
             self.a = torch.cuda.Event(enable_timing=True)
@@ -136,6 +137,16 @@ class Engine:
         # shared mutable state, and the reference's Flask front end calls predict() from request threads
         # (buildAPI.py:78,111).  Re-entrant so that predict() may call predict_device().
         self.lock = threading.RLock()
+        # Filter gradients beside the input-gradient chain: conv2d_wgrad / dwconv_wgrad launches go to a second
+        # stream behind an event, so that these MFMA-bound kernels overlap the bandwidth-bound BatchNormalization / depthwise /
+        # add kernels of the chain.  SG_SIDE_WGRAD=0 keeps everything on one stream.
+        self._side_on = os.environ.get("SG_SIDE_WGRAD", "1") == "1"
+        self._side_stream = None
+        self._side_dirty = False
+        self._in_side = False
+        self._ws2 = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        self._ws2_peak = 0
+        self._ws2_pinned = False
 
     # ------------------------------------------------------------------------------------------ plumbing
     @property
@@ -144,8 +155,50 @@ class Engine:
         # building a torch.cuda.Stream object per launch (~1800 launches per training step)
         return C.c_void_p(_raw_stream(self._dev_index))
 
+    @contextlib.contextmanager
+    def side(self, tag, *tensors):
+        """Launches inside the block go to the side stream, ordered behind everything queued on the current stream so far.
+        `tensors` are the operands that live in the current stream's memory pool: the allocator must not hand their blocks out
+        again before the side stream is done with them (record_stream).  Inline (no second stream) while the launches are being
+        bracketed for a profile, inside a hipGraph capture, or with SG_SIDE_WGRAD=0."""
+        if (not self._side_on or self._in_side or (self._ws_pinned and not self._ws2_pinned)
+                or (self._prof is not None and (tag or self._prof_all))):
+            yield
+            return
+        main = torch.cuda.current_stream(self.device)
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        sd = self._side_stream
+        sd.wait_stream(main)
+        for t in tensors:
+            if t is not None:
+                t.record_stream(sd)
+        self._in_side = True
+        try:
+            with torch.cuda.stream(sd):
+                yield
+        finally:
+            self._in_side = False
+            self._side_dirty = True
+
+    def join_side(self):
+        """The current stream waits for everything queued on the side stream (before the gradients are read)."""
+        if self._side_dirty:
+            torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
+            self._side_dirty = False
+
     def ws(self, nbytes: int):
         nbytes = int(nbytes)
+        if self._in_side:   # the side stream's launches have a scratch buffer of their own
+            if nbytes > self._ws2_peak:
+                self._ws2_peak = nbytes
+            if nbytes > self._ws2.numel():
+                if self._ws2_pinned:
+                    raise _lib.SgError(f"side-stream workspace request of {nbytes} B exceeds the private {self._ws2.numel()} B "
+                                       "buffer of the hipGraph being captured (the sizing pass saw a smaller request)")
+                torch.cuda.synchronize(self.device)   # (first steps only) nothing may still be using the old buffer
+                self._ws2 = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+            return C.c_void_p(self._ws2.data_ptr()), C.c_size_t(self._ws2.numel())
         if nbytes > self._ws_peak:
             self._ws_peak = nbytes
         if nbytes > self._ws.numel():
@@ -156,17 +209,21 @@ class Engine:
         return C.c_void_p(self._ws.data_ptr()), C.c_size_t(self._ws.numel())
 
     @contextlib.contextmanager
-    def private_ws(self, buf: torch.Tensor):
+    def private_ws(self, buf: torch.Tensor, side_buf: Optional[torch.Tensor] = None):
         """Launches inside the block use `buf` as their scratch.  A hipGraph bakes the scratch pointer into its kernel
         nodes, so every captured graph owns its buffer: the engine's shared one may be re-grown (= freed) by any
-        later eager call, and a replay would then write into whatever tensor owns that block by then."""
+        later eager call, and a replay would then write into whatever tensor owns that block by then.  `side_buf`: the
+        same for the side stream's launches (without it the filter gradients stay on the capturing stream)."""
         with self.lock:
-            old, old_pin = self._ws, self._ws_pinned
+            old, old_pin, old2, old_pin2 = self._ws, self._ws_pinned, self._ws2, self._ws2_pinned
             self._ws, self._ws_pinned = buf, True
+            if side_buf is not None:
+                self._ws2, self._ws2_pinned = side_buf, True
             try:
                 yield
             finally:
                 self._ws, self._ws_pinned = old, old_pin
+                self._ws2, self._ws2_pinned = old2, old_pin2
 
     # -- in-run timing of tagged launches with HIP events recorded on the launch stream (bench.py roofline) --
     def profile_begin(self, all_convs=False):

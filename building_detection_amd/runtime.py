@@ -528,7 +528,8 @@ class GraphedTrainStep:
         dist = model.dist
         self.x, self.y = torch.empty_like(xd), torch.empty_like(yd)
         self.lr = eng.zeros(4)
-        self.ws = torch.empty(max(eng._ws_peak, 256) + 256, dtype=torch.uint8, device=eng.device)
+        # (the eager sizing steps ran the filter gradients on the side stream with its own scratch; here they run inline)
+        self.ws = torch.empty(max(eng._ws_peak, eng._ws2_peak, 256) + 256, dtype=torch.uint8, device=eng.device)
         rt.release()
         # The job table of the weight planes is (re)built HERE, outside the capture, for this batch and mode: a forward with
         # another batch size since the eager warm-up steps (a validation batch, a predict()) has re-keyed the runtime's
@@ -555,6 +556,9 @@ class GraphedTrainStep:
             self.segments.append((state["graph"], ready))
             state["ctx"] = state["graph"] = None
 
+        def fires(index):
+            return cuts.next < len(cuts.buckets) and cuts.buckets[cuts.next][2] >= index
+
         def node_done(index):   # the backward sweep has finished node `index`: cut when that completes buckets
             ready = cuts.pop_ready(index)
             if ready:
@@ -562,10 +566,14 @@ class GraphedTrainStep:
                 if index > 0:   # node 0 ends the sweep: nothing is left to capture behind it
                     begin()
 
-        saved_hook = rt.on_node_done
+        saved_hook, saved_fires = rt.on_node_done, rt.node_done_fires
+        # (no side-stream scratch: inside a capture the filter gradients stay on the capturing stream.  A forked graph was
+        # measured - it replays correctly, but hipGraphLaunch then queues its ~2000 nodes from the host in 56 ms instead of
+        # 0.5 ms and the step is 1.4 ms SLOWER than the linear graph, against 1.5 ms faster for forked eager launches)
         with eng.private_ws(self.ws), _CaptureGuard():
             try:
                 rt.on_node_done = node_done if dist is not None else None
+                rt.node_done_fires = fires if dist is not None else None
                 begin()
                 p = rt.forward(self.x, training=True)
                 self.loss = eng.loss_fwd(model.loss_kind, p, self.y)
@@ -590,7 +598,7 @@ class GraphedTrainStep:
                         state["ctx"].__exit__(None, None, None)
                     except Exception:
                         pass
-                rt.on_node_done = saved_hook
+                rt.on_node_done, rt.node_done_fires = saved_hook, saved_fires
         self.graph = self.segments[0][0]
         self._loss_out = self._counts_out = None
         assert rt._planes_key == self._planes_key, "the weight-plane job table was rebuilt inside the capture"
@@ -693,6 +701,7 @@ class _Runtime:
         self._saved: Dict[int, dict] = {}
         self.bn_stats: Dict[int, tuple] = {}  # id(conv output tensor) -> (per-tile statistics, tiles)
         self.on_node_done = None
+        self.node_done_fires = None   # optional predicate: will on_node_done(index) hand gradients over (all-reduce / cut)?
         # weight planes of the matrix-pipe convolutions, prepared once per optimiser step (ensure_planes)
         self._planes_key = None
         self._planes_ptr: Dict[tuple, int] = {}
@@ -857,6 +866,8 @@ class _Runtime:
             slot = grads.pop(id(n.output), None)
             if slot is None:  # output does not influence the loss
                 if hook is not None:
+                    if self.node_done_fires is None or self.node_done_fires(n.index):
+                        e.join_side()
                     hook(n.index)
                 continue
             dy = slot[0]
@@ -884,4 +895,7 @@ class _Runtime:
             # this node's saved state and output gradient are dead now
             self._saved.pop(id(n), None)
             if hook is not None:
+                if self.node_done_fires is None or self.node_done_fires(n.index):
+                    e.join_side()  # a bucket's all-reduce reads filter gradients the side stream may still be writing
                 hook(n.index)  # data-parallel: launches the all-reduce of every gradient bucket now complete
+        e.join_side()  # Adam, get_gradients() and the loss-scaling checks read the gradients on the main stream
