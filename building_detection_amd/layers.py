@@ -200,7 +200,7 @@ class _SepConvNode(Node):
             e.conv2d_wgrad(t, dz, dpw, want_b, dw=rt.grad(self.pw), db=rt.grad(self.b) if want_b else None)
         ddw = e.conv_desc(tuple(x.shape), x.shape[-1], 3, 3, self.stride, 1, "same")
         dx = e.dwconv_dgrad(dt, rt.param(self.dw), ddw, x=x, pre_relu=self.pre_relu) if rt.needs_grad(self.inputs[0]) else None
-        with e.side(None, x, dt):
+        with e.side(None, x, dt, kind=3):
             e.dwconv_wgrad(x, dt, ddw, self.pre_relu, dw=rt.grad(self.dw), bn=rt.saved(self).get("bn"))
         return [dx]
 

@@ -140,7 +140,8 @@ class Engine:
         # Filter gradients beside the input-gradient chain: conv2d_wgrad / dwconv_wgrad launches go to a second
         # stream behind an event, so that these MFMA-bound kernels overlap the bandwidth-bound BatchNormalization / depthwise /
         # add kernels of the chain.  SG_SIDE_WGRAD=0 keeps everything on one stream.
-        self._side_on = os.environ.get("SG_SIDE_WGRAD", "1") == "1"
+        self._side_mode = int(os.environ.get("SG_SIDE_WGRAD", "1"))   # 1: all filter gradients, 2: GEMM ones only, 3: depthwise only
+        self._side_on = self._side_mode > 0
         self._side_stream = None
         self._side_dirty = False
         self._in_side = False
@@ -156,12 +157,13 @@ class Engine:
         return C.c_void_p(_raw_stream(self._dev_index))
 
     @contextlib.contextmanager
-    def side(self, tag, *tensors):
+    def side(self, tag, *tensors, kind=2):
         """Launches inside the block go to the side stream, ordered behind everything queued on the current stream so far.
         `tensors` are the operands that live in the current stream's memory pool: the allocator must not hand their blocks out
         again before the side stream is done with them (record_stream).  Inline (no second stream) while the launches are being
         bracketed for a profile, inside a hipGraph capture, or with SG_SIDE_WGRAD=0."""
         if (not self._side_on or self._in_side or (self._ws_pinned and not self._ws2_pinned)
+                or (self._side_mode > 1 and self._side_mode != kind)
                 or (self._prof is not None and (tag or self._prof_all))):
             yield
             return

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """How much of a training step runs on two streams at once: from a rocprofv3 --kernel-trace CSV of bench.py, takes the
-dispatches between the last two adam_kernel launches (one steady-state step) and prints the wall time, the summed kernel
+dispatches between two consecutive adam_kernel launches (one steady-state step of the timed region: the third from the end
+by default, bench.py's last two steps are the bracketed single-stream ones) and prints the wall time, the summed kernel
 time per queue, the time during which kernels of BOTH queues were running, and per kernel family the mean duration
 (to compare with a SG_SIDE_WGRAD=0 trace).  Use: python scripts/overlap_trace.py <kernel_trace.csv>"""
 import csv
@@ -11,7 +12,8 @@ from collections import defaultdict
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 adam = [i for i, r in enumerate(rows) if "adam_kernel" in r["Kernel_Name"]]
-a, b = adam[-2], adam[-1]
+back = int(sys.argv[2]) if len(sys.argv) > 2 else 3   # bench.py: the last two steps are the bracketed (single-stream) ones
+a, b = adam[-back - 1], adam[-back]
 step = rows[a + 1:b + 1]
 t0, t1 = int(step[0]["Start_Timestamp"]), int(step[-1]["End_Timestamp"])
 byq = defaultdict(list)
