@@ -143,6 +143,7 @@ class Engine:
         self._side_mode = int(os.environ.get("SG_SIDE_WGRAD", "1"))   # 1: all filter gradients, 2: GEMM ones only, 3: depthwise only
         self._side_on = self._side_mode > 0
         self._side_stream = None
+        self.side_launches = 0   # blocks that went to the side stream (tests)
         self._side_dirty = False
         self._in_side = False
         self._ws2 = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
@@ -176,6 +177,7 @@ class Engine:
             if t is not None:
                 t.record_stream(sd)
         self._in_side = True
+        self.side_launches += 1
         try:
             with torch.cuda.stream(sd):
                 yield

@@ -199,8 +199,10 @@ def _dp_worker(rank, world, port, q):
     launched = []
     for node in reversed(range(10)):  # backward sweep
         before = red.next
+        fires = red.will_fire(node)   # (the runtime joins its side stream exactly where this says a bucket leaves)
         red.node_done(node)
         launched.append(red.next - before)
+        assert fires == (red.next > before), (node, fires, before, red.next)
     red.finish()
     others = [torch.rand(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
     ok = torch.allclose(arena, sum(others), atol=1e-6)

@@ -569,6 +569,39 @@ def test_jit_compiled_train_step_is_bit_identical_to_the_eager_one(engine, polic
     assert np.array_equal(ma.predict(xv), mb.predict(xv))
 
 
+@pytest.mark.parametrize("name", ["res34", "hrnet", "v3plus"])
+def test_filter_gradients_on_the_second_stream_change_nothing(engine, name):
+    """Engine.side(): conv2d_wgrad / dwconv_wgrad / the Conv2DTranspose bias gradient queued on a second stream beside the
+    input-gradient chain (own scratch buffer, record_stream on the operands, joined before Adam).  Same launches, same
+    arithmetic: loss, gradients and weights after three Adam steps equal the single-stream run's to the bit, and the side
+    stream was really used."""
+    from building_detection_amd import zoo
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss
+    kw = {"aspp_pool": 4} if name == "v3plus" else {}
+    ma, mb = zoo.BUILDERS[name]((64, 64, 3), **kw), zoo.BUILDERS[name]((64, 64, 3), **kw)
+    mb.set_weights(ma.get_weights())
+    for m in (ma, mb):
+        m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
+    saved = engine._side_on
+    try:
+        for i in range(3):
+            x, y = synthetic_batch(2, 64, 64, seed=500 + i)
+            engine._side_on = False
+            la = ma.train_on_batch(x, y)
+            n0 = engine.side_launches
+            engine._side_on = True
+            lb = mb.train_on_batch(x, y)
+            assert engine.side_launches > n0, "the filter gradients never went to the side stream"
+            assert la == lb, (i, la, lb)
+            for ga, gb in zip(ma.get_gradients(), mb.get_gradients()):
+                assert np.array_equal(ga, gb)
+    finally:
+        engine._side_on = saved
+    for wa, wb in zip(ma.get_weights(), mb.get_weights()):
+        assert np.array_equal(wa, wb)
+
+
 @pytest.mark.parametrize("policy", ["float32", "mixed_bfloat16"])
 def test_batchnorm_applied_in_the_depthwise_gather(engine, policy, monkeypatch):
     """Fusion BatchNormalization(+ReLU) -> SeparableConv2D (training): the depthwise gather normalises the raw tensor with
