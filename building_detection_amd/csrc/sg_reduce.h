@@ -84,7 +84,10 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
   if (!fuse) return;
   if (S > 1) {
     __shared__ int s_last;
-    __threadfence();  // release: this workgroup's partial row is visible device-wide before its arrival is counted
+    // release only: round 2 used __threadfence() (acquire AND release at agent scope: write back and invalidate this XCD's
+    // L2 in every workgroup; step 86 -> 117 ms).  Round 3 re-measured with the scoped pair: still 79 -> 102 ms (fp32), 34 ->
+    // 52 ms (bf16) - the L2 writeback of ~1000 workgroups per launch is the cost, whatever it finds to write.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     __syncthreads();
     if (tx == 0 && ty == 0) {
       unsigned* slot = cnt + (size_t)seg * gridDim.x + blockIdx.x;
@@ -94,7 +97,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();  // acquire: the other workgroups' partial rows, not stale cache lines
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' partial rows, not stale cache lines
   } else {
     __syncthreads();  // S == 1: the partial row just written by this workgroup's ty == 0 threads
   }
