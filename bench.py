@@ -334,7 +334,9 @@ def main():
         # (x512 FLOP) in a separate rocprofv3 --pmc pass over this kernel set (scripts/pmc_mfma.py); it depends on the
         # shapes only, not on the run.
         exec_ratio, exec_note = None, "no PMC pass for this configuration"
-        pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_mfma.json")
+        pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        pj = next((q for q in (os.path.join(pdir, n) for n in ("r03_pmc_mfma.json", "r01_pmc_mfma.json")) if os.path.exists(q)),
+                  os.path.join(pdir, "r01_pmc_mfma.json"))
         if args.batch == 16 and args.size == 512 and x6 and os.path.exists(pj):
             with open(pj) as f:
                 k = json.load(f)["kernels"]
@@ -342,9 +344,9 @@ def main():
             executed = (k["x6_fwd_dgrad"]["bf16_mfma_flops"] * 12 / k["x6_fwd_dgrad"]["launches"]
                         + k["x6_wgrad"]["bf16_mfma_flops"] * 6 / k["x6_wgrad"]["launches"]) / 6.0  # fp32-equivalent
             exec_ratio = executed / (dil_tflop * 1e12)
-            exec_note = ("NOT measured in this run: a committed constant from round 1's counter pass (SQ_INSTS_VALU_MFMA_MOPS_BF16 x "
-                         "512, profiles/r01_pmc_mfma.json; it depends on the layer shapes only) / 6 / nominal FLOPs: padding taps "
-                         "of the dilated convs are skipped, not multiplied")
+            exec_note = ("NOT measured in this run: a committed constant from a separate counter pass (SQ_INSTS_VALU_MFMA_MOPS_BF16 x "
+                         "512, profiles/%s; it depends on the layer shapes only - round 1 and round 3 count the same operations) "
+                         "/ 6 / nominal FLOPs: padding taps of the dilated convs are skipped, not multiplied" % os.path.basename(pj))
         out = {
             "metric": f"{args.size}x{args.size} tiles/sec fwd+bwd {LABEL.get(args.model, args.model)} (full train step: fwd+loss+bwd+Adam)",
             "value": round(tiles_per_s, 3), "unit": "tiles/s", "n_gpus": world, "steps": args.steps,
