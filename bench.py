@@ -192,7 +192,8 @@ def main():
                          "eagerly between them (runtime.GraphedTrainStep).  The roofline figures then come from two extra "
                          "EAGER steps after the timed region, because launches inside a replay cannot be bracketed with "
                          "events.  Default: on for --gpus > 1 (eight Python hosts queueing ~1800 launches per step each leave "
-                         "no slack), off on one GPU (GPU-bound either way, and the roofline events sit in the timed steps)")
+                         "no slack); on one GPU the warm-up tries both forms and the timed region runs the faster one "
+                         "(config.train_step_choice)")
     ap.add_argument("--no-jit", dest="jit", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
@@ -241,7 +242,13 @@ def main():
         model = zoo.BUILDERS[args.model]((args.size, args.size, 3), 2, aspp_pool=args.size // 16)
     else:
         model = zoo.BUILDERS[args.model]((args.size, args.size, 3))
-    jit = bool(args.jit) if args.jit is not None else (world > 1)
+    # One GPU, neither --jit nor --no-jit: the step is captured during the warm-up AND tried both ways (two untimed steps
+    # each); the timed region runs the faster form.  Eager launches overlap the filter gradients on a second stream (DESIGN
+    # 10.9) and are 2 - 5 % faster while the Python host keeps ahead of the GPU (60 ms of enqueue per 77 ms step); on a box whose
+    # CPUs are busy with other tenants' work the same step was measured host-bound at 134 ms, where the replay (0.5 ms of host
+    # time per step) does not care.
+    auto = args.jit is None and world == 1
+    jit = True if auto else (bool(args.jit) if args.jit is not None else (world > 1))
     model.compile(optimizer="adam", loss=edge_focal_loss, metrics=[PA, IoU, MIoU, F1_score], jit_compile=jit)
     if jit and args.warmup < 3:
         args.warmup = 3   # two eager steps per shape, the third call captures (and replays) the graph
@@ -271,6 +278,22 @@ def main():
             jit = model.jit_compile = False
             model.train_on_batch(xd, yd, return_device_scalars=True)
     sync()
+    choice = None
+    if auto and jit:
+        def trial(n=2):
+            sync()
+            t = time.perf_counter()
+            for _ in range(n):
+                model.train_on_batch(xd, yd, return_device_scalars=True)
+            sync()
+            return (time.perf_counter() - t) / n * 1e3
+        t_replay = trial()
+        model.jit_compile = False
+        t_eager = trial()
+        jit = model.jit_compile = not (t_eager < 0.995 * t_replay)   # a tie goes to the replay: it cannot become host-bound
+        choice = {"untimed_trial_ms_per_step": {"eager_two_streams": round(t_eager, 3), "hipgraph_replay": round(t_replay, 3)},
+                  "chosen": "hipgraph_replay" if jit else "eager_two_streams"}
+        sync()
     eng.profile_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -363,6 +386,7 @@ def main():
                        "step_achieved_tflops": round(step_tflop / (ms_per_step / 1e3), 2),
                        "final_loss": float(loss.item()),
                        "host_enqueue_ms_per_step": round(t_enq / args.steps * 1e3, 2),
+                       "train_step_choice": choice,
                        "train_step": (("one hipGraph replay per step (compile(jit_compile=True))" if dist is None else
                                        "hipGraph segments per gradient bucket, eager RCCL all-reduces between them "
                                        "(compile(jit_compile=True) under DataParallel)") if jit else "eager launches")},

@@ -145,8 +145,11 @@ class Engine:
         self._side_stream = None
         self.side_launches = 0   # blocks that went to the side stream (tests)
         self._side_dirty = False
+        self._side_keep = []     # operands of the side stream's launches, released at the next join
         self._in_side = False
         self._ws2 = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
+        self._ws3 = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)   # (SG_SIDE_WGRAD=4: a third stream's scratch)
+        self._side_buf = "_ws2"
         self._ws2_peak = 0
         self._ws2_pinned = False
 
@@ -161,22 +164,25 @@ class Engine:
     def side(self, tag, *tensors, kind=2):
         """Launches inside the block go to the side stream, ordered behind everything queued on the current stream so far.
         `tensors` are the operands that live in the current stream's memory pool: the allocator must not hand their blocks out
-        again before the side stream is done with them (record_stream).  Inline (no second stream) while the launches are being
+        again before the side stream is done with them (they are held until join_side).  Inline (no second stream) while the launches are being
         bracketed for a profile, inside a hipGraph capture, or with SG_SIDE_WGRAD=0."""
         if (not self._side_on or self._in_side or (self._ws_pinned and not self._ws2_pinned)
-                or (self._side_mode > 1 and self._side_mode != kind)
+                or (self._side_mode in (2, 3) and self._side_mode != kind)
                 or (self._prof is not None and (tag or self._prof_all))):
             yield
             return
         main = torch.cuda.current_stream(self.device)
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
-        sd = self._side_stream
+            self._side_stream3 = torch.cuda.Stream(device=self.device)
+        sd = self._side_stream3 if (self._side_mode == 4 and kind == 3) else self._side_stream
         sd.wait_stream(main)
-        for t in tensors:
-            if t is not None:
-                t.record_stream(sd)
+        # the operands live in the main stream's pool: they are kept alive until the main stream has joined the side stream
+        # (join_side), after which any reuse of their blocks is ordered behind the side stream's reads.  (record_stream would
+        # do, but every recorded block costs the allocator an event it polls on later allocations.)
+        self._side_keep.extend(t for t in tensors if t is not None)
         self._in_side = True
+        self._side_buf = "_ws3" if sd is getattr(self, "_side_stream3", None) and self._side_mode == 4 and kind == 3 else "_ws2"
         self.side_launches += 1
         try:
             with torch.cuda.stream(sd):
@@ -189,20 +195,25 @@ class Engine:
         """The current stream waits for everything queued on the side stream (before the gradients are read)."""
         if self._side_dirty:
             torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
+            if self._side_mode == 4:
+                torch.cuda.current_stream(self.device).wait_stream(self._side_stream3)
             self._side_dirty = False
+            self._side_keep.clear()
 
     def ws(self, nbytes: int):
         nbytes = int(nbytes)
         if self._in_side:   # the side stream's launches have a scratch buffer of their own
             if nbytes > self._ws2_peak:
                 self._ws2_peak = nbytes
-            if nbytes > self._ws2.numel():
+            buf = getattr(self, self._side_buf)
+            if nbytes > buf.numel():
                 if self._ws2_pinned:
-                    raise _lib.SgError(f"side-stream workspace request of {nbytes} B exceeds the private {self._ws2.numel()} B "
+                    raise _lib.SgError(f"side-stream workspace request of {nbytes} B exceeds the private {buf.numel()} B "
                                        "buffer of the hipGraph being captured (the sizing pass saw a smaller request)")
                 torch.cuda.synchronize(self.device)   # (first steps only) nothing may still be using the old buffer
-                self._ws2 = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
-            return C.c_void_p(self._ws2.data_ptr()), C.c_size_t(self._ws2.numel())
+                buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+                setattr(self, self._side_buf, buf)
+            return C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel())
         if nbytes > self._ws_peak:
             self._ws_peak = nbytes
         if nbytes > self._ws.numel():
