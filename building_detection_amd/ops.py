@@ -148,8 +148,6 @@ class Engine:
         self._side_keep = []     # operands of the side stream's launches, released at the next join
         self._in_side = False
         self._ws2 = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
-        self._ws3 = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)   # (SG_SIDE_WGRAD=4: a third stream's scratch)
-        self._side_buf = "_ws2"
         self._ws2_peak = 0
         self._ws2_pinned = False
 
@@ -174,15 +172,13 @@ class Engine:
         main = torch.cuda.current_stream(self.device)
         if self._side_stream is None:
             self._side_stream = torch.cuda.Stream(device=self.device)
-            self._side_stream3 = torch.cuda.Stream(device=self.device)
-        sd = self._side_stream3 if (self._side_mode == 4 and kind == 3) else self._side_stream
+        sd = self._side_stream
         sd.wait_stream(main)
         # the operands live in the main stream's pool: they are kept alive until the main stream has joined the side stream
         # (join_side), after which any reuse of their blocks is ordered behind the side stream's reads.  (record_stream would
         # do, but every recorded block costs the allocator an event it polls on later allocations.)
         self._side_keep.extend(t for t in tensors if t is not None)
         self._in_side = True
-        self._side_buf = "_ws3" if sd is getattr(self, "_side_stream3", None) and self._side_mode == 4 and kind == 3 else "_ws2"
         self.side_launches += 1
         try:
             with torch.cuda.stream(sd):
@@ -195,8 +191,6 @@ class Engine:
         """The current stream waits for everything queued on the side stream (before the gradients are read)."""
         if self._side_dirty:
             torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
-            if self._side_mode == 4:
-                torch.cuda.current_stream(self.device).wait_stream(self._side_stream3)
             self._side_dirty = False
             self._side_keep.clear()
 
@@ -205,15 +199,13 @@ class Engine:
         if self._in_side:   # the side stream's launches have a scratch buffer of their own
             if nbytes > self._ws2_peak:
                 self._ws2_peak = nbytes
-            buf = getattr(self, self._side_buf)
-            if nbytes > buf.numel():
+            if nbytes > self._ws2.numel():
                 if self._ws2_pinned:
-                    raise _lib.SgError(f"side-stream workspace request of {nbytes} B exceeds the private {buf.numel()} B "
+                    raise _lib.SgError(f"side-stream workspace request of {nbytes} B exceeds the private {self._ws2.numel()} B "
                                        "buffer of the hipGraph being captured (the sizing pass saw a smaller request)")
                 torch.cuda.synchronize(self.device)   # (first steps only) nothing may still be using the old buffer
-                buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
-                setattr(self, self._side_buf, buf)
-            return C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel())
+                self._ws2 = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=self.device)
+            return C.c_void_p(self._ws2.data_ptr()), C.c_size_t(self._ws2.numel())
         if nbytes > self._ws_peak:
             self._ws_peak = nbytes
         if nbytes > self._ws.numel():
