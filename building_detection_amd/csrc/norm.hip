@@ -289,6 +289,74 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(const T* __restr
   }
 }
 
+// y = [relu]( f_a(a) + f_b(b) ), f = BatchNormalization's apply (training: saved mean / invstd; inference: moving mean /
+// variance) for an operand whose parameter pointers are given, the identity otherwise: the residual add of an Xception block
+// applies the normalisation of the branch (and of the 1x1 shortcut) it sums, so that tensor is never written and read again
+// (sg_add2_bn; one of BatchNormalization's two forward passes for those layers).  Column-stationary like bn_apply_cols_kernel;
+// the same expression, so with fp32 storage the result has the bits of bn_apply + add_n.
+struct Add2BnArgs {
+  const float* mean[2];
+  const float* invstd[2];
+  const float* gamma[2];
+  const float* beta[2];
+};
+
+template <int V, typename T>
+__global__ __launch_bounds__(256) void add2_bn_kernel(const T* __restrict__ a, const T* __restrict__ b, const Add2BnArgs q,
+                                                      T* __restrict__ y, int64_t rows, int C, int relu, float eps, int infer,
+                                                      int prow, FastDiv fd_cv) {
+  const uint32_t i0 = blockIdx.x * 256u + threadIdx.x, cv = (uint32_t)(C / V);
+  const uint32_t r0 = fd_div(i0, fd_cv);
+  const int c = (int)(i0 - r0 * cv) * V;
+  float mv[2][V], is[2][V], gv[2][V], bv[2][V];
+  const bool on[2] = {q.mean[0] != nullptr, q.mean[1] != nullptr};
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    if (on[o]) {
+      ldv<V>(q.mean[o] + c, mv[o]);
+      ldv<V>(q.invstd[o] + c, is[o]);
+      ldv<V>(q.gamma[o] + c, gv[o]);
+      ldv<V>(q.beta[o] + c, bv[o]);
+      if (infer) {
+#pragma unroll
+        for (int k = 0; k < V; ++k) is[o][k] = rsqrtf(is[o][k] + eps);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < V; ++k) { mv[o][k] = 0.f; is[o][k] = 1.f; gv[o][k] = 1.f; bv[o][k] = 0.f; }
+    }
+  }
+  auto one = [&](const float (&xa)[V], const float (&xb)[V], int64_t r) {
+    float o[V];
+#pragma unroll
+    for (int k = 0; k < V; ++k) {
+      const float ta = on[0] ? fmaf((xa[k] - mv[0][k]) * is[0][k], gv[0][k], bv[0][k]) : xa[k];
+      const float tb = on[1] ? fmaf((xb[k] - mv[1][k]) * is[1][k], gv[1][k], bv[1][k]) : xb[k];
+      float t = ta + tb;
+      if (relu) t = fmaxf(t, 0.f);
+      o[k] = t;
+    }
+    stv<V>(y + r * C + c, o);
+  };
+  const int64_t stride = prow, gstep = (int64_t)gridDim.y * 2 * prow;
+  for (int64_t r = (int64_t)blockIdx.y * 2 * prow + r0; r < rows; r += gstep) {
+    if (r + stride < rows) {
+      float a0[V], a1[V], b0[V], b1[V];
+      ldv<V>(a + r * C + c, a0);
+      ldv<V>(a + (r + stride) * C + c, a1);
+      ldv<V>(b + r * C + c, b0);
+      ldv<V>(b + (r + stride) * C + c, b1);
+      one(a0, b0, r);
+      one(a1, b1, r + stride);
+    } else {
+      float a0[V], b0[V];
+      ldv<V>(a + r * C + c, a0);
+      ldv<V>(b + r * C + c, b0);
+      one(a0, b0, r);
+    }
+  }
+}
+
 // grid of the column-stationary kernels: x = the blocks of one period (b0 x 256 threads = prow whole rows), y = groups of
 // `unroll` consecutive periods; a thread walks groups gridDim.y apart.  Returns false when no such grid of a sensible size
 // exists (the flat kernels take the launch).
@@ -461,6 +529,43 @@ int sg_bn_apply(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const
     return launch_bn_apply<T>((hipStream_t)stream, vec, (const T*)x, (const float*)mean, (const float*)invstd, (const float*)gamma,
                               (const float*)beta, (T*)y, rows, C, relu, 0.f, 0, ctx->num_cus);
   });
+  return 0;
+}
+
+int sg_add2_bn(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* a, const void* b, const void* a_mean,
+               const void* a_invstd, const void* a_gamma, const void* a_beta, const void* b_mean, const void* b_invstd,
+               const void* b_gamma, const void* b_beta, void* y, int relu, int infer, float eps) {
+  SG_CHECK_ARG(ctx && (dtype == SG_F32 || dtype == SG_BF16), "sg_add2_bn: bad ctx/dtype");
+  SG_CHECK_ARG(rows > 0 && C > 0 && a && b && y, "sg_add2_bn: bad argument");
+  SG_CHECK_ARG((a_mean != nullptr) == (a_invstd != nullptr && a_gamma != nullptr && a_beta != nullptr) &&
+                   (b_mean != nullptr) == (b_invstd != nullptr && b_gamma != nullptr && b_beta != nullptr),
+               "sg_add2_bn: an operand's four BatchNormalization parameters come together or not at all");
+  SG_CHECK_ARG(rows * C < (1ll << 31), "sg_add2_bn: tensor exceeds 2^31 elements");
+  if (!((C % 4 == 0) && sg_aligned16(a) && sg_aligned16(b) && sg_aligned16(y))) {
+    sg_set_error("sg_add2_bn: needs C %% 4 == 0 and 16-byte aligned tensors; apply the BatchNormalization and add instead");
+    return SG_EUNSUPPORTED;
+  }
+  Add2BnArgs q;
+  q.mean[0] = (const float*)a_mean; q.invstd[0] = (const float*)a_invstd; q.gamma[0] = (const float*)a_gamma; q.beta[0] = (const float*)a_beta;
+  q.mean[1] = (const float*)b_mean; q.invstd[1] = (const float*)b_invstd; q.gamma[1] = (const float*)b_gamma; q.beta[1] = (const float*)b_beta;
+  SG_DTYPE_SWITCH(dtype, "sg_add2_bn", {
+    const bool wide = sizeof(T) == 2 && C % 8 == 0;
+    const int V = wide ? 8 : 4;
+    int prow = 0;
+    dim3 grid;
+    if (!bn_cols_grid(ctx->num_cus, rows, C / V, 2, prow, grid)) {
+      sg_set_error("sg_add2_bn: no column-stationary grid for C = %d", C);
+      return SG_EUNSUPPORTED;
+    }
+    const FastDiv fd = make_fastdiv((uint32_t)(C / V));
+    if (wide)
+      hipLaunchKernelGGL((add2_bn_kernel<8, T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, q, (T*)y, rows, C,
+                         relu, eps, infer, prow, fd);
+    else
+      hipLaunchKernelGGL((add2_bn_kernel<4, T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, q, (T*)y, rows, C,
+                         relu, eps, infer, prow, fd);
+  });
+  SG_LAUNCH_CHECK("add2_bn_kernel");
   return 0;
 }
 

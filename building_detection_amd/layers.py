@@ -344,6 +344,7 @@ class _BNNode(Node):
         self.momentum, self.epsilon = momentum, epsilon
         self.relu = False  # fused by the optimisation pass when followed by a single-consumer ReLU
         self.defer_to = None  # fused by the optimisation pass: the SeparableConv2D that applies this layer in its gather
+        self.defer_add = None  # fused by the optimisation pass: the two-operand Add that applies this layer while it sums
 
     def build(self, x):
         c = x.shape[-1]
@@ -359,18 +360,22 @@ class _BNNode(Node):
         if training:
             st = rt.bn_stats.pop(id(x), None)
             if st is not None:  # statistics already produced by the conv that wrote x
-                defer = self.defer_to is not None
+                defer = self.defer_to is not None or self.defer_add is not None
                 y, mean, invstd = e.bn_train_fwd_from_tiles(x, st[0], st[1], rt.param(self.gamma), rt.param(self.beta),
                                                             rt.param(self.mm), rt.param(self.mv), relu=self.relu,
                                                             momentum=self.momentum, eps=self.epsilon, apply=not defer)
-                if defer:  # the consumer's depthwise gather normalises: this layer's "output" is its raw input
+                if defer:  # the consumer (depthwise gather / residual add) normalises: this layer's "output" is its raw input
                     rt.save(self, mean=mean, invstd=invstd, deferred=True)
                     return x
             else:
                 y, mean, invstd = e.bn_train_fwd(x, rt.param(self.gamma), rt.param(self.beta), rt.param(self.mm),
                                                  rt.param(self.mv), relu=self.relu, momentum=self.momentum, eps=self.epsilon)
-            rt.save(self, mean=mean, invstd=invstd)
+            rt.save(self, mean=mean, invstd=invstd, deferred=False)
             return y
+        if self.defer_add is not None and x.shape[-1] % 4 == 0:   # inference: the Add applies the moving statistics
+            rt.save(self, deferred=True)
+            return x
+        rt.save(self, deferred=False)
         return e.bn_infer(x, rt.param(self.gamma), rt.param(self.beta), rt.param(self.mm), rt.param(self.mv),
                           relu=self.relu, eps=self.epsilon)
 
@@ -671,6 +676,7 @@ class _AddNode(Node):
     def __init__(self, name=None):
         super().__init__(name)
         self.relu = False
+        self.bn_src = [None, None]   # fused by the optimisation pass: the BatchNormalization layers this Add applies to its operands
 
     def build(self, xs):
         for t in xs:
@@ -678,6 +684,18 @@ class _AddNode(Node):
         return self.connect(xs, xs[0].shape)
 
     def forward(self, rt, xs, training):
+        if len(xs) == 2 and (self.bn_src[0] is not None or self.bn_src[1] is not None):
+            bn = [None, None]
+            for i, src in enumerate(self.bn_src):
+                if src is None:
+                    continue
+                sv = rt._saved.get(id(src)) or {}
+                if sv.get("deferred"):   # that layer handed its RAW input on (it had the statistics / is in inference mode)
+                    bn[i] = ((sv["mean"], sv["invstd"]) if training else (rt.param(src.mm), rt.param(src.mv))) + \
+                            (rt.param(src.gamma), rt.param(src.beta))
+            if bn[0] is not None or bn[1] is not None:
+                eps = next(s.epsilon for s in self.bn_src if s is not None)
+                return rt.eng.add2_bn(xs[0], xs[1], bn[0], bn[1], relu=self.relu, infer=not training, eps=eps)
         return rt.eng.add_n(xs, relu=self.relu)
 
     def backward(self, rt, xs, y, dy):

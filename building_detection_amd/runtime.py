@@ -145,6 +145,27 @@ class Model:
         # time: _BNNode.forward falls back to the materialising form) and the stride-1 run kernels' geometry.
         # Default OFF: measured on the DeepLabv3+ step the 39 dropped bn_apply launches save 1.05 ms and the
         # depthwise kernels, which are instruction- not bandwidth-bound, give 0.8 ms of it back (fp32 -0.3 ms, bf16 0.0).
+        # BatchNormalization (no ReLU) -> two-operand Add: the residual adds of the Xception blocks sum a normalised branch and
+        # the shortcut (itself a normalised 1x1 convolution in the entry / exit flow).  The Add applies the normalisation while
+        # it sums (sg_add2_bn), the normalised tensor is never written or read: one of the layer's two forward passes
+        # (SG_BN_ADD=0 keeps them apart).  The backward is untouched: dy of the Add IS dy of the BatchNormalization, whose
+        # backward reads its raw input.
+        if os.environ.get("SG_BN_ADD", "1") == "1":
+            for n in self.nodes:
+                if not isinstance(n, L._AddNode) or len(n.inputs) != 2 or len(n.output.shape) != 4:
+                    continue
+                epss = set()
+                for i, t in enumerate(n.inputs):
+                    p_ = t.node
+                    if (isinstance(p_, L._BNNode) and not p_.relu and p_.defer_to is None and p_.defer_add is None
+                            and len(t.consumers) == 1 and id(t) not in outs and t.shape[-1] % 4 == 0
+                            and n.inputs[0] is not n.inputs[1]):
+                        n.bn_src[i], p_.defer_add = p_, n
+                        epss.add(p_.epsilon)
+                if len(epss) > 1:   # (one eps per launch: two different ones never occur on this path)
+                    for i, p_ in enumerate(n.bn_src):
+                        if p_ is not None:
+                            p_.defer_add, n.bn_src[i] = None, None
         if os.environ.get("SG_BN_DEFER", "0") == "1":
             for n in self.nodes:
                 if not isinstance(n, L._BNNode) or len(n.output.shape) != 4 or id(n.output) in outs:

@@ -397,6 +397,40 @@ def test_upsample(engine, s):
     close(engine.upsample_bwd(dy.cuda(), x.shape, s), xr.grad, what="up bwd")
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("which", ["a", "b", "ab"])
+def test_add2_bn_equals_batchnorm_then_add(engine, which, dtype):
+    """sg_add2_bn: the residual add applies the BatchNormalization of its operand(s) while it sums.  fp32 storage: the bits of
+    bn (training statistics / inference moving statistics) followed by add_n(+ReLU); bf16 storage skips the rounding of the
+    normalised tensor, so it is compared with the fp32 result at bf16 resolution."""
+    g = torch.Generator().manual_seed(len(which) + (0 if dtype == torch.float32 else 7))
+    n, h, w, c = 3, 6, 10, 728
+    a, b = rnd(g, n, h, w, c).cuda(), rnd(g, n, h, w, c).cuda()
+    par = [tuple(t.cuda() for t in (rnd(g, c), torch.rand(c, generator=g) + 0.5, torch.rand(c, generator=g) + 0.5, rnd(g, c)))
+           for _ in range(2)]   # (mean, invstd or variance, gamma, beta)
+    for infer in (False, True):
+        for relu in (False, True):
+            def norm(x, p):
+                mean, iv, gamma, beta = p
+                if infer:
+                    return engine.bn_infer(x, gamma, beta, mean, iv, eps=1e-3)
+                y = torch.empty_like(x)
+                from building_detection_amd.ops import _ptr, _dt, check
+                check(engine.lib.sg_bn_apply(engine.h, engine.stream, _dt(x), x.numel() // c, c, _ptr(x), _ptr(gamma), _ptr(beta),
+                                             _ptr(mean), _ptr(iv), _ptr(y), 0), "sg_bn_apply")
+                return y
+            ref = engine.add_n([norm(a, par[0]) if "a" in which else a, norm(b, par[1]) if "b" in which else b], relu=relu)
+            ad, bd = a.to(dtype), b.to(dtype)
+            got = engine.add2_bn(ad, bd, par[0] if "a" in which else None, par[1] if "b" in which else None, relu=relu,
+                                 infer=infer, eps=1e-3)
+            if dtype == torch.float32:
+                assert torch.equal(got, ref), (which, infer, relu)
+            else:
+                ref16 = engine.add_n([norm(ad.float(), par[0]) if "a" in which else ad.float(),
+                                      norm(bd.float(), par[1]) if "b" in which else bd.float()], relu=relu)
+                assert float((got.float() - ref16).abs().max()) <= 2 ** -7 * float(ref16.abs().max())
+
+
 def test_upsample_bwd_large_window_with_pixel_stride_and_accumulate(engine):
     """The ASPP image-pooling case (1x1 -> HxW): the window kernel, rectangular windows, dy read out of a wider buffer
     (channel slice of a concat gradient), added to an existing dx."""
