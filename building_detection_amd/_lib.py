@@ -73,6 +73,7 @@ _SIGNATURES = {
     "sg_bias_grad": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz]),
     "sg_dwconv2d_fwd": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _i]),
     "sg_dwconv2d_dgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i]),
+    "sg_dwconv2d_dgrad_acc": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp]),
     "sg_dwconv2d_fwd_bn": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "sg_dwconv2d_wgrad_bn": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "sg_dwconv2d_wgrad_ws_bytes": (_sz, [_vp, _dp]),

@@ -143,7 +143,8 @@ struct DwRunParams {
   const T* __restrict__ in;        // x (fwd) or dy (dgrad)
   const float* __restrict__ w;     // [3][3][C]
   const T* __restrict__ mask;      // dgrad with pre_relu: forward input, else null
-  T* __restrict__ out;
+  const T* res;                    // dgrad: a gradient already collected for the same tensor, added to the result (may be `out`)
+  T* out;
   int N, H, W, C, in_ld, out_ld, mask_ld, relu_in, flip;
   // BN = true kernels: the input is the RAW output of the producing convolution and the preceding training-mode
   // BatchNormalization (+ ReLU) is applied as the window is loaded - fmaf((x - mean) * invstd, gamma, beta), the very
@@ -238,6 +239,11 @@ __global__ __launch_bounds__(256, 3) void dw_s1_run_kernel(const DwRunParams<T> 
         if constexpr (MASK) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] = m[k][e] > 0.f ? o[e] : 0.f;
+        }
+        if (p.res) {   // uniform: the other consumer's gradient of this tensor rides along (sg_dwconv2d_dgrad_acc)
+          const f32x4 rv = ld4<T>(p.res + (opix + k) * p.out_ld + c);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] += rv[e];
         }
         st4<T>(p.out + (opix + k) * p.out_ld + c, o);
       }
@@ -972,7 +978,7 @@ static int dwconv2d_fwd_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv
     const bool vec = (p.C % 4 == 0) && (p.x_ld % 4 == 0) && (p.y_ld % 4 == 0) && sg_aligned16(x) && sg_aligned16(w) && sg_aligned16(y);
     if (vec && dw_run_ok(d)) {
       DwRunParams<T> r;
-      r.in = (const T*)x; r.w = (const float*)w; r.mask = nullptr; r.out = (T*)y;
+      r.in = (const T*)x; r.w = (const float*)w; r.mask = nullptr; r.res = nullptr; r.out = (T*)y;
       r.bn_gamma = (const float*)bn_gamma; r.bn_beta = (const float*)bn_beta; r.bn_mean = (const float*)bn_mean; r.bn_invstd = (const float*)bn_invstd;
       r.N = d->N; r.H = d->H; r.W = d->W; r.C = p.C; r.in_ld = p.x_ld; r.out_ld = p.y_ld; r.mask_ld = 0;
       r.relu_in = pre_relu; r.flip = 0; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
@@ -1000,12 +1006,21 @@ int sg_dwconv2d_fwd_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc*
   return dwconv2d_fwd_impl(ctx, stream, dtype, d, x, w, y, relu, gamma, beta, mean, invstd);
 }
 
-int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
-                      const void* x_for_mask, void* dx, int pre_relu) {
+static int dwconv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                              const void* x_for_mask, void* dx, int pre_relu, const void* res) {
   int rc = dw_check(ctx, dtype, d, "sg_dwconv2d_dgrad");
   if (rc) return rc;
   SG_CHECK_ARG(dy && w && dx, "sg_dwconv2d_dgrad: null tensor");
   SG_CHECK_ARG(!pre_relu || x_for_mask, "sg_dwconv2d_dgrad: pre_relu needs the forward input");
+  if (res) {
+    const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+    if (!((d->Cin % 4 == 0) && (xl % 4 == 0) && (yl % 4 == 0) && sg_aligned16(dy) && sg_aligned16(w) && sg_aligned16(dx) &&
+          sg_aligned16(res) && (!pre_relu || sg_aligned16(x_for_mask)) && dw_run_ok(d))) {
+      sg_set_error("sg_dwconv2d_dgrad_acc: only the stride-1 3x3 run kernels (W %% 4 == 0, C %% 4 == 0, 16-byte aligned) add a "
+                   "collected gradient; add it afterwards instead");
+      return SG_EUNSUPPORTED;
+    }
+  }
   SG_DTYPE_SWITCH(dtype, "sg_dwconv2d_dgrad", {
     DwParams<T> p;
     dw_fill(p, d);
@@ -1015,6 +1030,7 @@ int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
     if (vec && dw_run_ok(d)) {  // stride-1 dgrad = the same stencil with the kernel flipped
       DwRunParams<T> r;
       r.in = (const T*)dy; r.w = (const float*)w; r.mask = pre_relu ? (const T*)x_for_mask : nullptr; r.out = (T*)dx;
+      r.res = (const T*)res;
       r.bn_gamma = r.bn_beta = r.bn_mean = r.bn_invstd = nullptr;
       r.N = d->N; r.H = d->H; r.W = d->W; r.C = p.C; r.in_ld = p.y_ld; r.out_ld = p.x_ld; r.mask_ld = p.x_ld;
       r.relu_in = 0; r.flip = 1; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
@@ -1029,6 +1045,17 @@ int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
   });
   SG_LAUNCH_CHECK("dw_dgrad_kernel");
   return 0;
+}
+
+int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                      const void* x_for_mask, void* dx, int pre_relu) {
+  return dwconv2d_dgrad_impl(ctx, stream, dtype, d, dy, w, x_for_mask, dx, pre_relu, nullptr);
+}
+
+int sg_dwconv2d_dgrad_acc(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                          const void* x_for_mask, void* dx, int pre_relu, const void* res) {
+  SG_CHECK_ARG(res != nullptr, "sg_dwconv2d_dgrad_acc: null res");
+  return dwconv2d_dgrad_impl(ctx, stream, dtype, d, dy, w, x_for_mask, dx, pre_relu, res);
 }
 
 size_t sg_dwconv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {

@@ -199,7 +199,15 @@ class _SepConvNode(Node):
         with e.side(None, t, dz):
             e.conv2d_wgrad(t, dz, dpw, want_b, dw=rt.grad(self.pw), db=rt.grad(self.b) if want_b else None)
         ddw = e.conv_desc(tuple(x.shape), x.shape[-1], 3, 3, self.stride, 1, "same")
-        dx = e.dwconv_dgrad(dt, rt.param(self.dw), ddw, x=x, pre_relu=self.pre_relu) if rt.needs_grad(self.inputs[0]) else None
+        dx = None
+        if rt.needs_grad(self.inputs[0]):
+            # a gradient already collected for this layer's input (the residual add of the block it opens) is added by the kernel
+            # (looked up through ReLU nodes that were absorbed into this layer's gather: they pass their gradient on unchanged)
+            root = self.inputs[0]
+            while isinstance(root.node, _ActNode) and root.node.fused_away and len(root.consumers) == 1:
+                root = root.node.inputs[0]
+            res = rt.take_pending(root) if e.dwconv_dgrad_acc_ok(ddw) else None
+            dx = e.dwconv_dgrad(dt, rt.param(self.dw), ddw, x=x, pre_relu=self.pre_relu, res=res)
         with e.side(None, x, dt, kind=3):
             e.dwconv_wgrad(x, dt, ddw, self.pre_relu, dw=rt.grad(self.dw), bn=rt.saved(self).get("bn"))
         return [dx]

@@ -368,11 +368,22 @@ class Engine:
               "sg_dwconv2d_fwd")
         return y
 
-    def dwconv_dgrad(self, dy, w, d: ConvDesc, x=None, pre_relu=False, out=None):
+    def dwconv_dgrad(self, dy, w, d: ConvDesc, x=None, pre_relu=False, out=None, res=None):
+        """res: a gradient already collected for the same input tensor, added to the result inside the kernel
+        (sg_dwconv2d_dgrad_acc: stride-1 3x3, W % 4 == 0, C % 4 == 0 only - dwconv_dgrad_acc_ok)."""
         dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin, dtype=dy.dtype)
+        if res is not None:
+            check(self.lib.sg_dwconv2d_dgrad_acc(self.h, self.stream, _dt(dy), C.byref(d), _ptr(dy), _ptr(w), _ptr(x), _ptr(dx),
+                                                 int(pre_relu), _ptr(res)), "sg_dwconv2d_dgrad_acc")
+            return dx
         check(self.lib.sg_dwconv2d_dgrad(self.h, self.stream, _dt(dy), C.byref(d), _ptr(dy), _ptr(w), _ptr(x), _ptr(dx),
                                          int(pre_relu)), "sg_dwconv2d_dgrad")
         return dx
+
+    @staticmethod
+    def dwconv_dgrad_acc_ok(d: ConvDesc) -> bool:
+        return (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.dilation == 1 and d.pad_t == 1 and d.pad_l == 1 and d.Ho == d.H
+                and d.Wo == d.W and d.W % 4 == 0 and d.Cin % 4 == 0 and d.x_ld == 0 and d.y_ld == 0)
 
     def dwconv_wgrad(self, x, dy, d: ConvDesc, pre_relu=False, dw=None, bn=None):
         if dw is None:

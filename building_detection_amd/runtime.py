@@ -722,6 +722,7 @@ class _Runtime:
         self._saved: Dict[int, dict] = {}
         self.bn_stats: Dict[int, tuple] = {}  # id(conv output tensor) -> (per-tile statistics, tiles)
         self.on_node_done = None
+        self._pending = None          # the sweep's gradient table while a node's backward runs (take_pending)
         self.node_done_fires = None   # optional predicate: will on_node_done(index) hand gradients over (all-reduce / cut)?
         # weight planes of the matrix-pipe convolutions, prepared once per optimiser step (ensure_planes)
         self._planes_key = None
@@ -833,6 +834,15 @@ class _Runtime:
     def needs_grad(self, sym: KTensor) -> bool:
         return sym.node is not None
 
+    def take_pending(self, sym: KTensor):
+        """Inside a node's backward: the gradient collected so far for tensor `sym` (the node's input, or the tensor its input
+        is an identity of), REMOVED from the sweep's table; None if there is none.  The node must return an input gradient
+        that includes it - the table then receives the complete gradient and no separate add runs."""
+        if self._pending is None or os.environ.get("SG_GRAD_ACC", "1") != "1":
+            return None
+        cur = self._pending.pop(id(sym), None)
+        return None if cur is None else cur[0]
+
     def shared(self, t):
         return _Shared(t)
 
@@ -894,7 +904,9 @@ class _Runtime:
             dy = slot[0]
             xs = [self.values[id(t)] for t in n.inputs]
             y = self.values[id(n.output)]
+            self._pending = grads
             dxs = n.backward(self, xs, y, dy)
+            self._pending = None
             for sym, g in zip(n.inputs, dxs):
                 if g is None or sym.node is None:
                     continue
@@ -906,6 +918,7 @@ class _Runtime:
                 cur = grads.get(id(sym))
                 if cur is None:
                     grads[id(sym)] = [g, fresh]
+
                 elif cur[1]:
                     e.add_n([cur[0], g], out=cur[0])
                 elif fresh:

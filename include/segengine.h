@@ -153,6 +153,12 @@ int sg_dwconv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
                     const void* w, void* y, int pre_relu);
 int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
                       const void* w, const void* x_for_mask, void* dx, int pre_relu);
+/* The same with a gradient already collected for the layer's input added to the result: dx = dgrad(dy) [masked] + res (res may
+ * be dx itself).  The input of an Xception block feeds the block AND its residual add; the block's input gradient then leaves
+ * this kernel complete instead of through a separate add (v3plus.py's `add([residual, shortcut])` blocks).  Stride-1 3x3,
+ * W % 4 == 0, C % 4 == 0, 16-byte aligned tensors, else SG_EUNSUPPORTED. */
+int sg_dwconv2d_dgrad_acc(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
+                          const void* w, const void* x_for_mask, void* dx, int pre_relu, const void* res);
 /* The depthwise convolution of a SeparableConv2D whose input is BatchNormalization(+ReLU) of a tensor x_raw, in training
  * mode, with that normalisation applied as the window is loaded - fmaf((x - mean) * invstd, gamma, beta), then max(., 0) if
  * relu - so that the normalised tensor is never written (the pattern BatchNormalization -> Activation('relu') ->

@@ -397,6 +397,25 @@ def test_upsample(engine, s):
     close(engine.upsample_bwd(dy.cuda(), x.shape, s), xr.grad, what="up bwd")
 
 
+@pytest.mark.parametrize("pre_relu", [False, True])
+def test_depthwise_dgrad_adds_a_collected_gradient(engine, pre_relu):
+    """sg_dwconv2d_dgrad_acc: dx = dgrad(dy) [masked by x > 0] + res inside the kernel - the bits of the dgrad followed by
+    add_n; res may be the output buffer itself."""
+    g = torch.Generator().manual_seed(5 + pre_relu)
+    n, h, w, c = 2, 12, 16, 728
+    x, dy, res = rnd(g, n, h, w, c).cuda(), rnd(g, n, h, w, c).cuda(), rnd(g, n, h, w, c).cuda()
+    wt = rnd(g, 3, 3, c, 1).cuda()
+    d = engine.conv_desc((n, h, w, c), c, 3, 3, 1, 1, "same")
+    assert engine.dwconv_dgrad_acc_ok(d)
+    ref = engine.add_n([res, engine.dwconv_dgrad(dy, wt, d, x=x, pre_relu=pre_relu)])
+    got = engine.dwconv_dgrad(dy, wt, d, x=x, pre_relu=pre_relu, res=res)
+    assert torch.equal(got, ref)
+    buf = res.clone()
+    engine.dwconv_dgrad(dy, wt, d, x=x, pre_relu=pre_relu, res=buf, out=buf)
+    assert torch.equal(buf, ref)
+    assert not engine.dwconv_dgrad_acc_ok(engine.conv_desc((n, h, w, c), c, 3, 3, 2, 1, "same"))
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("which", ["a", "b", "ab"])
 def test_add2_bn_equals_batchnorm_then_add(engine, which, dtype):
