@@ -67,6 +67,7 @@ _SIGNATURES = {
     "sg_bn_apply": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "sg_conv2d_dgrad_ws_bytes": (_sz, [_dp]),
     "sg_conv2d_dgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "sg_conv2d_dgrad_acc": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "sg_conv2d_wgrad_ws_bytes": (_sz, [_vp, _dp]),
     "sg_conv2d_wgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _vp, _sz]),
     "sg_bias_grad_ws_bytes": (_sz, [_vp, _i64, _i]),

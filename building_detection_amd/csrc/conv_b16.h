@@ -331,8 +331,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
     for (int idx = t; idx < BM * CPT; idx += NT) {
       const int rl = idx / CPT, c = idx - rl * CPT;
       const int row = m0 + rl, col = n0 + 8 * c;
-      if (row < p.M && col < p.Nout)
-        *reinterpret_cast<u32x4_t*>(py + row_to_yoff(p, row) + col) = *reinterpret_cast<const u32x4_t*>(smem + rl * TP + c * 16);
+      if (row < p.M && col < p.Nout) {
+        const int64_t yo = row_to_yoff(p, row) + col;
+        u32x4_t o = *reinterpret_cast<const u32x4_t*>(smem + rl * TP + c * 16);
+        if (p.res) {   // uniform: a collected gradient rides along (the tile's bf16 values + res in fp32, rounded again)
+          f32x4 a0 = {__uint_as_float(o[0] << 16), __uint_as_float(o[0] & 0xffff0000u), __uint_as_float(o[1] << 16),
+                      __uint_as_float(o[1] & 0xffff0000u)};
+          f32x4 a1 = {__uint_as_float(o[2] << 16), __uint_as_float(o[2] & 0xffff0000u), __uint_as_float(o[3] << 16),
+                      __uint_as_float(o[3] & 0xffff0000u)};
+          f32x4 b0, b1;
+          ld8_bf16(reinterpret_cast<const bf16_t*>(p.res) + yo, b0, b1);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { a0[e] += b0[e]; a1[e] += b1[e]; }
+          st8_bf16(py + yo, a0, a1);
+        } else {
+          *reinterpret_cast<u32x4_t*>(py + yo) = o;
+        }
+      }
     }
   } else {
 #pragma unroll
@@ -348,7 +363,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) void conv_b16_kernel
           if (cv && row < p.M) {
             float v = acc[i][j][r] + bv;
             if (do_relu) v = fmaxf(v, 0.f);
-            st1<bf16_t>(py + row_to_yoff(p, row) + col, v);
+            const int64_t yo = row_to_yoff(p, row) + col;
+            if (p.res) v += ld1<bf16_t>(reinterpret_cast<const bf16_t*>(p.res) + yo);
+            st1<bf16_t>(py + yo, v);
           }
         }
       }

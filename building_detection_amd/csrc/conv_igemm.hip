@@ -70,6 +70,9 @@ struct IgemmParams {
   // 2 / 4 taps instead of 9 four times, a 1x1 kernel one tap for a quarter of the tiles and none for the rest.
   int perm2;
   FastDiv fd_mc, fd_hcwc, fd_wc;
+  // dgrad: a gradient already collected for the same tensor (y's layout, may be y itself), added in the epilogue
+  // (sg_conv2d_dgrad_acc; conv_x6_kernel / conv_b16_kernel only)
+  const float* res;
 };
 
 __device__ __forceinline__ int spt_of(const IgemmParams& p) { return p.C / BK; }  // slabs per tap (UT)
@@ -1170,6 +1173,16 @@ template <int NPL, typename TA>
 int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH, int KW, void* ws, int num_cus,
            hipStream_t st, bool prepared = false) {
   // prepared: `ws` already holds this launch's weight planes (sg_prepare_planes, once per optimiser step), no split here
+  if (p.res) {  // only the slab kernels below add a collected gradient (callers ask sg_conv2d_planes_job: kind 1)
+    bool other = false;
+    if constexpr (NPL == 3) other = x6p_ok(p, KH, KW);
+    if constexpr ((NPL == 3 && std::is_same<TA, float>::value) || (NPL == 1 && !std::is_same<TA, float>::value))
+      other = other || pw_wide_ok(p, EL<TA>::BYTES);
+    if (other) {
+      sg_set_error("sg_conv2d_dgrad_acc: this launch takes the patch / wide pointwise kernel, which do not add a collected gradient");
+      return SG_EUNSUPPORTED;
+    }
+  }
   if constexpr (NPL == 3) {
     if (x6p_ok(p, KH, KW)) return run_x6p(p, w, dgrad, Cin, Cout, ws, num_cus, st, prepared);
   }
@@ -1698,6 +1711,7 @@ void fill_fwd_params(IgemmParams& p, const sg_conv_desc* d, const void* x, const
   p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
   p.stats = nullptr;
   p.perm2 = 0;
+  p.res = nullptr;
 }
 
 void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, const void* wt, const void* bias, void* dx,
@@ -1722,6 +1736,7 @@ void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, co
   p.w_bytes = wb < (1ll << 31) ? (uint32_t)wb : 0;
   p.stats = nullptr;
   p.perm2 = 0;
+  p.res = nullptr;
 }
 
 // any-shape fallback for bf16 storage: the native fp32-MFMA kernel with widening loads (TA) and a rounding store (TY).
@@ -2042,8 +2057,22 @@ size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d) {
   return native > x6 ? native : x6;
 }
 
+static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                            const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* res);
+
 int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
                     const void* bias, void* dx, int flags, void* ws, size_t ws_bytes) {
+  return conv2d_dgrad_impl(ctx, stream, dtype, d, dy, w, bias, dx, flags, ws, ws_bytes, nullptr);
+}
+
+int sg_conv2d_dgrad_acc(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                        const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* res) {
+  SG_CHECK_ARG(res != nullptr, "sg_conv2d_dgrad_acc: null res");
+  return conv2d_dgrad_impl(ctx, stream, dtype, d, dy, w, bias, dx, flags, ws, ws_bytes, res);
+}
+
+static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                            const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* res) {
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_dgrad: null ctx");
   SG_CHECK_ARG(dt_ok(dtype), "sg_conv2d_dgrad: dtype %d", dtype);
   int rc = check_desc(d, "sg_conv2d_dgrad");
@@ -2066,6 +2095,10 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   const bool thin = thin_ok(d) && aligned16(dx) && !(flags & (SG_EPI_BIAS | SG_EPI_RELU));
   SG_CHECK_ARG(!head32 || (b16 && d->Cout <= 4), "sg_conv2d_dgrad: SG_HEAD_F32 needs Cout <= 4 (a softmax head) on bf16 storage");
   hipStream_t st = (hipStream_t)stream;
+  if (res && (head32 || thin)) {
+    sg_set_error("sg_conv2d_dgrad_acc: thin / softmax-head launches do not add a collected gradient");
+    return SG_EUNSUPPORTED;
+  }
   if (head32 && !thin) {  // fp32 dy in, bf16 dx out, any shape
     const int nb = images_per_2gib_mixed(d, 2, 4);  // dx bf16 (the forward's x), dy fp32
     SG_CHECK_ARG(nb >= 1, "sg_conv2d_dgrad: one image of the softmax head beyond 2 GiB");
@@ -2096,8 +2129,9 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
         sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
         const char* dys = (const char*)dy + (int64_t)n0 * d->Ho * d->Wo * yl * eb;
         char* dxs = (char*)dx + (int64_t)n0 * d->H * d->W * xl * eb;
+        const char* ress = res ? (const char*)res + (int64_t)n0 * d->H * d->W * xl * eb : nullptr;
         g_sub_batch = true;
-        int rcs = sg_conv2d_dgrad(ctx, stream, dtype, &sub, dys, w, bias, dxs, flags, ws, ws_bytes);
+        int rcs = conv2d_dgrad_impl(ctx, stream, dtype, &sub, dys, w, bias, dxs, flags, ws, ws_bytes, ress);
         g_sub_batch = false;
         if (rcs) return rcs;
       }
@@ -2122,6 +2156,7 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   float* wt = (float*)ws;
   IgemmParams p;
   fill_dgrad_params(p, d, dy, wt, bias, dx, flags, eb);
+  p.res = (const float*)res;
   const int ch = b16 ? 8 : 4;
   const bool vec = (d->Cout % ch == 0) && (p.x_ld % ch == 0) && (d->Cin % 4 == 0) && aligned16(dy);
   const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);
@@ -2140,6 +2175,10 @@ int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   if (prepared) {
     sg_set_error("sg_conv2d_dgrad: SG_WS_PREPARED planes given, but this launch does not take a prepared-planes kernel");
     return SG_EINVAL;
+  }
+  if (res) {
+    sg_set_error("sg_conv2d_dgrad_acc: this launch takes the fp32-MFMA kernels, which do not add a collected gradient");
+    return SG_EUNSUPPORTED;
   }
   {
     dim3 grid((unsigned)sg_cdiv(d->Cout, 32), (unsigned)sg_cdiv(d->Cin, 32), (unsigned)(d->KH * d->KW));

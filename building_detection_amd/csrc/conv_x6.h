@@ -667,7 +667,9 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         if (cv && row < p.M) {
           float v = acc[i][j][r] + bv;
           if (do_relu) v = fmaxf(v, 0.f);
-          st1<TA>(reinterpret_cast<TA*>(p.y) + row_to_yoff(p, row) + col, v);
+          const int64_t yo = row_to_yoff(p, row) + col;
+          if (p.res) v += ld1<TA>(reinterpret_cast<const TA*>(p.res) + yo);   // uniform: a collected gradient rides along
+          st1<TA>(reinterpret_cast<TA*>(p.y) + yo, v);
         }
       }
     }

@@ -124,8 +124,19 @@ class _ConvNode(Node):
             want_b = self.b is not None and not getattr(self, "bias_grad_zero", False)
             # the input gradient first: the chain goes on with it, the filter gradient follows on the side stream beside the
             # bandwidth-bound kernels of the next node (two MFMA kernels side by side only share the matrix pipe)
-            dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype, planes=rt.planes(self, "d")) \
-                if rt.needs_grad(self.inputs[0]) else None
+            dx = None
+            if rt.needs_grad(self.inputs[0]):
+                # a gradient already collected for this layer's input (it has other consumers: the ASPP branches, a block's
+                # shortcut convolution) is added in the dgrad kernel's epilogue where the launch takes the slab kernels
+                res = None
+                # (not for the dilated ASPP / SK convolutions: they are the roofline kernel set, timed as pure convolutions)
+                if (self._tag is None and rt.plane_kind(self, "d") == 1 and rt.planes(self, "d") is not None
+                        and dz.dtype == x.dtype):
+                    root = self.inputs[0]
+                    while isinstance(root.node, _ActNode) and root.node.fused_away and len(root.consumers) == 1:
+                        root = root.node.inputs[0]
+                    res = rt.take_pending(root)
+                dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype, planes=rt.planes(self, "d"), res=res)
             with e.side(self._tag, x, dz):
                 e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=rt.grad(self.w), db=rt.grad(self.b) if want_b else None)
         return [dx]

@@ -312,9 +312,11 @@ class Engine:
                                             wsp, wsn), "sg_conv2d_fwd_ws")
         return y
 
-    def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None, out_dtype=None, planes=None):
+    def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None, out_dtype=None, planes=None, res=None):
         """dx of the forward conv described by `d`; also Conv2DTranspose forward (then bias/relu apply).
-        out_dtype = torch.bfloat16 with an fp32 dy: the backward of the fp32 softmax head of a bf16 model (SG_HEAD_F32)."""
+        out_dtype = torch.bfloat16 with an fp32 dy: the backward of the fp32 softmax head of a bf16 model (SG_HEAD_F32).
+        res: a gradient already collected for the same tensor, added in the kernel's epilogue (sg_conv2d_dgrad_acc: only for
+        launches whose prepared planes are of kind 1, the slab kernels)."""
         _chk(dy, "dy"); _chk32(w, "w")
         odt = out.dtype if out is not None else (out_dtype or dy.dtype)
         dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin, dtype=odt)
@@ -325,8 +327,12 @@ class Engine:
             wsp, wsn = self.ws(self.lib.sg_conv2d_dgrad_ws_bytes(C.byref(d)))
         flags = (_lib.SG_EPI_BIAS if bias is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
         with self.timed(self._gemm_tag()):
-            check(self.lib.sg_conv2d_dgrad(self.h, self.stream, dt, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
-                                           flags, wsp, wsn), "sg_conv2d_dgrad")
+            if res is not None:
+                check(self.lib.sg_conv2d_dgrad_acc(self.h, self.stream, dt, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
+                                                   flags, wsp, wsn, _ptr(res)), "sg_conv2d_dgrad_acc")
+            else:
+                check(self.lib.sg_conv2d_dgrad(self.h, self.stream, dt, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
+                                               flags, wsp, wsn), "sg_conv2d_dgrad")
         return dx
 
     def conv2d_wgrad(self, x, dy, d: ConvDesc, want_bias=True, dw=None, db=None):

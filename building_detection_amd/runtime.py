@@ -727,6 +727,7 @@ class _Runtime:
         # weight planes of the matrix-pipe convolutions, prepared once per optimiser step (ensure_planes)
         self._planes_key = None
         self._planes_ptr: Dict[tuple, int] = {}
+        self._planes_kind: Dict[tuple, int] = {}
         self._planes_arena = None
         self._planes_jobs = None
         self._planes_launch = (0, 0)
@@ -772,6 +773,10 @@ class _Runtime:
                                                       C.c_void_p(arena.data_ptr()), C.c_void_p(jobs.data_ptr()), launch[0],
                                                       launch[1]), "sg_prepare_planes")
 
+    def plane_kind(self, node, tag) -> int:
+        """Which kernel family `node`'s launch `tag` takes (sg_conv2d_planes_job's kind; 0: none of the prepared-plane kernels)."""
+        return self._planes_kind.get((id(node), tag), 0) if self._planes_ptr else 0
+
     def planes(self, node, tag):
         """Device address of the prepared planes of `node`'s launch `tag` ("f" / "d"), or None (the launch then converts its
         kernel itself, in the workspace)."""
@@ -788,7 +793,7 @@ class _Runtime:
         key = (int(batch), m.compute_dtype, e.lib.sg_get_conv_x6(), bwd)
         if key != self._planes_key:
             dt = _lib.SG_BF16 if m.compute_dtype == "bfloat16" else _lib.SG_F32
-            jobs, ptr_of, off, blocks = [], {}, 0, 0
+            jobs, ptr_of, kinds, off, blocks = [], {}, {}, 0, 0
             for n in m.nodes:
                 sites = getattr(n, "plane_sites", None)
                 if sites is None:
@@ -803,10 +808,12 @@ class _Runtime:
                         continue
                     job.w_off, job.out_off, job.block0 = wspec.offset, off, blocks
                     ptr_of[(id(n), tag)] = off
+                    kinds[(id(n), tag)] = int(job.kind)
                     off += (nbytes.value + 255) // 256 * 256
                     blocks += job.nblocks
                     jobs.append(job)
             self._planes_key = key
+            self._planes_kind = kinds   # 1: slab kernels (conv_x6 / conv_b16), 2: patch kernel, 3: wide pointwise kernel
             self._planes_ptr = {}
             self._planes_arena = self._planes_jobs = None
             self._planes_launch = (len(jobs), blocks)

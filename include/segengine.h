@@ -130,6 +130,12 @@ int sg_bn_apply(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const
 size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d);
 int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
                     const void* w, const void* bias, void* dx, int flags, void* ws, size_t ws_bytes);
+/* sg_conv2d_dgrad with a gradient already collected for the same tensor added in the epilogue: dx = dgrad(dy) [+ bias] [relu]
+ * + res (res in dx's layout; it may be dx itself).  Only launches that take the slab kernels (sg_conv2d_planes_job kind 1) do
+ * this; the others return SG_EUNSUPPORTED and launch nothing. */
+int sg_conv2d_dgrad_acc(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
+                        const void* w, const void* bias, void* dx, int flags, void* ws, size_t ws_bytes,
+                        const void* res);
 
 /* Conv2D kernel gradient dw[KH,KW,Cin,Cout] (and dbias[Cout] if non-null) = sum over N*Ho*Wo.
  * Deterministic split-K: partial slabs in ws, then a fixed-order reduce (no float atomics: bit-reproducible run

@@ -397,6 +397,33 @@ def test_upsample(engine, s):
     close(engine.upsample_bwd(dy.cuda(), x.shape, s), xr.grad, what="up bwd")
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 96, 3, 1, 2), (2, 32, 32, 64, 128, 1, 2, 1), (1, 16, 16, 256, 40, 3, 1, 1)],
+                         ids=["dilated3x3", "stride2_1x1_parity_rows", "ragged_columns"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_conv_dgrad_adds_a_collected_gradient(engine, case, dtype):
+    """sg_conv2d_dgrad_acc: dx = dgrad(dy) + res in the epilogue of the slab kernels (conv_x6_kernel / conv_b16_kernel, also
+    with the stride-2 parity-class row order).  fp32: the bits of the dgrad followed by add_n, res may be the output itself;
+    bf16: within one rounding of it."""
+    n, h, w, cin, cout, k, stride, dil = case
+    g = torch.Generator().manual_seed(cin + cout + k)
+    x_shape = (n, h, w, cin)
+    wt = (rnd(g, k, k, cin, cout) * (1.0 / np.sqrt(k * k * cin))).cuda()
+    d = engine.conv_desc(x_shape, cout, k, k, stride, dil, "same")
+    dy = rnd(g, n, d.Ho, d.Wo, cout).cuda().to(dtype)
+    res = rnd(g, *x_shape).cuda().to(dtype)
+    plain = engine.conv2d_dgrad(dy, wt, d)
+    ref = engine.add_n([res, plain])
+    got = engine.conv2d_dgrad(dy, wt, d, res=res)
+    if dtype == torch.float32:
+        assert torch.equal(got, ref)
+        buf = res.clone()
+        engine.conv2d_dgrad(dy, wt, d, res=buf, out=buf)
+        assert torch.equal(buf, ref)
+    else:
+        exact = res.float() + plain.float()
+        assert float((got.float() - exact).abs().max()) <= 2 ** -7 * float(exact.abs().max())
+
+
 @pytest.mark.parametrize("pre_relu", [False, True])
 def test_depthwise_dgrad_adds_a_collected_gradient(engine, pre_relu):
     """sg_dwconv2d_dgrad_acc: dx = dgrad(dy) [masked by x > 0] + res inside the kernel - the bits of the dgrad followed by
