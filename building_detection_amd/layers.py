@@ -562,6 +562,13 @@ class _AvgPoolNode(Node):
     def backward(self, rt, xs, y, dy):
         (x,) = xs
         kh, kw = self._k(x)
+        # a gradient buffer the sweep already owns for this input (scSE's combine node, the other ASPP branches): the spread-out
+        # dy / (kh kw) is added into it in place instead of being written out and summed by a separate add
+        acc = rt.take_pending(self.inputs[0], owned_only=True)
+        if acc is not None and acc.dtype == dy.dtype:
+            return [rt.eng.avgpool_bwd(dy, tuple(x.shape), kh, kw, out=acc, accumulate=True)]
+        if acc is not None:
+            rt.put_back(self.inputs[0], acc)
         return [rt.eng.avgpool_bwd(dy, tuple(x.shape), kh, kw)]
 
 

@@ -841,14 +841,22 @@ class _Runtime:
     def needs_grad(self, sym: KTensor) -> bool:
         return sym.node is not None
 
-    def take_pending(self, sym: KTensor):
+    def take_pending(self, sym: KTensor, owned_only: bool = False):
         """Inside a node's backward: the gradient collected so far for tensor `sym` (the node's input, or the tensor its input
         is an identity of), REMOVED from the sweep's table; None if there is none.  The node must return an input gradient
-        that includes it - the table then receives the complete gradient and no separate add runs."""
+        that includes it - the table then receives the complete gradient and no separate add runs.  owned_only: only a
+        buffer the sweep may write in place (not a gradient shared with another tensor) - for nodes that accumulate into it."""
         if self._pending is None or os.environ.get("SG_GRAD_ACC", "1") != "1":
             return None
-        cur = self._pending.pop(id(sym), None)
-        return None if cur is None else cur[0]
+        cur = self._pending.get(id(sym))
+        if cur is None or (owned_only and not cur[1]):
+            return None
+        del self._pending[id(sym)]
+        return cur[0]
+
+    def put_back(self, sym: KTensor, t):
+        """Undo an owned take_pending the node could not use."""
+        self._pending[id(sym)] = [t, True]
 
     def shared(self, t):
         return _Shared(t)
