@@ -1454,8 +1454,8 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const TA* __restrict__ x,
 
 template <int CO, typename TA, typename TY>
 __global__ __launch_bounds__(256) void thin_dgrad_kernel(const TY* __restrict__ dy, const float* __restrict__ w,
-                                                         TA* __restrict__ dx, int64_t total, int chunks, int y_ld,
-                                                         int x_ld) {
+                                                         TA* dx, int64_t total, int chunks, int y_ld, int x_ld,
+                                                         const TA* res) {
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (gid >= total) return;
   const int64_t pix = gid / chunks;
@@ -1470,6 +1470,11 @@ __global__ __launch_bounds__(256) void thin_dgrad_kernel(const TY* __restrict__ 
 #pragma unroll
     for (int o = 0; o < CO; ++o) a = fmaf(g[o], w[(4 * c + k) * CO + o], a);
     r[k] = a;
+  }
+  if (res) {   // uniform: a gradient already collected for the same tensor (sg_conv2d_dgrad_acc; may be dx itself)
+    const f32x4 t = ld4<TA>(res + pix * x_ld + 4 * c);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] += t[k];
   }
   st4<TA>(dx + pix * x_ld + 4 * c, r);
 }
@@ -1531,12 +1536,12 @@ int thin_fwd_t(const sg_conv_desc* d, const TA* x, const float* w, const float* 
 }
 
 template <int CO, typename TA, typename TY>
-int thin_dgrad_t(const sg_conv_desc* d, const TY* dy, const float* w, TA* dx, hipStream_t st) {
+int thin_dgrad_t(const sg_conv_desc* d, const TY* dy, const float* w, TA* dx, hipStream_t st, const void* res = nullptr) {
   const int64_t P = (int64_t)d->N * d->H * d->W;
   const int chunks = d->Cin / 4;
   const int64_t total = P * chunks;
   hipLaunchKernelGGL((thin_dgrad_kernel<CO, TA, TY>), dim3((unsigned)sg_cdiv(total, 256)), dim3(256), 0, st, dy, w, dx, total, chunks,
-                     d->y_ld ? d->y_ld : d->Cout, d->x_ld ? d->x_ld : d->Cin);
+                     d->y_ld ? d->y_ld : d->Cout, d->x_ld ? d->x_ld : d->Cin, (const TA*)res);
   SG_LAUNCH_CHECK("thin_dgrad_kernel");
   return 0;
 }
@@ -2095,8 +2100,8 @@ static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv
   const bool thin = thin_ok(d) && aligned16(dx) && !(flags & (SG_EPI_BIAS | SG_EPI_RELU));
   SG_CHECK_ARG(!head32 || (b16 && d->Cout <= 4), "sg_conv2d_dgrad: SG_HEAD_F32 needs Cout <= 4 (a softmax head) on bf16 storage");
   hipStream_t st = (hipStream_t)stream;
-  if (res && (head32 || thin)) {
-    sg_set_error("sg_conv2d_dgrad_acc: thin / softmax-head launches do not add a collected gradient");
+  if (res && head32) {
+    sg_set_error("sg_conv2d_dgrad_acc: softmax-head launches do not add a collected gradient");
     return SG_EUNSUPPORTED;
   }
   if (head32 && !thin) {  // fp32 dy in, bf16 dx out, any shape
@@ -2140,7 +2145,7 @@ static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv
   }
   if (thin) {
     if (!b16) {
-#define CALL(CO) thin_dgrad_t<CO, float, float>(d, (const float*)dy, (const float*)w, (float*)dx, st)
+#define CALL(CO) thin_dgrad_t<CO, float, float>(d, (const float*)dy, (const float*)w, (float*)dx, st, res)
       THIN_SWITCH(d->Cout, CALL)
 #undef CALL
     } else if (head32) {
@@ -2148,7 +2153,7 @@ static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv
       THIN_SWITCH(d->Cout, CALL)
 #undef CALL
     } else {
-#define CALL(CO) thin_dgrad_t<CO, bf16_t, bf16_t>(d, (const bf16_t*)dy, (const float*)w, (bf16_t*)dx, st)
+#define CALL(CO) thin_dgrad_t<CO, bf16_t, bf16_t>(d, (const bf16_t*)dy, (const float*)w, (bf16_t*)dx, st, res)
       THIN_SWITCH(d->Cout, CALL)
 #undef CALL
     }

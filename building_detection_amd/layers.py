@@ -8,6 +8,8 @@ reference's un-fused spelling onto the generic nodes.
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -130,8 +132,11 @@ class _ConvNode(Node):
                 # shortcut convolution) is added in the dgrad kernel's epilogue where the launch takes the slab kernels
                 res = None
                 # (not for the dilated ASPP / SK convolutions: they are the roofline kernel set, timed as pure convolutions)
-                if (self._tag is None and rt.plane_kind(self, "d") == 1 and rt.planes(self, "d") is not None
-                        and dz.dtype == x.dtype):
+                # or the thin 1x1 kernel (scSE's spatial squeeze, Cout = 1)
+                thin = (self.k == 1 and self.stride == 1 and self.filters <= 4 and x.shape[-1] % 4 == 0 and x.shape[-1] >= 16
+                        and "SG_CONV_NOTHIN" not in os.environ)
+                if (self._tag is None and dz.dtype == x.dtype
+                        and (thin or (rt.plane_kind(self, "d") == 1 and rt.planes(self, "d") is not None))):
                     root = self.inputs[0]
                     while isinstance(root.node, _ActNode) and root.node.fused_away and len(root.consumers) == 1:
                         root = root.node.inputs[0]

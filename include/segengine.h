@@ -131,8 +131,8 @@ size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d);
 int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
                     const void* w, const void* bias, void* dx, int flags, void* ws, size_t ws_bytes);
 /* sg_conv2d_dgrad with a gradient already collected for the same tensor added in the epilogue: dx = dgrad(dy) [+ bias] [relu]
- * + res (res in dx's layout; it may be dx itself).  Only launches that take the slab kernels (sg_conv2d_planes_job kind 1) do
- * this; the others return SG_EUNSUPPORTED and launch nothing. */
+ * + res (res in dx's layout; it may be dx itself).  Only launches that take the slab kernels (sg_conv2d_planes_job kind 1) or
+ * the thin 1x1 kernel (Cout <= 4, not the fp32 softmax head) do this; the others return SG_EUNSUPPORTED and launch nothing. */
 int sg_conv2d_dgrad_acc(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
                         const void* w, const void* bias, void* dx, int flags, void* ws, size_t ws_bytes,
                         const void* res);

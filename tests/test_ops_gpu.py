@@ -397,8 +397,9 @@ def test_upsample(engine, s):
     close(engine.upsample_bwd(dy.cuda(), x.shape, s), xr.grad, what="up bwd")
 
 
-@pytest.mark.parametrize("case", [(2, 16, 32, 64, 96, 3, 1, 2), (2, 32, 32, 64, 128, 1, 2, 1), (1, 16, 16, 256, 40, 3, 1, 1)],
-                         ids=["dilated3x3", "stride2_1x1_parity_rows", "ragged_columns"])
+@pytest.mark.parametrize("case", [(2, 16, 32, 64, 96, 3, 1, 2), (2, 32, 32, 64, 128, 1, 2, 1), (1, 16, 16, 256, 40, 3, 1, 1),
+                                  (2, 16, 16, 64, 1, 1, 1, 1)],
+                         ids=["dilated3x3", "stride2_1x1_parity_rows", "ragged_columns", "thin_1x1_to_1"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_conv_dgrad_adds_a_collected_gradient(engine, case, dtype):
     """sg_conv2d_dgrad_acc: dx = dgrad(dy) + res in the epilogue of the slab kernels (conv_x6_kernel / conv_b16_kernel, also
