@@ -242,8 +242,8 @@ def main():
         model = zoo.BUILDERS[args.model]((args.size, args.size, 3), 2, aspp_pool=args.size // 16)
     else:
         model = zoo.BUILDERS[args.model]((args.size, args.size, 3))
-    # One GPU, neither --jit nor --no-jit: the step is captured during the warm-up AND tried both ways (two untimed steps
-    # each); the timed region runs the faster form.  Eager launches overlap the filter gradients on a second stream (DESIGN
+    # One GPU, neither --jit nor --no-jit: the step is captured during the warm-up AND tried both ways (three untimed steps
+    # each, median); the timed region runs the faster form.  Eager launches overlap the filter gradients on a second stream (DESIGN
     # 10.9) and are 2 - 5 % faster while the Python host keeps ahead of the GPU (60 ms of enqueue per 77 ms step); on a box whose
     # CPUs are busy with other tenants' work the same step was measured host-bound at 134 ms, where the replay (0.5 ms of host
     # time per step) does not care.
@@ -280,13 +280,15 @@ def main():
     sync()
     choice = None
     if auto and jit:
-        def trial(n=2):
-            sync()
-            t = time.perf_counter()
+        def trial(n=3):   # median of n individually timed steps: one stalled step (a busy neighbour) does not decide
+            ts = []
             for _ in range(n):
+                sync()
+                t = time.perf_counter()
                 model.train_on_batch(xd, yd, return_device_scalars=True)
-            sync()
-            return (time.perf_counter() - t) / n * 1e3
+                sync()
+                ts.append((time.perf_counter() - t) * 1e3)
+            return sorted(ts)[n // 2]
         t_replay = trial()
         model.jit_compile = False
         t_eager = trial()
