@@ -458,3 +458,28 @@ def test_segmented_data_parallel_step_gloo_world2():
         assert ok, f"rank {rank}: the arena after the segmented step is not the sum of the per-rank gradients"
         assert same_points, "segments hand buckets over at other points than the eager reducer"
         assert nb >= 4 and 2 <= nseg <= nb + 1
+
+
+def test_residual_adds_take_over_their_batchnorm_layers(monkeypatch):
+    """Model._fuse: a BatchNormalization (no fused ReLU) whose only consumer is a two-operand Add is applied BY that Add
+    (sg_add2_bn; layers._AddNode.bn_src / _BNNode.defer_add).  Graph-level check on the CPU: the Xception blocks of DeepLabv3+
+    (23 layers: 16 middle-flow branches + the branch and the 1x1 shortcut of the entry / exit blocks + ...), HRNet's basic
+    blocks, none in Res34-UNet (its blocks activate before they add); SG_BN_ADD=0 switches the pass off; every deferred layer
+    is consumed by exactly the Add that lists it."""
+    sys.path.insert(0, ROOT)
+    from building_detection_amd import zoo, layers as L
+
+    def count(m):
+        adds = [n for n in m.nodes if isinstance(n, L._AddNode)]
+        pairs = [(n, s) for n in adds for s in n.bn_src if s is not None]
+        for n, s in pairs:
+            assert s.defer_add is n and not s.relu and s.output.consumers == [n] and len(n.inputs) == 2
+        assert sum(1 for b in m.nodes if isinstance(b, L._BNNode) and b.defer_add is not None) == len(pairs)
+        return len(pairs)
+
+    monkeypatch.delenv("SG_BN_ADD", raising=False)
+    assert count(zoo.BUILDERS["v3plus"]((128, 128, 3), 2, aspp_pool=8)) == 23
+    assert count(zoo.BUILDERS["hrnet"]((64, 64, 3))) == 42
+    assert count(zoo.BUILDERS["res34"]((64, 64, 3))) == 0
+    monkeypatch.setenv("SG_BN_ADD", "0")
+    assert count(zoo.BUILDERS["v3plus"]((128, 128, 3), 2, aspp_pool=8)) == 0
