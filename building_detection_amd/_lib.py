@@ -84,7 +84,7 @@ _SIGNATURES = {
     "sg_bn_train_fwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _sz]),
     "sg_bn_train_bwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "sg_bn_infer": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i]),
-    "sg_add2_bn": (_i, [_vp, _vp, _i, _i64, _i] + [_vp] * 11 + [_i, _i, _f]),
+    "sg_add2_bn": (_i, [_vp, _vp, _i, _i64, _i] + [_vp] * 11 + [_i, _i, _f, _i, _i]),
     "sg_act_fwd": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),
     "sg_act_bwd": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp, _vp, _i]),
     "sg_add_n": (_i, [_vp, _vp, _i, _i, _pp, _i64, _vp, _i]),

@@ -299,6 +299,7 @@ struct Add2BnArgs {
   const float* invstd[2];
   const float* gamma[2];
   const float* beta[2];
+  int relu_op[2];   // the operand's BatchNormalization has a fused ReLU (Res34's blocks activate before they add)
 };
 
 template <int V, typename T>
@@ -330,8 +331,10 @@ __global__ __launch_bounds__(256) void add2_bn_kernel(const T* __restrict__ a, c
     float o[V];
 #pragma unroll
     for (int k = 0; k < V; ++k) {
-      const float ta = on[0] ? fmaf((xa[k] - mv[0][k]) * is[0][k], gv[0][k], bv[0][k]) : xa[k];
-      const float tb = on[1] ? fmaf((xb[k] - mv[1][k]) * is[1][k], gv[1][k], bv[1][k]) : xb[k];
+      float ta = on[0] ? fmaf((xa[k] - mv[0][k]) * is[0][k], gv[0][k], bv[0][k]) : xa[k];
+      float tb = on[1] ? fmaf((xb[k] - mv[1][k]) * is[1][k], gv[1][k], bv[1][k]) : xb[k];
+      if (q.relu_op[0]) ta = fmaxf(ta, 0.f);
+      if (q.relu_op[1]) tb = fmaxf(tb, 0.f);
       float t = ta + tb;
       if (relu) t = fmaxf(t, 0.f);
       o[k] = t;
@@ -534,7 +537,7 @@ int sg_bn_apply(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const
 
 int sg_add2_bn(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* a, const void* b, const void* a_mean,
                const void* a_invstd, const void* a_gamma, const void* a_beta, const void* b_mean, const void* b_invstd,
-               const void* b_gamma, const void* b_beta, void* y, int relu, int infer, float eps) {
+               const void* b_gamma, const void* b_beta, void* y, int relu, int infer, float eps, int a_relu, int b_relu) {
   SG_CHECK_ARG(ctx && (dtype == SG_F32 || dtype == SG_BF16), "sg_add2_bn: bad ctx/dtype");
   SG_CHECK_ARG(rows > 0 && C > 0 && a && b && y, "sg_add2_bn: bad argument");
   SG_CHECK_ARG((a_mean != nullptr) == (a_invstd != nullptr && a_gamma != nullptr && a_beta != nullptr) &&
@@ -548,6 +551,8 @@ int sg_add2_bn(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const 
   Add2BnArgs q;
   q.mean[0] = (const float*)a_mean; q.invstd[0] = (const float*)a_invstd; q.gamma[0] = (const float*)a_gamma; q.beta[0] = (const float*)a_beta;
   q.mean[1] = (const float*)b_mean; q.invstd[1] = (const float*)b_invstd; q.gamma[1] = (const float*)b_gamma; q.beta[1] = (const float*)b_beta;
+  q.relu_op[0] = (a_mean && a_relu) ? 1 : 0;
+  q.relu_op[1] = (b_mean && b_relu) ? 1 : 0;
   SG_DTYPE_SWITCH(dtype, "sg_add2_bn", {
     const bool wide = sizeof(T) == 2 && C % 8 == 0;
     const int V = wide ? 8 : 4;

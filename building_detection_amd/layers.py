@@ -726,7 +726,9 @@ class _AddNode(Node):
                             (rt.param(src.gamma), rt.param(src.beta))
             if bn[0] is not None or bn[1] is not None:
                 eps = next(s.epsilon for s in self.bn_src if s is not None)
-                return rt.eng.add2_bn(xs[0], xs[1], bn[0], bn[1], relu=self.relu, infer=not training, eps=eps)
+                ra, rb = (s is not None and s.relu for s in self.bn_src)
+                return rt.eng.add2_bn(xs[0], xs[1], bn[0], bn[1], relu=self.relu, infer=not training, eps=eps,
+                                      relu_a=ra and bn[0] is not None, relu_b=rb and bn[1] is not None)
         return rt.eng.add_n(xs, relu=self.relu)
 
     def backward(self, rt, xs, y, dy):

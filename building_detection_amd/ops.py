@@ -479,16 +479,16 @@ class Engine:
         check(self.lib.sg_add_n(self.h, self.stream, _dt(xs[0]), len(xs), arr, xs[0].numel(), _ptr(y), int(relu)), "sg_add_n")
         return y
 
-    def add2_bn(self, a, b, bn_a=None, bn_b=None, relu=False, infer=False, eps=1e-3, out=None):
+    def add2_bn(self, a, b, bn_a=None, bn_b=None, relu=False, infer=False, eps=1e-3, out=None, relu_a=False, relu_b=False):
         """relu?(f_a(a) + f_b(b)): bn_x = (mean, invstd | moving variance, gamma, beta) applies that BatchNormalization to the
-        operand on the way (sg_add2_bn), None leaves it as it is."""
+        operand on the way (sg_add2_bn), None leaves it as it is; relu_x: followed by that layer's fused ReLU."""
         _chk(a, "a"); _chk(b, "b")
         c = a.shape[-1]
         y = out if out is not None else torch.empty_like(a)
         pa = [_ptr(t) for t in bn_a] if bn_a is not None else [None] * 4
         pb = [_ptr(t) for t in bn_b] if bn_b is not None else [None] * 4
         check(self.lib.sg_add2_bn(self.h, self.stream, _dt(a), a.numel() // c, c, _ptr(a), _ptr(b), *pa, *pb, _ptr(y), int(relu),
-                                  int(infer), float(eps)), "sg_add2_bn")
+                                  int(infer), float(eps), int(relu_a), int(relu_b)), "sg_add2_bn")
         return y
 
     def copy_channels(self, src, src_off, dst, dst_off, c, accumulate=False):

@@ -157,7 +157,12 @@ class Model:
                 epss = set()
                 for i, t in enumerate(n.inputs):
                     p_ = t.node
-                    if (isinstance(p_, L._BNNode) and not p_.relu and p_.defer_to is None and p_.defer_add is None
+                    through_relu = False   # BN -> ReLU (absorbed into the BN) -> Add: the Add applies both (res34.py's blocks)
+                    if (isinstance(p_, L._ActNode) and p_.fused_away and len(t.consumers) == 1 and id(t) not in outs
+                            and isinstance(p_.inputs[0].node, L._BNNode) and p_.inputs[0].node.relu
+                            and len(p_.inputs[0].consumers) == 1):
+                        t, p_, through_relu = p_.inputs[0], p_.inputs[0].node, True
+                    if (isinstance(p_, L._BNNode) and p_.relu == through_relu and p_.defer_to is None and p_.defer_add is None
                             and len(t.consumers) == 1 and id(t) not in outs and t.shape[-1] % 4 == 0
                             and n.inputs[0] is not n.inputs[1]):
                         n.bn_src[i], p_.defer_add = p_, n

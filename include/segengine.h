@@ -233,10 +233,12 @@ int sg_bn_train_fwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
  * add([BatchNormalization(branch), shortcut]) and add([BN(branch), BN(1x1 shortcut)])):
  * y = [relu](f_a(a) + f_b(b)), f = gamma * (x - mean) * invstd + beta for an operand whose four parameter pointers are given
  * (infer != 0: `invstd` holds the moving VARIANCE and eps is added under the root), the identity for null pointers.  The
- * normalised tensor is never materialised.  C % 4 == 0 and 16-byte aligned tensors, else SG_EUNSUPPORTED. */
+ * normalised tensor is never materialised.  a_relu / b_relu: that operand's BatchNormalization is followed by a ReLU before the
+ * add (res34.py's blocks).  C % 4 == 0 and 16-byte aligned tensors, else SG_EUNSUPPORTED. */
 int sg_add2_bn(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* a, const void* b,
                const void* a_mean, const void* a_invstd, const void* a_gamma, const void* a_beta, const void* b_mean,
-               const void* b_invstd, const void* b_gamma, const void* b_beta, void* y, int relu, int infer, float eps);
+               const void* b_invstd, const void* b_gamma, const void* b_beta, void* y, int relu, int infer, float eps,
+               int a_relu, int b_relu);
 /* With a fused ReLU the backward needs the mask [y > 0].  Given beta it is recomputed from x (the same
  * fmaf((x-mean)*invstd, gamma, beta) the forward evaluated), which saves reading y in both passes; with
  * beta == NULL the mask is read from y. */

@@ -470,6 +470,10 @@ def test_add2_bn_equals_batchnorm_then_add(engine, which, dtype):
             ad, bd = a.to(dtype), b.to(dtype)
             got = engine.add2_bn(ad, bd, par[0] if "a" in which else None, par[1] if "b" in which else None, relu=relu,
                                  infer=infer, eps=1e-3)
+            if dtype == torch.float32 and which == "ab":   # an operand's own fused ReLU (res34.py: activation before the add)
+                refr = engine.add_n([torch.relu(norm(a, par[0])), norm(b, par[1])], relu=relu)
+                gotr = engine.add2_bn(a, b, par[0], par[1], relu=relu, infer=infer, eps=1e-3, relu_a=True)
+                assert torch.equal(gotr, refr), ("relu_a", infer, relu)
             if dtype == torch.float32:
                 assert torch.equal(got, ref), (which, infer, relu)
             else:
