@@ -135,6 +135,33 @@ def cpu_baseline(threads, batch, size, steps, model=None):
     return out
 
 
+def bf16_leg(args):
+    """BASELINE configs[2] on one GPU: `bench.py --dtype bf16` (same model, batch and tile size; 3 warm-up + 10 timed steps, its
+    own family / dilated-set brackets) as a CHILD process; returns the figures the driver's record should carry."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--dtype", "bf16", "--steps", "10", "--warmup", "3",
+           "--batch", str(args.batch), "--size", str(args.size), "--model", args.model, "--no-cpu-baseline", "--no-bf16-leg"]
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=420)
+        line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return {"error": f"exit {r.returncode}: {r.stderr.decode()[-400:]}"}
+        j = json.loads(line[-1])
+        rf = j.get("roofline", {})
+        return {"ms_per_step": j["ms_per_step"], "tiles_per_s": j["value"], "steps": j["steps"], "warmup": j["warmup"],
+                "dtype": j["dtype"], "dtype_note": j.get("dtype_note"),
+                "roofline": {"frac": rf.get("frac"), "achieved": rf.get("achieved"), "peak": rf.get("peak"), "unit": rf.get("unit"),
+                             "ms_per_step": rf.get("ms_per_step")},
+                "family": {"frac": (rf.get("family") or {}).get("frac"), "achieved": (rf.get("family") or {}).get("achieved"),
+                           "ms_per_step": (rf.get("family") or {}).get("ms_per_step")},
+                "train_step": j["config"].get("train_step"), "train_step_choice": j["config"].get("train_step_choice"),
+                "final_loss": j["config"].get("final_loss"), "host_enqueue_ms_per_step": j["config"].get("host_enqueue_ms_per_step"),
+                "peak_device_memory_gib": j["config"].get("peak_device_memory_gib"),
+                "note": "child process `bench.py --dtype bf16`, after and outside the fp32 timed region"}
+    except Exception as e:   # the leg must never take the fp32 line down
+        return {"error": repr(e)}
+
+
 def spawn_ranks(n: int) -> int:
     """Start `n` copies of this script as ranks 0..n-1 of one job (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
     environment, rendezvous on 127.0.0.1), wait for them, return the worst exit code.  Rank 0's stdout (the JSON
@@ -196,6 +223,9 @@ def main():
                          "(config.train_step_choice)")
     ap.add_argument("--no-jit", dest="jit", action="store_false")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-bf16-leg", action="store_true",
+                    help="skip config.bf16_leg (BASELINE configs[2]'s per-GPU workload: the same model and batch with bf16 storage, "
+                         "3 warm-up + 10 steps in a child process after the fp32 timed region; single-GPU fp32 DeepLabv3+ runs only)")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--comm", default=os.environ.get("SG_BENCH_COMM", "sg"), choices=["sg", "torch"],
                     help="gradient all-reduce transport: sg = RCCL through libsegengine's sg_comm_* (C ABI), torch = "
@@ -304,6 +334,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     prof = eng.profile_end()
+    peak_mem = torch.cuda.max_memory_allocated(local_rank)
     # outside the timed region: two more steps with EVERY GEMM-convolution launch bracketed (the whole kernel family)
     # (every rank runs them - the data-parallel step all-reduces - but only rank 0 brackets its launches)
     fam = {}
@@ -420,6 +451,15 @@ def main():
                     out["cpu_baseline"]["parity"]["what"] += " (bf16 engine vs the fp32 oracle: the tolerance contract of DESIGN.md section 8, not the 1e-3 fp32 bar)"
             except Exception as e:  # the baseline must never take the GPU number down with it
                 out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        out["config"]["peak_device_memory_gib"] = round(peak_mem / 2.0 ** 30, 2)
+        out["config"]["side_stream_filter_gradients"] = os.environ.get("SG_SIDE_WGRAD", "1") != "0"
+        if world == 1 and not b16 and args.model == "v3plus" and not args.no_bf16_leg:
+            # BASELINE configs[2]'s per-GPU workload (bf16 storage), AFTER and OUTSIDE the fp32 timed region: a child process
+            # (started, not exec'ed: this process has used the GPU) runs the same bench with --dtype bf16 and its line is
+            # folded into config.bf16_leg.  The fp32 model's memory is released first.
+            del model
+            torch.cuda.empty_cache()
+            out["config"]["bf16_leg"] = bf16_leg(args)
         sys.stdout.flush()
         os.write(_JSON_FD, (json.dumps(out) + "\n").encode())   # the ONE line on the real stdout
     if dist is not None:

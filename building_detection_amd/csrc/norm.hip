@@ -543,7 +543,6 @@ int sg_add2_bn(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const 
   SG_CHECK_ARG((a_mean != nullptr) == (a_invstd != nullptr && a_gamma != nullptr && a_beta != nullptr) &&
                    (b_mean != nullptr) == (b_invstd != nullptr && b_gamma != nullptr && b_beta != nullptr),
                "sg_add2_bn: an operand's four BatchNormalization parameters come together or not at all");
-  SG_CHECK_ARG(rows * C < (1ll << 31), "sg_add2_bn: tensor exceeds 2^31 elements");
   if (!((C % 4 == 0) && sg_aligned16(a) && sg_aligned16(b) && sg_aligned16(y))) {
     sg_set_error("sg_add2_bn: needs C %% 4 == 0 and 16-byte aligned tensors; apply the BatchNormalization and add instead");
     return SG_EUNSUPPORTED;
@@ -553,22 +552,31 @@ int sg_add2_bn(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const 
   q.mean[1] = (const float*)b_mean; q.invstd[1] = (const float*)b_invstd; q.gamma[1] = (const float*)b_gamma; q.beta[1] = (const float*)b_beta;
   q.relu_op[0] = (a_mean && a_relu) ? 1 : 0;
   q.relu_op[1] = (b_mean && b_relu) ? 1 : 0;
+  // The kernel indexes with 32 bits: a tensor of 2^31 elements or more (the BatchNormalization in front of this add has
+  // already handed its RAW input on, so there is no unfused form to fall back to) is walked in row chunks below that, each
+  // an even number of rows so that a chunk starts 16-byte aligned with bf16 storage too.  Element-wise: same bits.
+  const int64_t chunk_rows = rows * C < (1ll << 31) ? rows : (((1ll << 31) - 1) / C) & ~1ll;
+  SG_CHECK_ARG(chunk_rows > 0, "sg_add2_bn: a single row exceeds 2^31 elements");
   SG_DTYPE_SWITCH(dtype, "sg_add2_bn", {
     const bool wide = sizeof(T) == 2 && C % 8 == 0;
     const int V = wide ? 8 : 4;
-    int prow = 0;
-    dim3 grid;
-    if (!bn_cols_grid(ctx->num_cus, rows, C / V, 2, prow, grid)) {
-      sg_set_error("sg_add2_bn: no column-stationary grid for C = %d", C);
-      return SG_EUNSUPPORTED;
+    for (int64_t r0 = 0; r0 < rows; r0 += chunk_rows) {
+      const int64_t nr = rows - r0 < chunk_rows ? rows - r0 : chunk_rows;
+      const T* ca = (const T*)a + r0 * C;
+      const T* cb = (const T*)b + r0 * C;
+      T* cy = (T*)y + r0 * C;
+      int prow = 0;
+      dim3 grid;
+      if (!bn_cols_grid(ctx->num_cus, nr, C / V, 2, prow, grid)) {
+        sg_set_error("sg_add2_bn: no column-stationary grid for C = %d", C);
+        return SG_EUNSUPPORTED;
+      }
+      const FastDiv fd = make_fastdiv((uint32_t)(C / V));
+      if (wide)
+        hipLaunchKernelGGL((add2_bn_kernel<8, T>), grid, dim3(256), 0, (hipStream_t)stream, ca, cb, q, cy, nr, C, relu, eps, infer, prow, fd);
+      else
+        hipLaunchKernelGGL((add2_bn_kernel<4, T>), grid, dim3(256), 0, (hipStream_t)stream, ca, cb, q, cy, nr, C, relu, eps, infer, prow, fd);
     }
-    const FastDiv fd = make_fastdiv((uint32_t)(C / V));
-    if (wide)
-      hipLaunchKernelGGL((add2_bn_kernel<8, T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, q, (T*)y, rows, C,
-                         relu, eps, infer, prow, fd);
-    else
-      hipLaunchKernelGGL((add2_bn_kernel<4, T>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)a, (const T*)b, q, (T*)y, rows, C,
-                         relu, eps, infer, prow, fd);
   });
   SG_LAUNCH_CHECK("add2_bn_kernel");
   return 0;

@@ -102,20 +102,23 @@ class SgTransport:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = torch.device("cuda", device) if isinstance(device, int) else device
-        # Rank 0 draws the RCCL id; EVERY rank then takes part in the broadcast, whatever happened on rank 0: a failure
-        # there (no usable librccl for dlopen - the one case DataParallel's "sg_or_torch" fallback exists for) travels as
-        # (None, message), so that all ranks raise the same error after the same collective and meet again in the
-        # caller's next one, instead of rank 0 leaving the others waiting inside this broadcast.
-        ident = [(None, None)]
-        if self.rank == 0:
-            try:
-                ident[0] = (_unique_id(self.lib, _lib), None)
-            except Exception as e:
-                ident[0] = (None, f"{type(e).__name__}: {e}")
-        dist.broadcast_object_list(ident, src=0, group=group)  # any backend: the id is 128 opaque host bytes
-        uid, err = ident[0]
-        if uid is None:
-            raise _lib.SgError(f"sg_comm_unique_id failed on rank 0: {err}")
+        # EVERY rank probes its own RCCL first (sg_comm_unique_id: dlopen + a local ncclGetUniqueId, no communication; the one
+        # failure DataParallel's "sg_or_torch" fallback exists for is "no usable librccl for dlopen"), then all ranks exchange
+        # (ok, message) AND rank 0's id in ONE collective.  Only when every rank is ready does anybody enter sg_comm_init
+        # (ncclCommInitRank, itself a collective): a rank whose library is missing can therefore never leave the others
+        # waiting inside ncclCommInitRank, and all ranks raise the same error after the same collective.  (A failure INSIDE
+        # ncclCommInitRank - a fabric fault - is RCCL's to report on every rank; it is not the fallback's case.)
+        mine = [None, None]
+        try:
+            mine[0] = _unique_id(self.lib, _lib)
+        except Exception as e:
+            mine[1] = f"{type(e).__name__}: {e}"
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, (mine[0] if self.rank == 0 else (mine[0] is not None), mine[1]), group=group)
+        bad = [(r, m) for r, (ok, m) in enumerate(everyone) if not ok]
+        if bad:
+            raise _lib.SgError("sg_comm_unique_id failed on rank(s) " + ", ".join(f"{r}: {m}" for r, m in bad))
+        uid = everyone[0][0]
         h = C.c_void_p()
         _lib.check(self.lib.sg_comm_init(uid, self.rank, self.world, self.device.index, C.byref(h)), "sg_comm_init")
         self.h = h
@@ -173,10 +176,12 @@ def make_transport(comm: str, device, group=None, fallback_backend: str = "nccl"
     """The gradient transport of a DataParallel model.
 
     comm: "torch" | "sg" | "sg_or_torch" | "auto" (torch on an nccl group, sg otherwise).  "sg_or_torch" falls back to
-    torch.distributed when libsegengine cannot bring RCCL up.  The decision is a collective: SgTransport.__init__ lets
-    every rank see rank 0's failure (same broadcast, same exception), then all ranks sum a failure flag - also covering a
-    rank-local failure after the broadcast - and take the same branch.  `fallback_backend` is "nccl" in production; the
-    CPU tests pass "gloo"."""
+    torch.distributed when libsegengine cannot bring RCCL up on ANY rank.  The decision is a collective: in
+    SgTransport.__init__ every rank probes its own librccl and all ranks exchange the outcome before anybody calls
+    ncclCommInitRank, so either all ranks construct the transport or all raise the same error; the summed flag below then
+    only confirms that they take the same branch.  What this does NOT cover: a failure inside ncclCommInitRank itself (all
+    ranks are in that collective together; RCCL reports or times out on every rank).  `fallback_backend` is "nccl" in
+    production; the CPU tests pass "gloo"."""
     import torch
     import torch.distributed as dist
     if comm == "auto":

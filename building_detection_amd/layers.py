@@ -142,8 +142,8 @@ class _ConvNode(Node):
                         root = root.node.inputs[0]
                     res = rt.take_pending(root)
                 dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype, planes=rt.planes(self, "d"), res=res)
-            with e.side(self._tag, x, dz):
-                e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=rt.grad(self.w), db=rt.grad(self.b) if want_b else None)
+            gw, gb = rt.grad(self.w), (rt.grad(self.b) if want_b else None)
+            e.side_run(self._tag, (x, dz), lambda: e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=gw, db=gb))
         return [dx]
 
     def flops(self, batch):
@@ -212,8 +212,8 @@ class _SepConvNode(Node):
         dpw = e.conv_desc(tuple(t.shape), self.filters, 1, 1)
         want_b = not getattr(self, "bias_grad_zero", False)
         dt = e.conv2d_dgrad(dz, rt.param(self.pw), dpw, planes=rt.planes(self, "d"))
-        with e.side(None, t, dz):
-            e.conv2d_wgrad(t, dz, dpw, want_b, dw=rt.grad(self.pw), db=rt.grad(self.b) if want_b else None)
+        gpw, gb = rt.grad(self.pw), (rt.grad(self.b) if want_b else None)
+        e.side_run(None, (t, dz), lambda: e.conv2d_wgrad(t, dz, dpw, want_b, dw=gpw, db=gb))
         ddw = e.conv_desc(tuple(x.shape), x.shape[-1], 3, 3, self.stride, 1, "same")
         dx = None
         if rt.needs_grad(self.inputs[0]):
@@ -224,8 +224,12 @@ class _SepConvNode(Node):
                 root = root.node.inputs[0]
             res = rt.take_pending(root) if e.dwconv_dgrad_acc_ok(ddw) else None
             dx = e.dwconv_dgrad(dt, rt.param(self.dw), ddw, x=x, pre_relu=self.pre_relu, res=res)
-        with e.side(None, x, dt, kind=3):
-            e.dwconv_wgrad(x, dt, ddw, self.pre_relu, dw=rt.grad(self.dw), bn=rt.saved(self).get("bn"))
+        bn = rt.saved(self).get("bn")
+        # (the deferred BatchNormalization's mean / invstd belong to that node's saved state, which the sweep drops right after
+        # its backward: the side stream's reader keeps them alive as it keeps x and dt)
+        gdw = rt.grad(self.dw)
+        e.side_run(None, (x, dt) + (tuple(bn[:4]) if bn else ()),
+                   lambda: e.dwconv_wgrad(x, dt, ddw, self.pre_relu, dw=gdw, bn=bn), kind=3)
         return [dx]
 
     def flops(self, batch):
@@ -283,9 +287,12 @@ class _ConvTNode(Node):
         dz = e.act_bwd(y, dy, _lib.SG_ACT_RELU) if self.activation == "relu" else dy
         d = self.fdesc(rt, x)
         # dw_F = wgrad_F(x_F = dz, dy_F = x); the bias gradient is the column sum of dz
-        with e.side(None, dz, x):
-            e.conv2d_wgrad(dz, x, d, want_bias=False, dw=rt.grad(self.w))
-            e.bias_grad(dz, rt.grad(self.b))
+        gw, gb = rt.grad(self.w), rt.grad(self.b)
+
+        def filter_and_bias_gradient():
+            e.conv2d_wgrad(dz, x, d, want_bias=False, dw=gw)
+            e.bias_grad(dz, gb)
+        e.side_run(None, (dz, x), filter_and_bias_gradient)
         dx = e.conv2d_fwd(dz, rt.param(self.w), None, desc=d, planes=rt.planes(self, "f")) if rt.needs_grad(self.inputs[0]) else None
         return [dx]
 

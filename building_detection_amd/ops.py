@@ -7,6 +7,7 @@ tf.keras `get_weights()` layouts (HWIO, depthwise [kh,kw,C,1], Conv2DTranspose [
 """
 from __future__ import annotations
 
+import collections
 import contextlib
 import ctypes as C
 import os
@@ -145,8 +146,16 @@ class Engine:
         self._side_stream = None
         self.side_launches = 0   # blocks that went to the side stream (tests)
         self._side_dirty = False
-        self._side_keep = []     # operands of the side stream's launches, released at the next join
+        # Operands of the side stream's launches.  They live in the main stream's pool and must not be handed out again while
+        # the side stream may still read them: groups of blocks are closed by an event on the side stream ((event, tensors),
+        # oldest first) and dropped as soon as that event has completed (polled at the next side block) - not only at the
+        # join at the end of the sweep, which would keep every layer's output gradient alive for the whole backward pass.
+        self._side_keep = []         # tensors of the open group (no event recorded yet)
+        self._side_groups = collections.deque()
+        self._side_free_events = []
+        self._side_group_blocks = 0
         self._in_side = False
+        self.lane = None         # set while a training step is captured with a side lane (side_run defers into it)
         self._ws2 = torch.empty(1 << 20, dtype=torch.uint8, device=self.device)
         self._ws2_peak = 0
         self._ws2_pinned = False
@@ -186,13 +195,55 @@ class Engine:
         finally:
             self._in_side = False
             self._side_dirty = True
+            self._side_group_blocks += 1
+            if self._side_group_blocks >= self._SIDE_GROUP:
+                self._close_side_group(sd)
+            while self._side_groups and self._side_groups[0][0].query():   # the side stream is past this group's launches
+                ev, _ = self._side_groups.popleft()
+                self._side_free_events.append(ev)
+
+    _SIDE_GROUP = 4   # side blocks per release event (an event costs the host a few microseconds)
+
+    def side_run(self, tag, tensors, fn, kind=2):
+        """`fn()` - the launches of one filter gradient - beside the input-gradient chain.  Eager step: inside side() (second
+        stream behind an event).  While a training step is being captured with lanes (runtime.GraphedTrainStep sets
+        `self.lane`): NOT launched now but deferred - the capture collects the segment's filter-gradient calls and records
+        them into a side graph of their own after the segment's main graph, which the replay launches on the second stream
+        beside the NEXT segment.  `tensors` are the operands the call reads (kept alive for it either way)."""
+        lane = self.lane
+        if (lane is not None and self._side_on and not self._in_side
+                and not (self._side_mode in (2, 3) and self._side_mode != kind)):
+            lane.defer(fn, [t for t in tensors if t is not None])
+            return
+        with self.side(tag, *tensors, kind=kind):
+            fn()
+
+    def _close_side_group(self, sd):
+        if self._side_keep:
+            ev = self._side_free_events.pop() if self._side_free_events else torch.cuda.Event()
+            ev.record(sd)
+            self._side_groups.append((ev, self._side_keep))
+            self._side_keep = []
+        self._side_group_blocks = 0
+
+    def side_kept_bytes(self) -> int:
+        """Bytes of operands currently held for the side stream (tests)."""
+        seen, n = set(), 0
+        for t in [t for _, ts in self._side_groups for t in ts] + list(self._side_keep):
+            if t.data_ptr() not in seen:
+                seen.add(t.data_ptr())
+                n += t.numel() * t.element_size()
+        return n
 
     def join_side(self):
         """The current stream waits for everything queued on the side stream (before the gradients are read)."""
         if self._side_dirty:
             torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
             self._side_dirty = False
-            self._side_keep.clear()
+            self._side_keep = []
+            while self._side_groups:
+                self._side_free_events.append(self._side_groups.popleft()[0])
+            self._side_group_blocks = 0
 
     def ws(self, nbytes: int):
         nbytes = int(nbytes)

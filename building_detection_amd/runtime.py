@@ -529,6 +529,23 @@ class GraphedPredict:
         return self.y
 
 
+class _Lane:
+    """The filter-gradient calls deferred while one segment of a training step is captured (ops.Engine.side_run)."""
+
+    def __init__(self):
+        self.thunks, self.keep, self.blocks = [], [], 0
+
+    def defer(self, fn, tensors):
+        self.thunks.append(fn)
+        self.keep.extend(tensors)
+        self.blocks += 1
+
+    def take(self):
+        out = (self.thunks, self.keep)
+        self.thunks, self.keep, self.blocks = [], [], 0
+        return out
+
+
 class GraphedTrainStep:
     """One optimisation step of a compiled model - forward, loss, confusion counts, backward, Adam - captured into
     hipGraphs for one (x, y) shape (Model.compile(jit_compile=True)).  The step's inputs are two static device buffers, its
@@ -537,13 +554,20 @@ class GraphedTrainStep:
     planes are rebuilt inside the graph (the capture starts with them marked stale), BatchNorm's moving statistics and the
     optimiser moments are updated in place as in the eager step.
 
-    Single process: ONE graph.  Under data parallelism (model.dist set) the capture is CUT wherever the backward sweep
-    completes a gradient bucket (dist.BucketReducer's schedule): the step becomes a short chain of graph SEGMENTS - forward +
-    loss + backward down to the first complete bucket, then one segment per further bucket - plus one graph for Adam.
-    Between two segments the host hands the finished bucket to the transport EXACTLY as the eager step does (an eager
-    sg_comm_allreduce_sum / all_reduce on the communication stream behind an event on the compute stream), so RCCL never
-    runs inside a capture and the all-reduce of bucket k still overlaps the backward of segment k+1.  A step costs the host
-    (segments + 1) graph launches and (buckets + 2) collective calls instead of ~1800 kernel launches."""
+    The capture is CUT into a chain of graph SEGMENTS, plus one graph for Adam:
+      * under data parallelism (model.dist set) wherever the backward sweep completes a gradient bucket
+        (dist.BucketReducer's schedule): between two segments the host hands the finished bucket to the transport EXACTLY as
+        the eager step does (an eager sg_comm_allreduce_sum / all_reduce on the communication stream), so RCCL never runs
+        inside a capture and the all-reduce of bucket k still overlaps the backward of segment k+1;
+      * with lanes (SG_JIT_LANES, default on) also every SG_JIT_LANE_BLOCKS filter gradients: a segment's filter-gradient
+        calls are NOT recorded into its main graph M_k but collected (Engine.side_run -> _Lane) and recorded, right after
+        M_k, into a side graph W_k of their own.  The replay launches M_0, W_0 || M_1, W_1 || M_2 ...: W_k goes to the
+        second stream behind an event after M_k and runs beside M_(k+1) - the eager step's overlap of the MFMA-bound filter
+        gradients with the bandwidth-bound kernels of the chain, for two graph launches and three event
+        calls per segment instead of ~1800 kernel launches.  (ONE forked graph replays correctly too, but hipGraphLaunch
+        then queues its nodes from the host one by one: 56 ms.)  Memory: the operands W_k reads live in the capture's pool;
+        they are held until the capture of M_(k+2) begins, and the replay makes M_(k+2) wait for W_k.
+    Same kernels on the same operands as the eager step: bit-identical results."""
 
     def __init__(self, model: "Model", xd, yd):
         import torch
@@ -554,8 +578,12 @@ class GraphedTrainStep:
         dist = model.dist
         self.x, self.y = torch.empty_like(xd), torch.empty_like(yd)
         self.lr = eng.zeros(4)
-        # (the eager sizing steps ran the filter gradients on the side stream with its own scratch; here they run inline)
+        lanes = os.environ.get("SG_JIT_LANES", "1") != "0" and eng._side_on
+        lane_blocks = max(1, int(os.environ.get("SG_JIT_LANE_BLOCKS", "6")))
+        # (the eager sizing steps ran the filter gradients on the side stream with its own scratch; without lanes they run
+        # inline here, on the main scratch)
         self.ws = torch.empty(max(eng._ws_peak, eng._ws2_peak, 256) + 256, dtype=torch.uint8, device=eng.device)
+        self.ws2 = torch.empty(max(eng._ws2_peak, 256) + 256, dtype=torch.uint8, device=eng.device) if lanes else None
         rt.release()
         # The job table of the weight planes is (re)built HERE, outside the capture, for this batch and mode: a forward with
         # another batch size since the eager warm-up steps (a validation batch, a predict()) has re-keyed the runtime's
@@ -565,67 +593,91 @@ class GraphedTrainStep:
         rt.weights_changed()  # the graph must contain the plane preparation: every replay follows an optimiser step
         self._planes_key = rt._planes_key
         torch.cuda.synchronize(eng.device)
-        self.segments = []        # [(graph, [(start, end) arena ranges complete after it])]
-        pool = torch.cuda.graph_pool_handle() if dist is not None else None
+        self.segments = []        # [main graph, [(start, end) arena ranges complete after it], side graph | None, kept operands]
+        segmented = dist is not None or lanes
+        pool = torch.cuda.graph_pool_handle() if segmented else None
         cuts = _SegmentCuts(dist.reducer.buckets) if dist is not None else None
+        lane = _Lane() if lanes else None
         state = {"ctx": None, "graph": None}
+        mode = "thread_local" if segmented else "global"
 
         def begin():
+            if len(self.segments) >= 2:   # the replay makes this segment wait for W_(k-2): its operands may be reused from here on
+                self.segments[-2][3] = None
             g = torch.cuda.CUDAGraph()
             kw = {"pool": pool} if pool is not None else {}
-            ctx = torch.cuda.graph(g, capture_error_mode="thread_local", **kw)
+            ctx = torch.cuda.graph(g, capture_error_mode=mode, **kw)
             ctx.__enter__()
             state["ctx"], state["graph"] = ctx, g
 
         def end(ready):
             state["ctx"].__exit__(None, None, None)
-            self.segments.append((state["graph"], ready))
+            main_graph = state["graph"]
             state["ctx"] = state["graph"] = None
+            side_graph, keep = None, None
+            if lane is not None and lane.thunks:
+                thunks, keep = lane.take()
+                side_graph = torch.cuda.CUDAGraph()
+                eng.lane = None          # (the calls below ARE the deferred ones)
+                eng._in_side = True      # their scratch is the side buffer
+                try:
+                    with torch.cuda.graph(side_graph, capture_error_mode=mode):
+                        for fn in thunks:
+                            fn()
+                finally:
+                    eng._in_side = False
+                    eng.lane = lane
+            self.segments.append([main_graph, ready, side_graph, keep])
 
         def fires(index):
-            return cuts.next < len(cuts.buckets) and cuts.buckets[cuts.next][2] >= index
+            return cuts is not None and cuts.next < len(cuts.buckets) and cuts.buckets[cuts.next][2] >= index
 
-        def node_done(index):   # the backward sweep has finished node `index`: cut when that completes buckets
-            ready = cuts.pop_ready(index)
-            if ready:
+        def node_done(index):   # the backward sweep has finished node `index`: cut when that completes buckets / fills the lane
+            ready = cuts.pop_ready(index) if cuts is not None else []
+            if ready or (lane is not None and lane.blocks >= lane_blocks):
                 end(ready)
                 if index > 0:   # node 0 ends the sweep: nothing is left to capture behind it
                     begin()
 
         saved_hook, saved_fires = rt.on_node_done, rt.node_done_fires
-        # (no side-stream scratch: inside a capture the filter gradients stay on the capturing stream.  A forked graph was
-        # measured - it replays correctly, but hipGraphLaunch then queues its ~2000 nodes from the host in 56 ms instead of
-        # 0.5 ms and the step is 1.4 ms SLOWER than the linear graph, against 1.5 ms faster for forked eager launches)
-        with eng.private_ws(self.ws), _CaptureGuard():
+        with eng.private_ws(self.ws, self.ws2), _CaptureGuard():
             try:
-                rt.on_node_done = node_done if dist is not None else None
-                rt.node_done_fires = fires if dist is not None else None
+                rt.on_node_done = node_done if segmented else None
+                rt.node_done_fires = fires if segmented else None
+                eng.lane = lane
                 begin()
                 p = rt.forward(self.x, training=True)
                 self.loss = eng.loss_fwd(model.loss_kind, p, self.y)
                 self.counts = eng.confusion_counts(p, self.y) if model.metric_names else None
                 dp = eng.loss_bwd(model.loss_kind, p, self.y, 1.0)
                 rt.backward(dp)
-                if dist is None:  # Adam rides in the same graph
+                if not segmented:  # Adam rides in the same graph
                     eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, 0.0, opt.beta_1, opt.beta_2, opt.epsilon, 1.0,
                                   lr_dev=self.lr)
                     end([])
                 else:
                     if state["ctx"] is not None:
-                        end(cuts.pop_ready(-1))
-                    assert cuts.done(), "a gradient bucket was never handed over"
-                    begin()  # its own graph: it runs after the LAST all-reduce has joined the compute stream
+                        end(cuts.pop_ready(-1) if cuts is not None else [])
+                    assert cuts is None or cuts.done(), "a gradient bucket was never handed over"
+                    eng.lane = None
+                    begin()  # its own graph: it runs after the LAST all-reduce / side graph has joined the compute stream
                     eng.adam_step(rt.w_train, rt.adam_m, rt.adam_v, rt.g_train, 0.0, opt.beta_1, opt.beta_2, opt.epsilon,
-                                  1.0 / dist.world, lr_dev=self.lr)
+                                  1.0 / (dist.world if dist is not None else 1), lr_dev=self.lr)
                     end([])
             finally:
+                eng.lane = None
                 if state["ctx"] is not None:   # an error inside a capture: leave capture mode before re-raising
                     try:
                         state["ctx"].__exit__(None, None, None)
                     except Exception:
                         pass
                 rt.on_node_done, rt.node_done_fires = saved_hook, saved_fires
+        for seg in self.segments:
+            seg[3] = None   # nothing is allocated in the pool from here on
+        self.segmented = segmented
         self.graph = self.segments[0][0]
+        self.side_graphs = sum(1 for seg in self.segments if seg[2] is not None)
+        self._lanes = _StreamLanes(eng) if self.side_graphs else None
         self._loss_out = self._counts_out = None
         assert rt._planes_key == self._planes_key, "the weight-plane job table was rebuilt inside the capture"
         self._planes = (rt._planes_arena, rt._planes_jobs)  # kept alive: the graph's nodes carry their addresses
@@ -642,10 +694,14 @@ class GraphedTrainStep:
         t = opt.iterations
         lr_t = float(opt.lr) * math.sqrt(1.0 - opt.beta_2 ** t) / (1.0 - opt.beta_1 ** t)
         self.lr.fill_(lr_t)
-        if dist is None:
+        if not self.segmented:
             self.graph.replay()
-        else:
-            run_segments([(g.replay, ready) for g, ready in self.segments[:-1]], self.rt.g_train, dist.tp)
+            self.rt.weights_changed()
+            return self.loss, self.counts
+        run_segments([(g.replay, ready, None if w is None else w.replay) for g, ready, w, _ in self.segments[:-1]],
+                     self.rt.g_train, dist.tp if dist is not None else None, self._lanes)
+        out = (self.loss, self.counts)
+        if dist is not None:
             # loss / counts of the GLOBAL batch: reduced in ordinary buffers of this object (the graphs' own outputs live in
             # the capture's private pool and are rewritten by the next replay)
             if self._loss_out is None:
@@ -655,11 +711,48 @@ class GraphedTrainStep:
             if self.counts is not None:
                 self._counts_out.copy_(self.counts)
             out = dist.reduce_step_scalars(self._loss_out, self._counts_out)
-            self.segments[-1][0].replay()   # Adam on the summed gradients (1 / world folded into the kernel)
-            self.rt.weights_changed()
-            return out
+        self.segments[-1][0].replay()   # Adam on the summed gradients (1 / world folded into the kernel)
         self.rt.weights_changed()
-        return self.loss, self.counts
+        return out
+
+
+class _StreamLanes:
+    """The two HIP streams of a replayed step with side graphs: `main` is torch's current stream, `side` the engine's second
+    stream.  run_segments drives it; the CPU tests pass an object with the same four methods that runs everything in line."""
+
+    def __init__(self, eng):
+        import torch
+        self.torch, self.eng = torch, eng
+        if eng._side_stream is None:
+            eng._side_stream = torch.cuda.Stream(device=eng.device)
+        self.side = eng._side_stream
+        self._free = []
+
+    def _event(self):
+        return self._free.pop() if self._free else self.torch.cuda.Event()
+
+    def fork(self):
+        """The side stream waits for everything queued on the main stream so far."""
+        ev = self._event()
+        ev.record(self.torch.cuda.current_stream(self.eng.device))
+        self.side.wait_event(ev)
+        self._free.append(ev)
+
+    def on_side(self):
+        """Context: launches inside go to the side stream."""
+        return self.torch.cuda.stream(self.side)
+
+    def mark_side(self):
+        """An event behind everything queued on the side stream so far."""
+        ev = self._event()
+        ev.record(self.side)
+        return ev
+
+    def wait_on_main(self, ev):
+        """The main stream waits for `ev` (mark_side); the event returns to the pool."""
+        if ev is not None:
+            self.torch.cuda.current_stream(self.eng.device).wait_event(ev)
+            self._free.append(ev)
 
 
 class _SegmentCuts:
@@ -684,17 +777,48 @@ class _SegmentCuts:
         return self.next == len(self.buckets)
 
 
-def run_segments(segments, arena, transport):
-    """The replay loop of a segmented data-parallel step: `segments` = [(launch, [(start, end), ...])]; after launching a
-    segment (a graph replay: stream-ordered, returns at once) each arena range it completed goes to the transport's
-    asynchronous sum-all-reduce, which waits for the compute stream's work queued so far and runs beside the next segment;
-    the compute stream joins the transport before whatever follows (Adam).  Device-agnostic: the CPU tests drive it over
-    gloo with callables that write gradients."""
-    for launch, ready in segments:
+def run_segments(segments, arena, transport, lanes=None):
+    """The replay loop of a segmented step: `segments` = [(launch, [(start, end), ...], side_launch | None)] (two-element
+    entries: no side graph).
+
+    launch() replays the segment's main graph M_k (stream-ordered, returns at once).  side_launch() replays its filter
+    gradients W_k: on the side stream (`lanes`: _StreamLanes) behind everything queued on the main stream so far, i.e.
+    beside M_(k+1); the main stream waits for W_(k-2) before M_k (W_(k-2)'s operands may be overwritten from M_k on: the
+    capture held them that long).  Each arena range a segment completed then goes to the transport's asynchronous
+    sum-all-reduce - issued from the side stream when the segment has a side graph (the range holds gradients W_k writes; the
+    side stream is behind M_k too) - which runs beside the next segment; at the end the main stream joins the side stream
+    and the transport before whatever follows (Adam).  Device-agnostic: the CPU tests drive it over gloo with callables that
+    write gradients and `lanes` = an in-line stand-in (or None: side launches run in line)."""
+    import contextlib
+    marks = []
+    for k, seg in enumerate(segments):
+        launch, ready = seg[0], seg[1]
+        side_launch = seg[2] if len(seg) > 2 else None
+        if lanes is not None and k >= 2:
+            lanes.wait_on_main(marks[k - 2])
+            marks[k - 2] = None
         launch()
-        for s, e in ready:
-            transport.allreduce_async(arena[s:e])
-    transport.join()
+        ctx = contextlib.nullcontext()
+        mark = None
+        if side_launch is not None:
+            if lanes is not None:
+                lanes.fork()
+                with lanes.on_side():
+                    side_launch()
+                mark = lanes.mark_side()
+                ctx = lanes.on_side()
+            else:
+                side_launch()
+        marks.append(mark)
+        if transport is not None and ready:
+            with ctx:
+                for s, e in ready:
+                    transport.allreduce_async(arena[s:e])
+    if lanes is not None:
+        for ev in marks:
+            lanes.wait_on_main(ev)
+    if transport is not None:
+        transport.join()
 
 
 class _Runtime:

@@ -190,10 +190,14 @@ def test_config3_deeplab_bf16_512_bs16(engine):
           (the north_star bar "1e-3, bit-exact argmax" is an fp32 statement; the numbers measured here are printed);
       (b) batch-slice invariance of inference, bit exact;
       (c) run-to-run determinism of the training step, bit exact (loss and the whole fp32 gradient arena);
-      (d) the backward pass IS the gradient of the bf16 forward: central differences of the loss along a direction signed
-          along the gradient against <g, d>.  bf16 storage rounds every activation to 8 bits and the weight planes to bf16,
-          so the steps are 16-64x the fp32 test's (relative 1.6e-2 ... 4e-3: far above one bf16 ulp of a weight, 3.9e-3, so
-          the planes really move; the loss change far above the rounding noise of the loss) and the bound is 10 %;
+      (d) a SIGN / SCALE SANITY CHECK of the whole backward pass, NOT a gradient check: central differences of the bf16 loss
+          along a direction signed with the gradient against <g, d>, over all parameters (asserted within [0.5, 1.1]: a
+          backward pass with the wrong sign, a lost factor of 2 or a dead parameter group moves it out) and per parameter
+          group (reported; a majority inside a wide band).  It cannot resolve more: the bf16 loss is a staircase in the
+          weights (a weight moves its bf16 plane only when it crosses a rounding boundary) and at random init a third of the
+          encoder gradient's signs are noise, so a group's quotient scatters by +-30 % and changes sign under changes of
+          ROUNDING alone (lab notebook 10.3).  What guards the bf16 backward pass is (e) below and the exact block
+          chains of tests/test_block_chains_gpu.py (every block incl. the Xception middle flow, cosine >= 0.99 vs fp64);
       (e) per-layer-group agreement of the bf16 gradient with the fp32 engine's at THIS workload on weights after 50 fp32 Adam
           steps, where the comparison is conditioned well enough to fail (VERDICT r2 next #1b); see the comment there."""
     from building_detection_amd import zoo, mixed_precision as MP
@@ -249,7 +253,7 @@ def test_config3_deeplab_bf16_512_bs16(engine):
     assert l1 == l2 and torch.equal(g1, g2), "the bf16 training step is not run-to-run deterministic"
     del g2
 
-    # (d) per parameter group, as for fp32 (same direction, same steps: the fp32 loss has so much curvature along a direction
+    # (d) sign / scale sanity check (see the docstring: not a gradient check).  Per parameter group, as for fp32 (same direction, same steps: the fp32 loss has so much curvature along a direction
     # signed with the gradient that only steps <= 3e-5 resolve it, and the bf16 forward answers such steps without bias -
     # 64 M weights cross their bf16 rounding boundaries in proportion; profiles/r03_diag_fd_512.txt).  What the ratio shows
     # in bf16 is how well <g, d> - d is signed with the bf16 gradient's own signs - predicts the real change of the loss:

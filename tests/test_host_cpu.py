@@ -329,7 +329,7 @@ def test_data_parallel_real_graph_sweep_gloo_world2():
         assert nb >= 4
 
 
-def _fallback_worker(rank, world, port, q):
+def _fallback_worker(rank, world, port, q, fail_rank):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import datetime
     import torch.distributed as dist
@@ -339,13 +339,16 @@ def _fallback_worker(rank, world, port, q):
 
     def no_rccl(lib, _l):
         raise _lib.SgError("sg_comm_unique_id: librccl.so could not be loaded (test)")
-    D._unique_id = no_rccl   # only rank 0 ever calls it
-    # comm="sg": every rank raises the SAME error, after the same broadcast ...
+
+    def fake_id(lib, _l):   # a rank whose RCCL is fine (never used: the readiness exchange fails first)
+        return bytes(_l.SG_COMM_ID_BYTES)
+    D._unique_id = no_rccl if rank == fail_rank else fake_id   # every rank probes its own library
+    # comm="sg": every rank raises the SAME error, after the same collective, and nobody has entered sg_comm_init ...
     try:
         D.make_transport("sg", 0)
         same_error = False
     except _lib.SgError as e:
-        same_error = "rank 0" in str(e) and "librccl" in str(e)
+        same_error = f"rank(s) {fail_rank}:" in str(e) and "librccl" in str(e)
     # ... so they are still in step: the next collective pairs up
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t)
@@ -358,16 +361,18 @@ def _fallback_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sg_comm_failure_on_rank0_keeps_the_ranks_in_step_gloo_world2():
-    """ADVICE r2 (dist.py:95): when rank 0 cannot draw the RCCL id (no librccl to dlopen - the case the sg_or_torch fallback
-    exists for) it used to raise BEFORE the id broadcast and go on to the flag all-reduce, while the other ranks waited inside
-    broadcast_object_list: mismatched collectives, a hang.  Now the failure travels through the broadcast as a sentinel,
-    every rank raises the same error and all of them meet in the next collective."""
+@pytest.mark.parametrize("fail_rank", [0, 1])
+def test_sg_comm_failure_on_one_rank_keeps_the_ranks_in_step_gloo_world2(fail_rank):
+    """ADVICE r2 (dist.py:95) / r3 (dist.py:177): when ONE rank cannot load RCCL (no librccl to dlopen - the case the
+    sg_or_torch fallback exists for), be it rank 0 (which draws the id) or any other, no rank may be left waiting in a
+    collective the failed rank never enters - neither the id exchange nor ncclCommInitRank.  Every rank probes its own
+    library, the outcome and rank 0's id travel in one all_gather_object, every rank raises the same error before anybody
+    calls sg_comm_init, and all of them meet in the next collective."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 33500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 33500 + os.getpid() % 2000 + 7 * fail_rank
+    procs = [ctx.Process(target=_fallback_worker, args=(r, 2, port, q, fail_rank)) for r in range(2)]
     for p in procs:
         p.start()
     try:
@@ -378,7 +383,7 @@ def test_sg_comm_failure_on_rank0_keeps_the_ranks_in_step_gloo_world2():
             if p.is_alive():
                 p.terminate()
     for rank, same_error, s, name, g in sorted(res):
-        assert same_error, f"rank {rank} did not see rank 0's sg_comm_unique_id failure"
+        assert same_error, f"rank {rank} did not see rank {fail_rank}'s sg_comm_unique_id failure"
         assert s == 3.0
         assert name == "torch" and g == [3.0] * 5
 
@@ -435,7 +440,94 @@ def _segments_worker(rank, world, port, q):
             if p.trainable:
                 want = sum(grad_of(p, r) for r in range(world))
                 ok = ok and torch.allclose(arena[p.offset:p.offset + p.size], want, atol=1e-6)
-    q.put((rank, bool(ok), len(segs), fired_eager == fired_seg, len(buckets)))
+    # --- the same step with side graphs (round 4: GraphedTrainStep's lanes): the filter gradients of a segment - here the
+    # gradients of its convolution kernels - are written by a separate side launch W_k, replayed behind M_k on the second
+    # stream.  An in-line stand-in for the two streams records the order of the calls.
+    from building_detection_amd import layers as L
+    log = []
+
+    class Lanes:
+        def __init__(self):
+            self.in_side = False
+        def fork(self):
+            log.append(("fork",))
+        def on_side(self):
+            lanes = self
+            class Ctx:
+                def __enter__(self_):
+                    lanes.in_side = True
+                def __exit__(self_, *a):
+                    lanes.in_side = False
+            return Ctx()
+        def mark_side(self):
+            log.append(("mark", len([1 for e in log if e[0] == "mark"])))
+            return log[-1]
+        def wait_on_main(self, ev):
+            if ev is not None:
+                log.append(("wait", ev[1]))
+
+    lanes = Lanes()
+
+    class Tp(TorchTransport):
+        def allreduce_async(self, t):
+            log.append(("allreduce", lanes.in_side))
+            super().allreduce_async(t)
+
+    def is_side(n):
+        return isinstance(n, (L._ConvNode, L._SepConvNode))
+
+    def main_launcher(k, nodes):
+        def launch():
+            log.append(("main", k))
+            for n in nodes:
+                for i, p in enumerate(n.params):
+                    if p.trainable and not (is_side(n) and i == 0):
+                        arena[p.offset:p.offset + p.size] = grad_of(p, rank)
+        return launch
+
+    def side_launcher(k, nodes):
+        side = [n for n in nodes if is_side(n)]
+        if not side:
+            return None
+        def launch():
+            log.append(("side", k, lanes.in_side))
+            for n in side:
+                p = n.params[0]
+                if p.trainable:
+                    arena[p.offset:p.offset + p.size] = grad_of(p, rank)
+        return launch
+
+    arena.zero_()
+    run_segments([(main_launcher(k, nodes), ready, side_launcher(k, nodes)) for k, (nodes, ready) in enumerate(segs)],
+                 arena, Tp(), lanes)
+    ok2 = True
+    for p in m.params:
+        if p.trainable:
+            want = sum(grad_of(p, r) for r in range(world))
+            ok2 = ok2 and torch.allclose(arena[p.offset:p.offset + p.size], want, atol=1e-6)
+    # order: W_k on the side lane right after M_k; M_k (k >= 2) behind a wait for W_(k-2) where that exists; a segment with a
+    # side graph hands its buckets over from the side lane; every mark is waited for exactly once
+    order_ok = True
+    has_side = [side_launcher(k, nodes) is not None for k, (nodes, _) in enumerate(segs)]
+    pos = {e: i for i, e in enumerate(log) if e[0] in ("main",)}
+    marks_of = {}
+    nmark = 0
+    for k, hs in enumerate(has_side):
+        if hs:
+            marks_of[k] = nmark
+            nmark += 1
+    for k in range(len(segs)):
+        i_main = log.index(("main", k))
+        if has_side[k]:
+            order_ok = order_ok and log[i_main + 1] == ("fork",) and log[i_main + 2] == ("side", k, True)
+        if k >= 2 and has_side[k - 2]:
+            order_ok = order_ok and ("wait", marks_of[k - 2]) in log[:i_main]
+    waits = [e[1] for e in log if e[0] == "wait"]
+    order_ok = order_ok and sorted(waits) == list(range(nmark))
+    ar_sides = [e[1] for e in log if e[0] == "allreduce"]
+    want_sides = [has_side[k] for k, (_, ready) in enumerate(segs) for _ in ready]
+    order_ok = order_ok and ar_sides == want_sides
+    q.put((rank, bool(ok and ok2 and order_ok), len(segs), fired_eager == fired_seg, len(buckets)))
     dist.destroy_process_group()
 
 

@@ -360,6 +360,17 @@ def test_maxpool_training_form_routes_by_the_recorded_cell(engine, k, stride, pa
     assert torch.equal(dx0, dx1)
     # every window's dy lands exactly once
     assert abs(float(dx1.double().sum()) - float(dy.double().sum())) <= 1e-3
+    # directly against the oracle: autograd of T.max_pool in fp64 on the same quantised input - ties in most
+    # windows, routed to the first maximum in scan order - without the all(-inf) corner, whose gradient the oracle drops
+    xq = (torch.round(rnd(g, 2, 15, 18, c) * 3) / 3)
+    xr = xq.double().requires_grad_()
+    yr = T.max_pool(xr, k, stride, padding)
+    dyq = rnd(g, *yr.shape)
+    yr.backward(dyq.double())
+    yq, geomq, idxq = engine.maxpool_fwd(xq.cuda(), k, stride, padding, want_idx=True)
+    assert torch.equal(yq.cpu().double(), yr.detach())
+    dxq = engine.maxpool_bwd_idx(dyq.cuda(), idxq, tuple(xq.shape), geomq)
+    close(dxq, xr.grad, rtol=1e-6, what="maxpool_bwd_idx vs oracle")
 
 
 def test_maxpool_odd_same(engine):
@@ -415,6 +426,11 @@ def test_conv_dgrad_adds_a_collected_gradient(engine, case, dtype):
     plain = engine.conv2d_dgrad(dy, wt, d)
     ref = engine.add_n([res, plain])
     got = engine.conv2d_dgrad(dy, wt, d, res=res)
+    # directly against the oracle: fp64 autograd of the forward convolution, plus res
+    xr = torch.zeros(*x_shape, dtype=torch.float64, requires_grad=True)
+    T.conv2d(xr, wt.cpu().double(), None, stride, dil, "same").backward(dy.float().cpu().double())
+    want = xr.grad + res.float().cpu().double()
+    close(got.float(), want, rtol=RTOL if dtype == torch.float32 else 2 ** -7, what="conv2d_dgrad_acc vs oracle")
     if dtype == torch.float32:
         assert torch.equal(got, ref)
         buf = res.clone()
@@ -438,6 +454,10 @@ def test_depthwise_dgrad_adds_a_collected_gradient(engine, pre_relu):
     ref = engine.add_n([res, engine.dwconv_dgrad(dy, wt, d, x=x, pre_relu=pre_relu)])
     got = engine.dwconv_dgrad(dy, wt, d, x=x, pre_relu=pre_relu, res=res)
     assert torch.equal(got, ref)
+    # directly against the oracle: fp64 autograd of depthwise(relu?(x)), plus res
+    xr = x.cpu().double().requires_grad_()
+    T.depthwise_conv2d(torch.relu(xr) if pre_relu else xr, wt.cpu().double(), 1, "same").backward(dy.cpu().double())
+    close(got, xr.grad + res.cpu().double(), what="dwconv2d_dgrad_acc vs oracle")
     buf = res.clone()
     engine.dwconv_dgrad(dy, wt, d, x=x, pre_relu=pre_relu, res=buf, out=buf)
     assert torch.equal(buf, ref)
@@ -474,6 +494,16 @@ def test_add2_bn_equals_batchnorm_then_add(engine, which, dtype):
                 refr = engine.add_n([torch.relu(norm(a, par[0])), norm(b, par[1])], relu=relu)
                 gotr = engine.add2_bn(a, b, par[0], par[1], relu=relu, infer=infer, eps=1e-3, relu_a=True)
                 assert torch.equal(gotr, refr), ("relu_a", infer, relu)
+            # directly against the oracle's arithmetic, fp64: f(x) = (x - mean) * invstd * gamma + beta with
+            # invstd given (training) or rsqrt(variance + eps) (inference)
+            def norm64(x, p):
+                mean, iv, gamma, beta = [t.cpu().double() for t in p]
+                inv = torch.rsqrt(iv + 1e-3) if infer else iv
+                return (x.float().cpu().double() - mean) * inv * gamma + beta
+            want = (norm64(ad, par[0]) if "a" in which else ad.float().cpu().double()) + \
+                   (norm64(bd, par[1]) if "b" in which else bd.float().cpu().double())
+            want = torch.relu(want) if relu else want
+            close(got.float(), want, rtol=RTOL if dtype == torch.float32 else 2 ** -7, what=f"add2_bn vs oracle {which} {infer} {relu}")
             if dtype == torch.float32:
                 assert torch.equal(got, ref), (which, infer, relu)
             else:
