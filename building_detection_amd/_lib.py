@@ -75,6 +75,8 @@ _SIGNATURES = {
     "sg_dwconv2d_fwd": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _i]),
     "sg_dwconv2d_dgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i]),
     "sg_dwconv2d_dgrad_acc": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp]),
+    "sg_dwconv2d_dgrad_bnsums_ws_bytes": (_sz, [_vp, _dp]),
+    "sg_dwconv2d_dgrad_bnsums": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp] + [_vp] * 5 + [_i, _vp, _vp, _vp, _sz]),
     "sg_dwconv2d_fwd_bn": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i]),
     "sg_dwconv2d_wgrad_bn": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "sg_dwconv2d_wgrad_ws_bytes": (_sz, [_vp, _dp]),
@@ -83,6 +85,7 @@ _SIGNATURES = {
     "sg_bn_ws_bytes": (_sz, [_vp, _i64, _i]),
     "sg_bn_train_fwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _i, _vp, _sz]),
     "sg_bn_train_bwd": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "sg_bn_train_bwd_apply": (_i, [_vp, _vp, _i, _i64, _i] + [_vp] * 9 + [_i]),
     "sg_bn_infer": (_i, [_vp, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _vp, _f, _i]),
     "sg_add2_bn": (_i, [_vp, _vp, _i, _i64, _i] + [_vp] * 11 + [_i, _i, _f, _i, _i]),
     "sg_act_fwd": (_i, [_vp, _vp, _i, _i, _i64, _vp, _vp]),

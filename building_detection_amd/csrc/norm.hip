@@ -420,6 +420,44 @@ int launch_bn_apply(hipStream_t st, bool vec, const T* x, const float* mean, con
 
 }  // namespace
 
+// dx of a training-mode BatchNormalization from its finished column sums (dbeta = sum g, dgamma = sum g * xhat): the apply
+// pass of sg_bn_train_bwd, also entered on its own by sg_bn_train_bwd_apply
+template <typename T>
+static void bn_bwd_apply_launch(sg_ctx* ctx, hipStream_t st, bool vec, int64_t rows, int C, const void* x, const void* y,
+                                const void* dy, const void* gamma, const void* beta, const void* save_mean,
+                                const void* save_invstd, void* dx, const void* dgamma, const void* dbeta, int relu) {
+    const bool wide = vec && sizeof(T) == 2 && C % 8 == 0;
+    const int V = wide ? 8 : (vec ? 4 : 1);
+    const unsigned blocks = ew_blocks(rows * (C / V));
+    const int mode = !relu ? 0 : (beta ? 2 : 1);
+    static const int cols_on = getenv("SG_BN_COLS") ? atoi(getenv("SG_BN_COLS")) : 1;
+    auto apply = [&](auto vt, auto mt) {
+      constexpr int V_ = decltype(vt)::value, M_ = decltype(mt)::value;
+      if constexpr (V_ > 1) {
+        int prow = 0;
+        dim3 cgrid;
+        if (cols_on && bn_cols_grid(ctx->num_cus, rows, C / V_, 1, prow, cgrid)) {
+          hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<V_, T, M_>), cgrid, dim3(256), 0, st, (const T*)x, (const T*)y,
+                             (const T*)dy, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
+                             (const float*)beta, (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, prow,
+                             make_fastdiv((uint32_t)(C / V_)));
+          return;
+        }
+      }
+      hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, T, M_>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
+                         (const float*)save_mean, (const float*)save_invstd, (const float*)gamma, (const float*)beta,
+                         (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, make_fastdiv((uint32_t)(C / V)));
+    };
+    auto apply_v = [&](auto vt) {
+      if (mode == 0) apply(vt, std::integral_constant<int, 0>{});
+      else if (mode == 1) apply(vt, std::integral_constant<int, 1>{});
+      else apply(vt, std::integral_constant<int, 2>{});
+    };
+    if (wide) apply_v(std::integral_constant<int, 8>{});
+    else if (vec) apply_v(std::integral_constant<int, 4>{});
+    else apply_v(std::integral_constant<int, 1>{});
+}
+
 extern "C" {
 
 size_t sg_bn_ws_bytes(const sg_ctx* ctx, int64_t rows, int C) {
@@ -487,38 +525,26 @@ int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
     };
     int rc = !relu ? reduce(BnBwdOp<T, 0>{}) : (beta ? reduce(BnBwdOp<T, 2>{}) : reduce(BnBwdOp<T, 1>{}));
     if (rc) return rc;
-    const bool wide = vec && sizeof(T) == 2 && C % 8 == 0;
-    const int V = wide ? 8 : (vec ? 4 : 1);
-    const unsigned blocks = ew_blocks(rows * (C / V));
-    const int mode = !relu ? 0 : (beta ? 2 : 1);
-    static const int cols_on = getenv("SG_BN_COLS") ? atoi(getenv("SG_BN_COLS")) : 1;
-    auto apply = [&](auto vt, auto mt) {
-      constexpr int V_ = decltype(vt)::value, M_ = decltype(mt)::value;
-      if constexpr (V_ > 1) {
-        int prow = 0;
-        dim3 cgrid;
-        if (cols_on && bn_cols_grid(ctx->num_cus, rows, C / V_, 1, prow, cgrid)) {
-          hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<V_, T, M_>), cgrid, dim3(256), 0, st, (const T*)x, (const T*)y,
-                             (const T*)dy, (const float*)save_mean, (const float*)save_invstd, (const float*)gamma,
-                             (const float*)beta, (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, prow,
-                             make_fastdiv((uint32_t)(C / V_)));
-          return;
-        }
-      }
-      hipLaunchKernelGGL((bn_bwd_apply_kernel<V_, T, M_>), dim3(blocks), dim3(256), 0, st, (const T*)x, (const T*)y, (const T*)dy,
-                         (const float*)save_mean, (const float*)save_invstd, (const float*)gamma, (const float*)beta,
-                         (const float*)dgamma, (const float*)dbeta, (T*)dx, rows, C, make_fastdiv((uint32_t)(C / V)));
-    };
-    auto apply_v = [&](auto vt) {
-      if (mode == 0) apply(vt, std::integral_constant<int, 0>{});
-      else if (mode == 1) apply(vt, std::integral_constant<int, 1>{});
-      else apply(vt, std::integral_constant<int, 2>{});
-    };
-    if (wide) apply_v(std::integral_constant<int, 8>{});
-    else if (vec) apply_v(std::integral_constant<int, 4>{});
-    else apply_v(std::integral_constant<int, 1>{});
+    bn_bwd_apply_launch<T>(ctx, st, vec, rows, C, x, y, dy, gamma, beta, save_mean, save_invstd, dx, dgamma, dbeta, relu);
     SG_LAUNCH_CHECK("bn_bwd_apply_kernel");
   });
+  return 0;
+}
+
+int sg_bn_train_bwd_apply(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* dy,
+                          const void* gamma, const void* beta, const void* save_mean, const void* save_invstd,
+                          const void* dgamma, const void* dbeta, void* dx, int relu) {
+  SG_CHECK_ARG(ctx && (dtype == SG_F32 || dtype == SG_BF16), "sg_bn_train_bwd_apply: bad ctx/dtype");
+  SG_CHECK_ARG(rows > 0 && C > 0 && x && dy && gamma && save_mean && save_invstd && dx && dgamma && dbeta,
+               "sg_bn_train_bwd_apply: bad argument");
+  SG_CHECK_ARG(!relu || beta, "sg_bn_train_bwd_apply: relu needs beta (the mask is recomputed from x)");
+  SG_CHECK_ARG(rows * C < (1ll << 31), "sg_bn_train_bwd_apply: tensor exceeds 2^31 elements");
+  const bool vec = (C % 4 == 0) && sg_aligned16(x) && sg_aligned16(dy) && sg_aligned16(dx);
+  SG_DTYPE_SWITCH(dtype, "sg_bn_train_bwd_apply", {
+    bn_bwd_apply_launch<T>(ctx, (hipStream_t)stream, vec, rows, C, x, nullptr, dy, gamma, beta, save_mean, save_invstd, dx, dgamma,
+                           dbeta, relu);
+  });
+  SG_LAUNCH_CHECK("bn_bwd_apply_kernel");
   return 0;
 }
 

@@ -27,10 +27,17 @@ struct seg_has_ctx<Op, V, std::void_t<decltype(std::declval<const Op&>().templat
 // `fuse`: the LAST workgroup of a (segment, column block) to finish - found with one agent-scope counter per column
 // block, cnt[seg * gridDim.x + blockIdx.x], zero before the launch and reset by that workgroup - also does the second
 // stage for its channels (same lanes, same order of additions as seg_finalize_kernel: bit-identical), so that the
-// few-microsecond finalize launch behind every reduction disappears.  The partial rows travel between workgroups (and
-// XCDs, whose L2s are not coherent) by release / acquire at agent scope: __threadfence() before the counter increment
-// writes this workgroup's partials back, __threadfence() after it invalidates the reader's caches.  With S == 1 there is
-// nothing to wait for and no counter.
+// few-microsecond finalize launch behind every reduction disappears.  With S == 1 (fuse = 1) there is nothing to wait
+// for and no counter.  For S > 1 the partial rows travel between workgroups (and XCDs, whose L2s are not coherent):
+//   fuse = 2 (rounds 2 / 3): plain stores, an agent-scope RELEASE fence in every workgroup before the counter increment,
+//     an acquire after it.  Correct, and a loss: the release is buffer_wbl2 - every one of ~1000 workgroups per launch
+//     writes back its XCD's whole L2, which holds the previous kernel's output = this kernel's input (step 79 -> 102 ms).
+//   fuse = 3 (round 4): the hand-off of MI355X_MICROARCH.md "Valid forms" without any cache-wide operation - every
+//     partial is stored WRITE-THROUGH (global_store sc1: __hip_atomic_store relaxed / agent), every storing wave drains
+//     its stores (s_waitcnt vmcnt(0)), workgroup barrier, ONE lane's agent-scope atomic add whose returned value tells the
+//     last arriver, workgroup barrier, and the last arriver reads every partial with sc1 loads (bypassing its L1; an
+//     agent-scope acquire - buffer_inv sc1, this CU's L1 only, ~2 us in that one workgroup - is kept in front of them
+//     because several of these 256-thread workgroups share a CU, which is outside the table of measured sc1-only forms).
 template <class Op, int V>
 __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int64_t rows, const int C, const int S,
                                                          float* __restrict__ part, unsigned* __restrict__ cnt, const int fuse) {
@@ -71,6 +78,7 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
 #pragma unroll
     for (int v = 0; v < V; ++v) mine[o * V + v] = acc[o][v];
   __syncthreads();
+  const bool wt = fuse == 3 && S > 1;   // write-through partials (uniform)
   if (ty == 0 && c < C) {
 #pragma unroll
     for (int o = 0; o < NO; ++o)
@@ -78,26 +86,38 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
       for (int v = 0; v < V; ++v) {
         float s = 0.f;
         for (int y = 0; y < TY; ++y) s += red[((size_t)(y * TX + tx)) * (NO * V) + o * V + v];
-        if (c + v < C) part[(((int64_t)seg * S + z) * NO + o) * C + c + v] = s;
+        if (c + v < C) {
+          float* dst = part + (((int64_t)seg * S + z) * NO + o) * C + c + v;
+          if (wt) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else *dst = s;
+        }
       }
   }
   if (!fuse) return;
   if (S > 1) {
     __shared__ int s_last;
-    // release only: round 2 used __threadfence() (acquire AND release at agent scope: write back and invalidate this XCD's
-    // L2 in every workgroup; step 86 -> 117 ms).  Round 3 re-measured with the scoped pair: still 79 -> 102 ms (fp32), 34 ->
-    // 52 ms (bf16) - the L2 writeback of ~1000 workgroups per launch is the cost, whatever it finds to write.
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    __syncthreads();
+    if (wt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores ...
+    } else {
+      // release only: round 2 used __threadfence() (acquire AND release at agent scope: write back and invalidate this XCD's
+      // L2 in every workgroup; step 86 -> 117 ms).  Round 3 re-measured with the scoped pair: still 79 -> 102 ms (fp32), 34 ->
+      // 52 ms (bf16) - the L2 writeback of ~1000 workgroups per launch is the cost, whatever it finds to write.
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
+    __syncthreads();                                      // ... before the one lane that signals for all of them
     if (tx == 0 && ty == 0) {
       unsigned* slot = cnt + (size_t)seg * gridDim.x + blockIdx.x;
-      const unsigned prev = atomicAdd(slot, 1u);
+      const unsigned prev = __hip_atomic_fetch_add(slot, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       s_last = (prev == (unsigned)S - 1u) ? 1 : 0;
-      if (s_last) atomicExch(slot, 0u);  // every other workgroup of this column block has already arrived
+      if (s_last) __hip_atomic_store(slot, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every other workgroup of this column block has already arrived
     }
     __syncthreads();
     if (!s_last) return;
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other workgroups' partial rows, not stale cache lines
+    if (wt) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the invalidate completes asynchronously)
+      __syncthreads();
+    }
   } else {
     __syncthreads();  // S == 1: the partial row just written by this workgroup's ty == 0 threads
   }
@@ -119,7 +139,8 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
       for (int z2 = zl; z2 < S; z2 += 4) {
         const float* q = rd + (((int64_t)seg * S + z2) * NO) * C + cc;
 #pragma unroll
-        for (int o = 0; o < NO; ++o) sum[o] += (double)q[(int64_t)o * C];
+        for (int o = 0; o < NO; ++o)
+          sum[o] += (double)(wt ? __hip_atomic_load(q + (int64_t)o * C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : q[(int64_t)o * C]);
       }
     }
     __syncthreads();  // the first stage's (or the previous 64 channels') use of the LDS buffer is over
@@ -241,8 +262,9 @@ template <class Op>
 static inline int seg_reduce_launch(const Op& op, const SegPlan& pl, int nseg, int64_t rows, int C, float* part,
                                     hipStream_t st, const char* name) {
   if (nseg <= 0 || rows <= 0 || C <= 0) return 0;
-  // SG_SEG_FUSED: 0 = always the separate finalize launch, 1 (default) = fused when S == 1 (no communication between
-  // workgroups), 2 = fused for every S through the arrival counters.  Mode 2 is correct (full GPU suite) but a LOSS on this
+  // SG_SEG_FUSED: 0 = always the separate finalize launch, 1 = fused when S == 1 (no communication between workgroups),
+  // 2 = fused for every S through the arrival counters with release / acquire fences, 3 = the same with write-through
+  // partials and no cache-wide fence (seg_reduce_kernel's comment).  Mode 2 is correct (full GPU suite) but a LOSS on this
   // part: the agent-scope release / acquire pair makes every workgroup write back and invalidate its XCD's whole L2 -
   // which holds the previous kernel's output, i.e. this kernel's input - and the DeepLabv3+ step went 86 -> 117 ms (fp32),
   // 39 -> 63 ms (bf16).  Kept for re-measurement only.
@@ -250,7 +272,7 @@ static inline int seg_reduce_launch(const Op& op, const SegPlan& pl, int nseg, i
   unsigned* cnt = nullptr;
   int fuse = 0;
   if (fused_mode >= 1 && pl.S == 1) fuse = 1;
-  else if (fused_mode >= 2 && (cnt = seg_counters((int64_t)nseg * pl.gx)) != nullptr) fuse = 1;
+  else if (fused_mode >= 2 && (cnt = seg_counters((int64_t)nseg * pl.gx)) != nullptr) fuse = fused_mode >= 3 ? 3 : 2;
   const size_t lds1 = (size_t)256 * Op::NOUT * pl.V * sizeof(float), lds2 = (size_t)4 * 64 * Op::NOUT * sizeof(double);
   const size_t lds = lds1 > lds2 ? lds1 : lds2;
   dim3 grid((unsigned)pl.gx, (unsigned)nseg, (unsigned)pl.S), block((unsigned)pl.TX, (unsigned)pl.TY);

@@ -153,6 +153,18 @@ struct DwRunParams {
   const float* __restrict__ bn_beta;
   const float* __restrict__ bn_mean;
   const float* __restrict__ bn_invstd;
+  // SUMS = true kernels (dgrad only): `out` is the gradient of a training-mode BatchNormalization's OUTPUT, whose raw input is
+  // bs_x.  Besides writing it the kernel sums, per channel, what that layer's backward needs - sum g and sum g * xhat with
+  // g = out [masked by the layer's fused ReLU, recomputed from bs_x as sg_bn_train_bwd does] and xhat = (bs_x - mean) * invstd
+  // - into bs_part[blockIdx.y][2][C]: the reduction pass of BatchNormalization's backward (two tensor reads) disappears for
+  // one more read here (sg_dwconv2d_dgrad_bnsums)
+  const T* __restrict__ bs_x = nullptr;
+  const float* __restrict__ bs_mean = nullptr;
+  const float* __restrict__ bs_invstd = nullptr;
+  const float* __restrict__ bs_gamma = nullptr;
+  const float* __restrict__ bs_beta = nullptr;
+  float* bs_part = nullptr;
+  int bs_ld = 0, bs_relu = 0;
   int lc;                          // lanes per run along the channels (set by launch_dw_run)
   int runs_per_row;                // W / 4
   int64_t nruns;                   // N * H * runs_per_row
@@ -164,13 +176,27 @@ struct DwRunParams {
 // RELU / MASK are compile-time and the window is branch-free (rows and columns outside the image load a valid address
 // and are zeroed by a select): with the run-time `if (relu_in)` and the `continue` on the row test every load sat in its
 // own basic block behind an s_waitcnt vmcnt(0) - 18..36 serialised memory latencies per run.
-template <int RR, typename T, bool RELU, bool MASK, bool BN = false>
+template <int RR, typename T, bool RELU, bool MASK, bool BN = false, bool SUMS = false>
 __global__ __launch_bounds__(256, 3) void dw_s1_run_kernel(const DwRunParams<T> p) {
   // p.lc lanes (a power of two <= 64) cover the channel chunks of one run; with few channels (C = 64: 16 chunks)
   // a wave takes several runs instead of idling three quarters of its lanes
   const int lc = p.lc, rpb = 256 / lc;
-  const int c = (blockIdx.x * lc + (threadIdx.x & (lc - 1))) * 4;
-  if (c >= p.C) return;
+  const int c_raw = (blockIdx.x * lc + (threadIdx.x & (lc - 1))) * 4;
+  if constexpr (!SUMS) {
+    if (c_raw >= p.C) return;
+  }
+  // SUMS: every thread reaches the workgroup's reduction below; a lane past the last channel chunk walks chunk 0 and drops
+  // its results
+  const bool live = c_raw < p.C;
+  const int c = live ? c_raw : 0;
+  f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 bmv, biv, bgm, bbt;
+  if constexpr (SUMS) {
+    bmv = *reinterpret_cast<const f32x4*>(p.bs_mean + c);
+    biv = *reinterpret_cast<const f32x4*>(p.bs_invstd + c);
+    bgm = *reinterpret_cast<const f32x4*>(p.bs_gamma + c);
+    bbt = *reinterpret_cast<const f32x4*>(p.bs_beta + c);
+  }
   f32x4 wt[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (p.flip ? 8 - t : t) * p.C + c);
@@ -228,10 +254,14 @@ __global__ __launch_bounds__(256, 3) void dw_s1_run_kernel(const DwRunParams<T> 
 #pragma unroll
     for (int rr = 0; rr < RR; ++rr) {
       const int64_t opix = ((int64_t)(n * p.H + oh0 + rr) * p.W + ow0);
-      f32x4 m[4];
+      f32x4 m[4], bx[4];
       if constexpr (MASK) {
 #pragma unroll
         for (int k = 0; k < 4; ++k) m[k] = ld4<T>(p.mask + (opix + k) * p.mask_ld + c);
+      }
+      if constexpr (SUMS) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bx[k] = ld4<T>(p.bs_x + (opix + k) * p.bs_ld + c);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -245,8 +275,40 @@ __global__ __launch_bounds__(256, 3) void dw_s1_run_kernel(const DwRunParams<T> 
 #pragma unroll
           for (int e = 0; e < 4; ++e) o[e] += rv[e];
         }
+        if constexpr (SUMS) {
+          // BnBwdOp's accumulation (norm.hip) on the complete gradient: the fused ReLU's mask from the forward's own fmaf
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float xh = (bx[k][e] - bmv[e]) * biv[e];
+            const bool on = !p.bs_relu || fmaf(xh, bgm[e], bbt[e]) > 0.f;
+            const float g = on ? o[e] : 0.f;
+            s1[e] += g;
+            s2[e] = fmaf(g, xh, s2[e]);
+          }
+        }
+        if (SUMS && !live) continue;
         st4<T>(p.out + (opix + k) * p.out_ld + c, o);
       }
+    }
+  }
+  if constexpr (SUMS) {
+    // the run slots of this workgroup (threads that share a channel chunk) are added in slot order; the partial row of this
+    // workgroup goes to bs_part[blockIdx.y], the rows are added in fp64 by the finalize launch (fixed order: deterministic)
+    __shared__ float red[256 * 8];
+    float* mine = red + threadIdx.x * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mine[e] = s1[e]; mine[4 + e] = s2[e]; }
+    __syncthreads();
+    if ((int)threadIdx.x < lc && live) {
+      f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < rpb; ++j) {
+        const float* q = red + (j * lc + threadIdx.x) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t1[e] += q[e]; t2[e] += q[4 + e]; }
+      }
+      float* row = p.bs_part + (int64_t)blockIdx.y * 2 * p.C + c;
+      *reinterpret_cast<f32x4*>(row) = t1;
+      *reinterpret_cast<f32x4*>(row + p.C) = t2;
     }
   }
 }
@@ -551,8 +613,10 @@ inline int dw_rows_per_run(int H, int64_t pixels, bool wgrad) {
   return (want >= 4 && H % 4 == 0) ? 4 : ((want >= 2 && H % 2 == 0) ? 2 : 1);
 }
 
+constexpr int DW_SUMS_MAX_ROWS = 1024;
+
 template <typename T>
-int launch_dw_run(const DwRunParams<T>& p_in, hipStream_t st) {
+int launch_dw_run(const DwRunParams<T>& p_in, hipStream_t st, int* sums_rows = nullptr) {
   DwRunParams<T> p = p_in;
   const int rr = dw_rows_per_run(p.H, (int64_t)p.N * p.H * p.W, false);
   p.nruns = (int64_t)p.N * (p.H / rr) * p.runs_per_row;
@@ -565,7 +629,26 @@ int launch_dw_run(const DwRunParams<T>& p_in, hipStream_t st) {
   const int64_t cap = sg_cdiv(16384, gx);
   if (gy > cap) gy = cap;
   if (gy < 1) gy = 1;
+  if (p.bs_part && gy > DW_SUMS_MAX_ROWS) gy = DW_SUMS_MAX_ROWS;   // partial rows the finalize launch adds per channel
   const dim3 grid(gx, (unsigned)gy);
+  if (p.bs_part) {
+    if (p.relu_in || p.bn_gamma) {
+      sg_set_error("dw_s1_run: BatchNormalization sums together with relu_in / a fused BatchNormalization");
+      return SG_EINVAL;
+    }
+#define SG_DW_RUN_SUMS(RR_)                                                                                             \
+  do {                                                                                                                  \
+    if (p.mask) hipLaunchKernelGGL((dw_s1_run_kernel<RR_, T, false, true, false, true>), grid, dim3(256), 0, st, p);    \
+    else hipLaunchKernelGGL((dw_s1_run_kernel<RR_, T, false, false, false, true>), grid, dim3(256), 0, st, p);          \
+  } while (0)
+    if (rr == 4) SG_DW_RUN_SUMS(4);
+    else if (rr == 2) SG_DW_RUN_SUMS(2);
+    else SG_DW_RUN_SUMS(1);
+#undef SG_DW_RUN_SUMS
+    SG_LAUNCH_CHECK("dw_s1_run_kernel<SUMS>");
+    if (sums_rows) *sums_rows = (int)gy;   // the number of partial rows written
+    return 0;
+  }
 #define SG_DW_RUN(RR_)                                                                                                  \
   do {                                                                                                                  \
     if (p.mask) hipLaunchKernelGGL((dw_s1_run_kernel<RR_, T, false, true>), grid, dim3(256), 0, st, p);                 \
@@ -1056,6 +1139,68 @@ int sg_dwconv2d_dgrad_acc(sg_ctx* ctx, void* stream, int dtype, const sg_conv_de
                           const void* x_for_mask, void* dx, int pre_relu, const void* res) {
   SG_CHECK_ARG(res != nullptr, "sg_dwconv2d_dgrad_acc: null res");
   return dwconv2d_dgrad_impl(ctx, stream, dtype, d, dy, w, x_for_mask, dx, pre_relu, res);
+}
+
+// second stage of the BatchNormalization sums written by dw_s1_run_kernel<SUMS>: seg_finalize_kernel adds the partial rows in
+// fp64 (fixed order) and hands the two totals of a channel to this op
+struct BnSumsFinalOp {
+  static constexpr int NOUT = 2;
+  float* dgamma;
+  float* dbeta;
+  __device__ __forceinline__ void finalize(int, int c, const double (&s)[2]) const {
+    dbeta[c] = (float)s[0];
+    dgamma[c] = (float)s[1];
+  }
+};
+
+size_t sg_dwconv2d_dgrad_bnsums_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
+  if (!ctx || !d) return 0;
+  return (size_t)DW_SUMS_MAX_ROWS * 2 * (size_t)d->Cin * sizeof(float) + 256;
+}
+
+int sg_dwconv2d_dgrad_bnsums(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                             const void* x_for_mask, void* dx, int pre_relu, const void* res, const void* bn_x,
+                             const void* bn_mean, const void* bn_invstd, const void* bn_gamma, const void* bn_beta, int bn_relu,
+                             void* dgamma, void* dbeta, void* ws, size_t ws_bytes) {
+  int rc = dw_check(ctx, dtype, d, "sg_dwconv2d_dgrad_bnsums");
+  if (rc) return rc;
+  SG_CHECK_ARG(dy && w && dx && bn_x && bn_mean && bn_invstd && bn_gamma && bn_beta && dgamma && dbeta,
+               "sg_dwconv2d_dgrad_bnsums: null tensor");
+  SG_CHECK_ARG(!pre_relu || x_for_mask, "sg_dwconv2d_dgrad_bnsums: pre_relu needs the forward input");
+  const int xl = d->x_ld ? d->x_ld : d->Cin, yl = d->y_ld ? d->y_ld : d->Cout;
+  if (!((d->Cin % 4 == 0) && (xl % 4 == 0) && (yl % 4 == 0) && sg_aligned16(dy) && sg_aligned16(w) && sg_aligned16(dx) &&
+        sg_aligned16(bn_x) && sg_aligned16(bn_mean) && sg_aligned16(bn_invstd) && sg_aligned16(bn_gamma) && sg_aligned16(bn_beta) &&
+        (!res || sg_aligned16(res)) && (!pre_relu || sg_aligned16(x_for_mask)) && dw_run_ok(d))) {
+    sg_set_error("sg_dwconv2d_dgrad_bnsums: only the stride-1 3x3 run kernels (W %% 4 == 0, C %% 4 == 0, 16-byte aligned); "
+                 "use sg_dwconv2d_dgrad and sg_bn_train_bwd instead");
+    return SG_EUNSUPPORTED;
+  }
+  if (!ws || ws_bytes < sg_dwconv2d_dgrad_bnsums_ws_bytes(ctx, d) - 256) {
+    sg_set_error("sg_dwconv2d_dgrad_bnsums: workspace %zu < %zu", ws_bytes, sg_dwconv2d_dgrad_bnsums_ws_bytes(ctx, d) - 256);
+    return SG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  SG_DTYPE_SWITCH(dtype, "sg_dwconv2d_dgrad_bnsums", {
+    DwRunParams<T> r;
+    r.in = (const T*)dy; r.w = (const float*)w; r.mask = pre_relu ? (const T*)x_for_mask : nullptr; r.out = (T*)dx;
+    r.res = (const T*)res;
+    r.bn_gamma = r.bn_beta = r.bn_mean = r.bn_invstd = nullptr;
+    r.N = d->N; r.H = d->H; r.W = d->W; r.C = d->Cin; r.in_ld = yl; r.out_ld = xl; r.mask_ld = xl;
+    r.relu_in = 0; r.flip = 1; r.runs_per_row = d->W / 4; r.nruns = (int64_t)d->N * d->H * r.runs_per_row;
+    r.fd_rpr = make_fastdiv((uint32_t)r.runs_per_row); r.fd_h = make_fastdiv((uint32_t)d->H);
+    r.bs_x = (const T*)bn_x; r.bs_ld = d->Cin;   /* the BatchNormalization's input is a dense tensor */ r.bs_mean = (const float*)bn_mean; r.bs_invstd = (const float*)bn_invstd;
+    r.bs_gamma = (const float*)bn_gamma; r.bs_beta = (const float*)bn_beta; r.bs_relu = bn_relu ? 1 : 0;
+    r.bs_part = (float*)ws;
+    int rows = 0;
+    rc = launch_dw_run(r, st, &rows);
+    if (rc) return rc;
+    BnSumsFinalOp op;
+    op.dgamma = (float*)dgamma; op.dbeta = (float*)dbeta;
+    hipLaunchKernelGGL((seg_finalize_kernel<BnSumsFinalOp>), dim3((unsigned)sg_cdiv(d->Cin, 64), 1u), dim3(256), 0, st, op, 1, d->Cin,
+                       rows, (const float*)ws);
+  });
+  SG_LAUNCH_CHECK("sg_dwconv2d_dgrad_bnsums");
+  return 0;
 }
 
 size_t sg_dwconv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {

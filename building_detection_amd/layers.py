@@ -171,6 +171,7 @@ class _SepConvNode(Node):
         self.filters, self.stride, self.activation = filters, stride, activation
         self.pre_relu = False  # set by the fusion pass when the producer is a single-consumer ReLU
         self.bn_src = None     # set by the fusion pass: the training-mode BatchNormalization(+ReLU) applied in the gather
+        self.bnsum_src = None  # set by the fusion pass: the BatchNormalization whose backward sums this layer's dgrad produces
 
     def build(self, x):
         _, h, w, c = x.shape
@@ -223,7 +224,18 @@ class _SepConvNode(Node):
             while isinstance(root.node, _ActNode) and root.node.fused_away and len(root.consumers) == 1:
                 root = root.node.inputs[0]
             res = rt.take_pending(root) if e.dwconv_dgrad_acc_ok(ddw) else None
-            dx = e.dwconv_dgrad(dt, rt.param(self.dw), ddw, x=x, pre_relu=self.pre_relu, res=res)
+            # this layer's input is the output of a training-mode BatchNormalization with no other consumer: dx IS that layer's
+            # output gradient, and the kernel sums what its backward needs (dgamma, dbeta) while it writes dx - the
+            # BatchNormalization then only applies (Model._fuse: bnsum_src / sums_from; sg_dwconv2d_dgrad_bnsums)
+            src = self.bnsum_src
+            sv = rt._saved.get(id(src)) if src is not None else None
+            if sv is not None and "mean" in sv and e.dwconv_dgrad_acc_ok(ddw) and dt.dtype == x.dtype:
+                dx = e.dwconv_dgrad_bnsums(dt, rt.param(self.dw), ddw, rt.values[id(src.inputs[0])], sv["mean"], sv["invstd"],
+                                           rt.param(src.gamma), rt.param(src.beta), src.relu, rt.grad(src.gamma),
+                                           rt.grad(src.beta), x=x, pre_relu=self.pre_relu, res=res)
+                sv["sums_done"] = True
+            else:
+                dx = e.dwconv_dgrad(dt, rt.param(self.dw), ddw, x=x, pre_relu=self.pre_relu, res=res)
         bn = rt.saved(self).get("bn")
         # (the deferred BatchNormalization's mean / invstd belong to that node's saved state, which the sweep drops right after
         # its backward: the side stream's reader keeps them alive as it keeps x and dt)
@@ -376,6 +388,7 @@ class _BNNode(Node):
         self.relu = False  # fused by the optimisation pass when followed by a single-consumer ReLU
         self.defer_to = None  # fused by the optimisation pass: the SeparableConv2D that applies this layer in its gather
         self.defer_add = None  # fused by the optimisation pass: the two-operand Add that applies this layer while it sums
+        self.sums_from = None  # fused by the optimisation pass: the SeparableConv2D whose depthwise dgrad sums this layer's dgamma / dbeta
 
     def build(self, x):
         c = x.shape[-1]
@@ -413,6 +426,9 @@ class _BNNode(Node):
     def backward(self, rt, xs, y, dy):
         (x,) = xs
         s = rt.saved(self)
+        if s.get("sums_done"):   # dgamma / dbeta came out of the consumer's depthwise dgrad (sums_from): only the apply pass is left
+            return [rt.eng.bn_train_bwd_apply(x, dy, rt.param(self.gamma), rt.param(self.beta), s["mean"], s["invstd"],
+                                              rt.grad(self.gamma), rt.grad(self.beta), relu=self.relu)]
         # beta lets the kernels recompute the fused ReLU's mask from x instead of reading y (two tensor passes less)
         dx, _, _ = rt.eng.bn_train_bwd(x, y, dy, rt.param(self.gamma), s["mean"], s["invstd"], relu=self.relu,
                                        dgamma=rt.grad(self.gamma), dbeta=rt.grad(self.beta), beta=rt.param(self.beta))

@@ -437,6 +437,18 @@ class Engine:
                                          int(pre_relu)), "sg_dwconv2d_dgrad")
         return dx
 
+    def dwconv_dgrad_bnsums(self, dy, w, d: ConvDesc, bn_x, bn_mean, bn_invstd, bn_gamma, bn_beta, bn_relu, dgamma, dbeta,
+                            x=None, pre_relu=False, res=None, out=None):
+        """dwconv_dgrad whose result is the output gradient of a training-mode BatchNormalization (raw input bn_x): also writes
+        that layer's dgamma / dbeta (sg_dwconv2d_dgrad_bnsums); follow with bn_train_bwd_apply.  Geometry: dwconv_dgrad_acc_ok."""
+        dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin, dtype=dy.dtype)
+        wsp, wsn = self.ws(self.lib.sg_dwconv2d_dgrad_bnsums_ws_bytes(self.h, C.byref(d)))
+        check(self.lib.sg_dwconv2d_dgrad_bnsums(self.h, self.stream, _dt(dy), C.byref(d), _ptr(dy), _ptr(w), _ptr(x), _ptr(dx),
+                                                int(pre_relu), _ptr(res), _ptr(bn_x), _ptr(bn_mean), _ptr(bn_invstd), _ptr(bn_gamma),
+                                                _ptr(bn_beta), int(bn_relu), _ptr(dgamma), _ptr(dbeta), wsp, wsn),
+              "sg_dwconv2d_dgrad_bnsums")
+        return dx
+
     @staticmethod
     def dwconv_dgrad_acc_ok(d: ConvDesc) -> bool:
         return (d.KH == 3 and d.KW == 3 and d.stride == 1 and d.dilation == 1 and d.pad_t == 1 and d.pad_l == 1 and d.Ho == d.H
@@ -486,6 +498,15 @@ class Engine:
             check(self.lib.sg_bn_apply(self.h, self.stream, _dt(x), rows, c, _ptr(x), _ptr(gamma), _ptr(beta), _ptr(mean),
                                        _ptr(invstd), _ptr(y), int(relu)), "sg_bn_apply")
         return y, mean, invstd
+
+    def bn_train_bwd_apply(self, x, dy, gamma, beta, mean, invstd, dgamma, dbeta, relu=False, out=None):
+        """dx of a training-mode BatchNormalization whose column sums dgamma / dbeta are already there (dwconv_dgrad_bnsums)."""
+        c = x.shape[-1]
+        dx = out if out is not None else torch.empty_like(x)
+        check(self.lib.sg_bn_train_bwd_apply(self.h, self.stream, _dt(x), x.numel() // c, c, _ptr(x), _ptr(dy), _ptr(gamma),
+                                             _ptr(beta), _ptr(mean), _ptr(invstd), _ptr(dgamma), _ptr(dbeta), _ptr(dx), int(relu)),
+              "sg_bn_train_bwd_apply")
+        return dx
 
     def bn_train_bwd(self, x, y, dy, gamma, mean, invstd, relu=False, out=None, dgamma=None, dbeta=None, beta=None):
         c = x.shape[-1]

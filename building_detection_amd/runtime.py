@@ -171,6 +171,26 @@ class Model:
                     for i, p_ in enumerate(n.bn_src):
                         if p_ is not None:
                             p_.defer_add, n.bn_src[i] = None, None
+        # BatchNormalization (+ fused ReLU) -> SeparableConv2D (stride 1), the layer's only consumer: the input gradient that the
+        # depthwise convolution's dgrad writes IS the BatchNormalization's output gradient.  That kernel also sums, per channel,
+        # dbeta = sum g and dgamma = sum g * xhat in its epilogue (sg_dwconv2d_dgrad_bnsums: one more read of the layer's raw
+        # input), so the reduction pass of the BatchNormalization's backward - two tensor reads of its five passes - is not run
+        # (round 4; conv_bn_relu / the Xception blocks, train_model/DeepLabv3plus.py:323-416,424-429; SG_BN_SUMS=0 switches it
+        # off).  Decided again at run time (geometry, training mode: _SepConvNode.backward).
+        if os.environ.get("SG_BN_SUMS", "1") == "1":
+            for n in self.nodes:
+                if not isinstance(n, L._BNNode) or len(n.output.shape) != 4 or id(n.output) in outs or n.defer_add is not None:
+                    continue
+                t = n.output
+                while (len(t.consumers) == 1 and isinstance(t.consumers[0], L._ActNode) and t.consumers[0].fused_away
+                       and id(t.consumers[0].output) not in outs):
+                    t = t.consumers[0].output
+                if len(t.consumers) != 1 or not isinstance(t.consumers[0], L._SepConvNode) or id(t) in outs:
+                    continue
+                sc = t.consumers[0]
+                _, h, w, c = t.shape
+                if sc.stride == 1 and sc.bnsum_src is None and w % 4 == 0 and c % 4 == 0:
+                    n.sums_from, sc.bnsum_src = sc, n
         if os.environ.get("SG_BN_DEFER", "0") == "1":
             for n in self.nodes:
                 if not isinstance(n, L._BNNode) or len(n.output.shape) != 4 or id(n.output) in outs:

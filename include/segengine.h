@@ -165,6 +165,19 @@ int sg_dwconv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* 
  * W % 4 == 0, C % 4 == 0, 16-byte aligned tensors, else SG_EUNSUPPORTED. */
 int sg_dwconv2d_dgrad_acc(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy,
                           const void* w, const void* x_for_mask, void* dx, int pre_relu, const void* res);
+/* sg_dwconv2d_dgrad[_acc] of a SeparableConv2D whose input is the output of a training-mode BatchNormalization(+ReLU) with no
+ * other consumer (conv_bn_relu / the Xception blocks, train_model/DeepLabv3plus.py:323-416,424-429): dx is then that layer's
+ * output gradient, and the kernel also produces what the layer's backward sums over the pixels - dbeta = sum g, dgamma = sum
+ * g * xhat, g = dx [masked by the fused ReLU, recomputed from bn_x as sg_bn_train_bwd does], xhat = (bn_x - mean) * invstd,
+ * bn_x the layer's RAW input (dense [N,H,W,C]) - in its epilogue: one more tensor read here instead of the two-read
+ * reduction pass of sg_bn_train_bwd.  Follow with sg_bn_train_bwd_apply.  res (may be NULL) as in sg_dwconv2d_dgrad_acc.
+ * Partial sums are added in a fixed order (deterministic); they differ from sg_bn_train_bwd's in rounding only.  Stride-1 3x3,
+ * W % 4 == 0, C % 4 == 0, 16-byte aligned tensors, else SG_EUNSUPPORTED.  Workspace: sg_dwconv2d_dgrad_bnsums_ws_bytes. */
+size_t sg_dwconv2d_dgrad_bnsums_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d);
+int sg_dwconv2d_dgrad_bnsums(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                             const void* x_for_mask, void* dx, int pre_relu, const void* res, const void* bn_x,
+                             const void* bn_mean, const void* bn_invstd, const void* bn_gamma, const void* bn_beta, int bn_relu,
+                             void* dgamma, void* dbeta, void* ws, size_t ws_bytes);
 /* The depthwise convolution of a SeparableConv2D whose input is BatchNormalization(+ReLU) of a tensor x_raw, in training
  * mode, with that normalisation applied as the window is loaded - fmaf((x - mean) * invstd, gamma, beta), then max(., 0) if
  * relu - so that the normalised tensor is never written (the pattern BatchNormalization -> Activation('relu') ->
@@ -246,6 +259,11 @@ int sg_bn_train_bwd(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, c
                     const void* y, const void* dy, const void* gamma, const void* beta, const void* save_mean,
                     const void* save_invstd, void* dx, void* dgamma, void* dbeta, int relu, void* ws,
                     size_t ws_bytes);
+/* The second pass of sg_bn_train_bwd on its own: dx from FINISHED column sums dgamma / dbeta (sg_dwconv2d_dgrad_bnsums wrote
+ * them).  relu: the fused ReLU's mask is recomputed from x (beta required). */
+int sg_bn_train_bwd_apply(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x, const void* dy,
+                          const void* gamma, const void* beta, const void* save_mean, const void* save_invstd,
+                          const void* dgamma, const void* dbeta, void* dx, int relu);
 int sg_bn_infer(sg_ctx* ctx, void* stream, int dtype, int64_t rows, int C, const void* x,
                 const void* gamma, const void* beta, const void* moving_mean, const void* moving_var,
                 void* y, float eps, int relu);

@@ -552,6 +552,36 @@ def test_segmented_data_parallel_step_gloo_world2():
         assert nb >= 4 and 2 <= nseg <= nb + 1
 
 
+def test_depthwise_dgrad_takes_over_the_batchnorm_backward_sums(monkeypatch):
+    """Model._fuse (round 4): a 4-D BatchNormalization whose output reaches exactly one stride-1 SeparableConv2D (through the
+    ReLU absorbed into either of them) has its backward column sums produced by that layer's depthwise dgrad
+    (sg_dwconv2d_dgrad_bnsums; layers._BNNode.sums_from / _SepConvNode.bnsum_src).  Graph-level check on the CPU: the 39
+    such layers of DeepLabv3+ (32 in the middle flow, 7 in the entry / exit flows), none in the U-Nets (their BatchNormalization
+    layers feed ordinary convolutions), SG_BN_SUMS=0 switches the pass off, and a layer the residual add applies (defer_add)
+    is never taken."""
+    sys.path.insert(0, ROOT)
+    from building_detection_amd import zoo, layers as L
+
+    def count(m):
+        pairs = [(n, n.sums_from) for n in m.nodes if isinstance(n, L._BNNode) and n.sums_from is not None]
+        for bn, sc in pairs:
+            assert isinstance(sc, L._SepConvNode) and sc.bnsum_src is bn and sc.stride == 1 and bn.defer_add is None
+            t = bn.output
+            while t.consumers and isinstance(t.consumers[0], L._ActNode):
+                assert len(t.consumers) == 1 and t.consumers[0].fused_away
+                t = t.consumers[0].output
+            assert t.consumers == [sc]
+        assert sum(1 for n in m.nodes if isinstance(n, L._SepConvNode) and n.bnsum_src is not None) == len(pairs)
+        return len(pairs)
+
+    monkeypatch.delenv("SG_BN_SUMS", raising=False)
+    assert count(zoo.BUILDERS["v3plus"]((128, 128, 3), 2, aspp_pool=8)) == 39
+    assert count(zoo.BUILDERS["bam"]((128, 128, 3), 2, aspp_pool=8)) == 39
+    assert count(zoo.BUILDERS["res34"]((64, 64, 3))) == 0
+    monkeypatch.setenv("SG_BN_SUMS", "0")
+    assert count(zoo.BUILDERS["v3plus"]((128, 128, 3), 2, aspp_pool=8)) == 0
+
+
 def test_residual_adds_take_over_their_batchnorm_layers(monkeypatch):
     """Model._fuse: a BatchNormalization (no fused ReLU) whose only consumer is a two-operand Add is applied BY that Add
     (sg_add2_bn; layers._AddNode.bn_src / _BNNode.defer_add).  Graph-level check on the CPU: the Xception blocks of DeepLabv3+

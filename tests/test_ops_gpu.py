@@ -465,6 +465,57 @@ def test_depthwise_dgrad_adds_a_collected_gradient(engine, pre_relu):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("bn_relu,pre_relu,with_res,shape", [(True, False, False, (2, 12, 16, 728)), (False, True, True, (3, 8, 8, 128)),
+                                                          (False, False, False, (2, 6, 20, 36)), (True, False, True, (1, 64, 32, 64))])
+def test_depthwise_dgrad_sums_the_batchnorm_backward(engine, bn_relu, pre_relu, with_res, shape, dtype):
+    """sg_dwconv2d_dgrad_bnsums + sg_bn_train_bwd_apply (round 4): z = BatchNormalization[+ReLU](y) in training mode, t =
+    depthwise3x3([relu](z)).  Given dt, the depthwise dgrad writes dz (+ res) AND the BatchNormalization's dgamma / dbeta; the
+    apply pass then gives dy.  Against fp64 autograd of the oracle's layers (tfops.batch_norm / depthwise_conv2d) and against the
+    unfused engine path (sg_dwconv2d_dgrad -> sg_bn_train_bwd: same values up to the order of the column sums).  Shapes: the
+    middle flow's, a pre-activation ReLU in the gather with a collected gradient riding along, a ragged channel count
+    (36: idle lanes in the channel dimension), a large map whose partial rows hit the cap of the finalize launch."""
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(c + h)
+    y = rnd(g, n, h, w, c) * 2
+    gamma, beta = torch.rand(c, generator=g) + 0.5, rnd(g, c) * 0.3
+    wt = rnd(g, 3, 3, c, 1)
+    dt = rnd(g, n, h, w, c)
+    res = rnd(g, n, h, w, c) if with_res else None
+    if dtype == torch.bfloat16:   # the engine sees bf16 tensors: the reference starts from the same rounded values
+        y, dt = y.bfloat16().float(), dt.bfloat16().float()
+        res = res.bfloat16().float() if with_res else None
+    # oracle, fp64
+    yr, gr, br = y.double().requires_grad_(), gamma.double().requires_grad_(), beta.double().requires_grad_()
+    z, _, _ = T.batch_norm(yr, gr, br, torch.zeros(c, dtype=torch.float64), torch.ones(c, dtype=torch.float64), True)
+    z = torch.relu(z) if bn_relu else z
+    z.retain_grad()
+    t = T.depthwise_conv2d(torch.relu(z) if pre_relu else z, wt.double(), 1, "same")
+    extra = (z * res.double()).sum() if with_res else 0.0      # a second consumer of z whose gradient is `res`
+    (((t * dt.double()).sum()) + extra).backward()
+    # engine
+    yd, dtd = y.cuda().to(dtype), dt.cuda().to(dtype)
+    gd, bd, wd = gamma.cuda(), beta.cuda(), wt.cuda()
+    zd, mean, invstd = engine.bn_train_fwd(yd, gd, bd, torch.zeros(c).cuda(), torch.ones(c).cuda(), relu=bn_relu)
+    d = engine.conv_desc((n, h, w, c), c, 3, 3, 1, 1, "same")
+    assert engine.dwconv_dgrad_acc_ok(d)
+    resd = res.cuda().to(dtype) if with_res else None
+    dgam, dbet = torch.full((c,), 7.0).cuda(), torch.full((c,), 7.0).cuda()
+    dz = engine.dwconv_dgrad_bnsums(dtd, wd, d, yd, mean, invstd, gd, bd, bn_relu, dgam, dbet, x=zd, pre_relu=pre_relu, res=resd)
+    dy = engine.bn_train_bwd_apply(yd, dz, gd, bd, mean, invstd, dgam, dbet, relu=bn_relu)
+    # the unfused engine path
+    dz0 = engine.dwconv_dgrad(dtd, wd, d, x=zd, pre_relu=pre_relu, res=resd)
+    dy0, dg0, db0 = engine.bn_train_bwd(yd, zd, dz0, gd, mean, invstd, relu=bn_relu, beta=bd)
+    assert torch.equal(dz, dz0), "the gradient tensor itself must not change"
+    tol = RTOL if dtype == torch.float32 else 2 ** -7
+    close(dgam, dg0, rtol=1e-5, what="dgamma vs the unfused path")
+    close(dbet, db0, rtol=1e-5, what="dbeta vs the unfused path")
+    close(dy.float(), dy0.float(), rtol=1e-5 if dtype == torch.float32 else 2 ** -7, what="dy vs the unfused path")
+    close(dgam, gr.grad, rtol=tol, what="dgamma vs oracle")
+    close(dbet, br.grad, rtol=tol, what="dbeta vs oracle")
+    close(dy.float(), yr.grad, rtol=tol, what="dy vs oracle")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("which", ["a", "b", "ab"])
 def test_add2_bn_equals_batchnorm_then_add(engine, which, dtype):
     """sg_add2_bn: the residual add applies the BatchNormalization of its operand(s) while it sums.  fp32 storage: the bits of
