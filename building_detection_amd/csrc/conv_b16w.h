@@ -1,0 +1,434 @@
+// bf16-storage convolution on 256 x 256 tiles, both operands by LDS-DMA: included by conv_igemm.hip after conv_pw.h (same
+// namespace, IgemmParams).  Round 4; VERDICT r2 / r3 "the bf16 long-K kernel".
+//
+// conv_b16_kernel gives a workgroup a 128 x 128 tile: for the ASPP forward (M = 16384 pixels, N = 256, K = 9 x 2048) that is
+// 2.4 GB from L2 to the CUs per launch (A twice, the weight planes 128 times), 0.75 LDS fragment reads per MFMA (64 x 32 per
+// wave), every operand byte through registers (buffer load -> ds_write), two barriers per 64-deep slab: 0.28 of the bf16 matrix
+// peak on the dilated set.  Here ONE workgroup per CU owns a 256 x 256 tile:
+//   * 8 waves as 2 (rows) x 4 (columns), 128 x 64 per wave: 6 fragment reads for 8 MFMAs per 16-deep k-step (0.75 -> 0.75 / 2:
+//     half the LDS read traffic per product), half the L2 -> LDS bytes per product;
+//   * BOTH operands go from L2 to LDS by LDS-DMA (buffer_load_dwordx4 ... lds: no registers, no ds_write).  The im2col gather
+//     of A rides in the per-lane SOURCE address - a lane owns four (row, 16-byte chunk) pieces per stage, its four byte
+//     offsets change only when the K walk enters another filter tap, and a row whose tap falls into the padding carries an
+//     out-of-range offset: the DMA writes zeros.  The XOR swizzle of the LDS image is applied to the source chunk (the DMA
+//     writes lane-linearly), as in pw_wide_kernel;
+//   * two 64 KB LDS stages of 64 channels, ONE barrier per stage: the DMA of stage s + 1 flies while stage s is multiplied;
+//   * M x N = 16384 x 256 is only 64 such tiles: the K walk is then CUT into S shares (split-K; grid = tiles x S), every share
+//     writes its fp32 partial tile, and b16w_reduce_kernel adds the S partials in order, applies bias / ReLU, rounds to bf16
+//     and - where the consumer is a training-mode BatchNormalization - produces the per-128-row-tile statistics the other
+//     kernels' epilogues produce.  S depends on ONE image's geometry only (b16w_plan), never on the batch: the rounding order
+//     of a pixel does not depend on its batch neighbours (bit-exact batch-slice invariance, tests/test_fullsize_gpu.py).
+// Padding-tap elimination, channel-block K order and the plane layout [K / 64][Npad][64] are conv_b16_kernel's (KS = 4).
+// Requires: stride-1 gather (div == 1, no parity-class rows), every 64-deep stage inside one tap (C % 64 == 0).
+#pragma once
+
+constexpr int BW_M = 256, BW_N = 256, BW_KD = 64, BW_RB = 128;
+constexpr int BW_STAGE = (BW_M + BW_N) * BW_RB;           // 65536
+constexpr int BW_TP = BW_N * 2 + 16;                      // LDS pitch of the staged bf16 output tile
+constexpr int BW_LDS = (2 * BW_STAGE > BW_M * BW_TP ? 2 * BW_STAGE : BW_M * BW_TP) + 256;
+
+__device__ __forceinline__ int bw_swz(int row) { return (row >> 1) & 7; }   // B16L<4>::swz
+
+__global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, const int S, float* __restrict__ part) {
+  constexpr unsigned OOB = 0x80000000u;
+  constexpr int WGN = 4, WM = 128, WN = 64, TM = 4, TN = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages] x { A [256][128 B], B [256][128 B] } | staged tile; tapinfo
+  int* tapinfo = reinterpret_cast<int*>(smem + BW_LDS - 256);    // [64]
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const uint32_t ntn = (p.Nout + BW_N - 1) / BW_N;
+  const uint32_t ntiles = gridDim.x / (uint32_t)S;
+  // split-major order: the tiles of one K share are neighbours (they read the same slice of the weight planes)
+  const uint32_t o = xcd_remap(blockIdx.x, gridDim.x);
+  const uint32_t split = o / ntiles, bid = o - split * ntiles;
+  const uint32_t tile_m = bid / ntn, tile_n = bid - tile_m * ntn;
+  const int m0 = tile_m * BW_M, n0 = tile_n * BW_N;
+
+  const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_w =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.wq), 0, (int)p.w_bytes, 0x00020000);
+
+  // ---- this lane's four DMA pieces per operand and stage: piece g = wave + 8 i covers rows 8 g .. 8 g + 7 (1 KB of LDS) --------
+  int a_lin[4], a_hw[4], a_chunk[4];
+  unsigned b_voff[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = (wave + 8 * i) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ bw_swz(row);          // the chunk of the row that lands in this lane's LDS slot
+    a_chunk[i] = 16 * c;
+    const int m = m0 + row;
+    if (m < p.M) {
+      uint32_t n, oh, ow;
+      row_to_pixel(p, (uint32_t)m, n, oh, ow);
+      const int ohs = (int)oh * p.a_mul + p.off_h, ows = (int)ow * p.a_mul + p.off_w;
+      a_lin[i] = (int)n * p.H * p.W + ohs * p.W + ows;
+      a_hw[i] = (ohs << 16) | (ows & 0xffff);
+    } else {
+      a_lin[i] = 0;
+      a_hw[i] = (int)0x80008000u;
+    }
+    const int nrow = n0 + row;
+    b_voff[i] = nrow < p.Npad ? (unsigned)((nrow * BW_KD + 8 * c) * 2) : OOB;
+  }
+  auto tap_valid = [&](int i, int dh, int dw, int& pix) -> bool {
+    const int ohs = a_hw[i] >> 16, ows = (int)(short)(a_hw[i] & 0xffff);
+    const int ih = ohs + dh, iw = ows + dw;
+    pix = a_lin[i] + dh * p.W + dw;
+    return ((unsigned)ih < (unsigned)p.H) && ((unsigned)iw < (unsigned)p.W);
+  };
+
+  // ---- the K walk of this tile: active taps (padding-tap elimination), channel-block order, this share's range -----------------
+  const int ntaps = p.K / p.C;
+  const int spt = p.C / BW_KD;          // stages per tap
+  int nact = ntaps;
+  bool use_map = false;
+  if (p.skip_taps && ntaps > 1) {   // uniform
+    nact = 0;
+    for (int tap = 0; tap < ntaps; ++tap) {
+      uint32_t kh, kw;
+      fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+      const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int pix;
+        any = any || tap_valid(i, dh, dw, pix);
+      }
+      if (__syncthreads_or(any ? 1 : 0)) {
+        if (t == 0) tapinfo[nact] = tap;
+        ++nact;
+      }
+    }
+    __syncthreads();
+    nact = __builtin_amdgcn_readfirstlane(nact);
+    use_map = true;
+  }
+  const int nstage = nact * spt;
+  int it_run = spt;
+  if (p.cb > 0) {
+    it_run = (p.cb * 32) / BW_KD;
+    if (it_run < 1) it_run = 1;
+    if (spt % it_run != 0) it_run = spt;
+  }
+  const int per = it_run * nact;
+  const int st_begin = (int)(((int64_t)split * nstage) / S), st_end = (int)(((int64_t)(split + 1) * nstage) / S);
+  const int nk = st_end - st_begin;
+  auto k0_of = [&](int L) -> int {   // stage index of the tile's walk -> first reduction index (uniform arithmetic)
+    if (ntaps <= 1) return L * BW_KD;
+    const int cbk = L / per, rem = L - cbk * per;
+    const int ti = rem / it_run, ci = rem - ti * it_run;
+    const int tap = use_map ? __builtin_amdgcn_readfirstlane(tapinfo[ti]) : ti;
+    return tap * p.C + (cbk * it_run + ci) * BW_KD;
+  };
+
+  int cur_tap = -1;
+  unsigned a_voff[4] = {OOB, OOB, OOB, OOB};
+  auto issue = [&](int L, int stage) {
+    const int k0 = k0_of(L);
+    const int tap = (int)fd_div((uint32_t)k0, p.fd_c);
+    if (tap != cur_tap) {   // uniform
+      cur_tap = tap;
+      uint32_t kh, kw;
+      fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+      const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        int pix;
+        const bool ok = tap_valid(i, dh, dw, pix);
+        a_voff[i] = ok ? (unsigned)pix * (unsigned)p.x_ld * 2u + (unsigned)a_chunk[i] : OOB;
+      }
+    }
+    const int soff_a = (k0 - tap * p.C) * 2;
+    const int soff_b = (k0 / BW_KD) * p.Npad * BW_KD * 2;
+    char* sa = smem + stage * BW_STAGE;
+    char* sb = sa + BW_M * BW_RB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pw_lds_dma16(rsrc_x, sa + (wave + 8 * i) * 1024, a_voff[i], soff_a);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) pw_lds_dma16(rsrc_w, sb + (wave + 8 * i) * 1024, b_voff[i], soff_b);
+  };
+
+  // ---- MFMA side -----------------------------------------------------------------------------------------------------------
+  const int wr = wave / WGN, wc = wave % WGN;
+  const int wm = wr * WM, wn = wc * WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int sw = bw_swz(lr);   // wm, wn and the 32-row sub-tile offsets are multiples of 32: the swizzle depends on lr only
+  const int a_lane = (wm + lr) * BW_RB, b_lane = BW_M * BW_RB + (wn + lr) * BW_RB;
+  auto compute = [&](int stage) {
+    const char* sbuf = smem + stage * BW_STAGE;
+    bf16x8_t af[2][TM], bf[2][TN];
+    auto frags = [&](int ks, bf16x8_t (&a)[TM], bf16x8_t (&b)[TN]) {
+      const int ko = ((2 * ks + lh) ^ sw) << 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sbuf + a_lane + 32 * i * BW_RB + ko);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sbuf + b_lane + 32 * j * BW_RB + ko);
+    };
+    frags(0, af[0], bf[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks + 1 < 4) frags(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);   // one k-step of look-ahead
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (nk > 0) {
+    issue(st_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    for (int s = 0; s < nk; ++s) {
+      const int cur = s & 1;
+      if (s + 1 < nk) {   // stage cur ^ 1 was last read before the previous barrier
+        issue(st_begin + s + 1, cur ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+
+  // ---- split-K share: the fp32 partial tile, branch-free buffer stores (a lane outside the tensor carries an out-of-range
+  // offset) ---------------------------------------------------------------------------------------------------------------------
+  if (S > 1) {
+    const int64_t slab = (int64_t)p.M * p.Nout;
+    float* dst = part + (int64_t)split * slab + (int64_t)m0 * p.Nout;
+    const int rows_here = (p.M - m0) < BW_M ? (p.M - m0) : BW_M;
+    const __amdgpu_buffer_rsrc_t rsrc_o = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)((uint32_t)rows_here * (uint32_t)p.Nout * 4u), 0x00020000);
+    const unsigned row0 = (unsigned)(wm + 4 * lh);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn + 32 * j + lr;
+      const unsigned cterm = col < p.Nout ? (unsigned)col * 4u : OOB;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const unsigned row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+          unsigned voff = cterm + row * (unsigned)p.Nout * 4u;
+          voff = row < (unsigned)rows_here ? voff : OOB;
+          const float v = acc[i][j][r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rsrc_o, (int)voff, 0, 0);
+        }
+    }
+    return;
+  }
+
+  // ---- whole-K tile: bias / ReLU, rounding to bf16; the tile leaves through LDS as 16-byte row chunks ------------------------
+  const bool has_bias = (p.flags & SG_EPI_BIAS) != 0;
+  const bool do_relu = (p.flags & SG_EPI_RELU) != 0;
+  bf16_t* __restrict__ py = reinterpret_cast<bf16_t*>(p.y);
+  const bool wide = (p.y_ld % 8 == 0) && (p.Nout % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
+  if (wide) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int cl = wn + 32 * j + lr;
+      const int col = n0 + cl;
+      const float bv = (has_bias && col < p.Nout) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int rl = wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          float v = acc[i][j][r] + bv;
+          if (do_relu) v = fmaxf(v, 0.f);
+          *reinterpret_cast<unsigned short*>(smem + rl * BW_TP + cl * 2) = f32_to_bf16_bits(v);
+        }
+    }
+    __syncthreads();
+    constexpr int CPT = BW_N / 8;
+    for (int idx = t; idx < BW_M * CPT; idx += 512) {
+      const int rl = idx / CPT, c = idx - rl * CPT;
+      const int row = m0 + rl, col = n0 + 8 * c;
+      if (row < p.M && col < p.Nout)
+        *reinterpret_cast<u32x4_t*>(py + (int64_t)row * p.y_ld + col) = *reinterpret_cast<const u32x4_t*>(smem + rl * BW_TP + c * 16);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn + 32 * j + lr;
+      const bool cv = col < p.Nout;
+      const float bv = (has_bias && cv) ? p.bias[col] : 0.f;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (cv && row < p.M) {
+            float v = acc[i][j][r] + bv;
+            if (do_relu) v = fmaxf(v, 0.f);
+            st1<bf16_t>(py + (int64_t)row * p.y_ld + col, v);
+          }
+        }
+    }
+  }
+
+  // ---- BatchNormalization statistics per 128-row tile (the layout of the 128-row kernels: stats[tile128][2][Nout]); a wave row
+  // IS one 128-row tile, so a column's sum over the tile is one wave's ---------------------------------------------------------
+  if (p.stats) {
+    float* tmean = reinterpret_cast<float*>(smem);   // [2][BW_N]
+    const int t128 = 2 * (int)tile_m + wr;
+    const int r128 = m0 + wm;
+    const int nvalid = (p.M - r128) < 128 ? (p.M - r128) : 128;
+    __syncthreads();   // every wave is done with the staged tile
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cl = wn + 32 * j + lr;
+        const int col = n0 + cl;
+        const float bv = (has_bias && col < p.Nout) ? p.bias[col] : 0.f;
+        const float mu = pass ? tmean[wr * BW_N + cl] : 0.f;
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = r128 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float dlt = acc[i][j][r] + bv - mu;
+            if (row < p.M) sacc += pass ? dlt * dlt : dlt;
+          }
+        sacc += __shfl_xor(sacc, 32, 64);   // lanes l and l + 32 hold the same column
+        if (lh == 0) {
+          if (pass == 0) tmean[wr * BW_N + cl] = nvalid > 0 ? sacc / (float)nvalid : 0.f;
+          if (col < p.Nout && nvalid > 0) p.stats[((int64_t)t128 * 2 + pass) * p.Nout + col] = sacc;
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Second stage of a split-K launch: y[m][n] = round_bf16(act(sum_s part[s][m][n] + bias[n])), the S partials added in order
+// (deterministic); one workgroup per (128 rows, 64 columns): a thread holds 8 rows x 4 columns, so the per-128-row-tile
+// BatchNormalization statistics (sum, then centred sum of squares around the tile mean - the conv epilogues' two passes) come
+// from registers.
+__global__ __launch_bounds__(256) void b16w_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
+                                                          bf16_t* __restrict__ y, float* __restrict__ stats, int M, int N, int y_ld,
+                                                          int S, int relu) {
+  __shared__ float red[16][64];
+  __shared__ float tmean[64];
+  const int t = threadIdx.x;
+  const int cq = t & 15, rq = t >> 4;
+  const int m0 = blockIdx.x * 128, col = blockIdx.y * 64 + 4 * cq;
+  const bool cv = col < N;   // N % 4 == 0
+  const int64_t slab = (int64_t)M * N;
+  f32x4 v[8];
+  f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+  if (bias && cv) bv = *reinterpret_cast<const f32x4*>(bias + col);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {
+    const int row = m0 + rq + 16 * k;
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (cv && row < M) {
+      const float* q = part + (int64_t)row * N + col;
+      a = *reinterpret_cast<const f32x4*>(q);
+      for (int s = 1; s < S; ++s) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(q + (int64_t)s * slab);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[e] += b[e];
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) a[e] += bv[e];
+      f32x4 o = a;
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
+      }
+      st4<bf16_t>(y + (int64_t)row * y_ld + col, o);
+    }
+    v[k] = a;   // (statistics are taken before an activation never requested together with them; rows past M hold zeros)
+  }
+  if (!stats) return;
+  const int nvalid = (M - m0) < 128 ? (M - m0) : 128;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    f32x4 sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int row = m0 + rq + 16 * k;
+      if (row < M) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float dlt = v[k][e] - (pass ? tmean[4 * cq + e] : 0.f);
+          sacc[e] += pass ? dlt * dlt : dlt;
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) red[rq][4 * cq + e] = sacc[e];
+    __syncthreads();
+    if (t < 64) {
+      float tot = 0.f;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tot += red[q][t];
+      const int c = blockIdx.y * 64 + t;
+      if (pass == 0) tmean[t] = tot / (float)nvalid;
+      if (c < N) stats[((int64_t)blockIdx.x * 2 + pass) * N + c] = tot;
+    }
+    __syncthreads();
+  }
+}
+
+// Which launches take the 256-wide kernel, and in how many K shares - from ONE image's geometry, the layer's channels and
+// the filter only (see the header).  A launch must bring >= 16 workgroups per image (256 at the benchmark's batch of 16);
+// fewer tiles are made up by split-K (<= 4 shares of >= 2048 reduction steps each).  SG_B16_WIDE=0 switches the kernel off.
+inline int b16w_plan(const IgemmParams& p) {
+  static const int on = getenv("SG_B16_WIDE") ? atoi(getenv("SG_B16_WIDE")) : 1;
+  if (!on) return 0;
+  if (p.div != 1 || p.perm2 || p.res || p.C % BW_KD != 0 || p.K < 1024) return 0;
+  if ((p.x_ld % 8) != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0 || p.x_bytes == 0) return 0;
+  if (p.Nout % 4 != 0) return 0;
+  const int64_t ntn = sg_cdiv(p.Nout, BW_N);
+  if ((double)p.Nout / (double)(ntn * BW_N) < 0.75) return 0;
+  const int64_t img_px = (int64_t)p.OH * p.OW;
+  if (img_px < BW_M || img_px % BW_M != 0) return 0;   // whole tiles per image
+  const int64_t img_wgs = ntn * (img_px / BW_M);
+  if (img_wgs >= 16) return 1;
+  int S = (int)(16 / img_wgs);
+  if (S > 4) S = 4;
+  while (S > 1 && p.K / S < 2048) --S;
+  return (S > 1 && img_wgs * S >= 16) ? S : 0;
+}
+
+inline size_t b16w_scratch_bytes(int S, int64_t M, int N) { return S > 1 ? (size_t)S * (size_t)M * (size_t)N * sizeof(float) : 0; }
+
+inline int launch_b16w(const IgemmParams& p, int S, float* scratch, hipStream_t st) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    int rc = set_dyn_lds(conv_b16w_kernel, (size_t)BW_LDS);
+    if (rc) return rc;
+    attr_done = true;
+  }
+  const int64_t tiles = sg_cdiv(p.M, BW_M) * sg_cdiv(p.Nout, BW_N);
+  if (tiles <= 0 || tiles * S > 0x7fffffff || (S > 1 && !scratch)) {
+    sg_set_error("conv_b16w: bad launch (%lld tiles, %d shares, scratch %p)", (long long)tiles, S, (void*)scratch);
+    return SG_EINVAL;
+  }
+  if ((((int64_t)p.M - 1) * p.y_ld + p.Nout) * 2 >= (1ll << 31) || (S > 1 && (int64_t)BW_M * p.Nout * 4 >= (1ll << 31))) {
+    sg_set_error("conv_b16w: an operand of %lld rows does not fit one 2 GiB buffer descriptor", (long long)p.M);
+    return SG_EINVAL;
+  }
+  hipLaunchKernelGGL(conv_b16w_kernel, dim3((unsigned)(tiles * S)), dim3(512), (size_t)BW_LDS, st, p, S, scratch);
+  SG_LAUNCH_CHECK("conv_b16w_kernel");
+  if (S > 1) {
+    dim3 grid((unsigned)sg_cdiv(p.M, 128), (unsigned)sg_cdiv(p.Nout, 64));
+    hipLaunchKernelGGL(b16w_reduce_kernel, grid, dim3(256), 0, st, (const float*)scratch,
+                       (p.flags & SG_EPI_BIAS) ? p.bias : nullptr, reinterpret_cast<bf16_t*>(p.y), p.stats, p.M, p.Nout, p.y_ld, S,
+                       (p.flags & SG_EPI_RELU) ? 1 : 0);
+    SG_LAUNCH_CHECK("b16w_reduce_kernel");
+  }
+  return 0;
+}

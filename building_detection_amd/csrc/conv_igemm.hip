@@ -73,6 +73,9 @@ struct IgemmParams {
   // dgrad: a gradient already collected for the same tensor (y's layout, may be y itself), added in the epilogue
   // (sg_conv2d_dgrad_acc; conv_x6_kernel / conv_b16_kernel only)
   const float* res;
+  // host side only: bytes of workspace that start at the weight planes (the planes, then scratch of a split-K launch:
+  // conv_b16w.h); SIZE_MAX = prepared planes, whose arena slot sg_conv2d_planes_job sized for both
+  size_t ws_room;
 };
 
 __device__ __forceinline__ int spt_of(const IgemmParams& p) { return p.C / BK; }  // slabs per tap (UT)
@@ -1099,6 +1102,7 @@ thread_local bool g_sub_batch = false;
 #include "conv_b16.h"
 #include "conv_x6wp.h"
 #include "conv_pw.h"
+#include "conv_b16w.h"
 
 template <int NPL, typename TA>
 int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
@@ -1230,7 +1234,23 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
   }
   if constexpr (NPL == 1 && !std::is_same<TA, float>::value) {
     static const bool deep = !(getenv("SG_B16_DEEP") && atoi(getenv("SG_B16_DEEP")) == 0);  // A/B switch
-    if (deep) return dispatch_b16(p, num_cus, st);
+    if (deep) {
+      // long reductions with 192+ output columns: 256 x 256 tiles, both operands by LDS-DMA, split-K where the tiles are few
+      // (conv_b16w.h); its scratch lies behind the planes
+      const int S = p.kd == BW_KD ? b16w_plan(p) : 0;
+      if (S > 0) {
+        const size_t planes_end = ((size_t)p.w_bytes + 255) & ~(size_t)255;
+        const size_t need = planes_end + b16w_scratch_bytes(S, p.M, p.Nout);
+        if (S > 1 && p.ws_room != SIZE_MAX && p.ws_room < need) {
+          sg_set_error("conv_b16w: workspace %zu < %zu (weight planes + %d split-K partial slabs)", p.ws_room, need, S);
+          return SG_EWORKSPACE;
+        }
+        IgemmParams q = p;
+        plan_common(q, true, 128, true, 2);
+        return launch_b16w(q, S, S > 1 ? reinterpret_cast<float*>((char*)ws + planes_end) : nullptr, st);
+      }
+      return dispatch_b16(p, num_cus, st);
+    }
   }
   return dispatch_x6<NPL, TA>(p, num_cus, st);
 }
@@ -1717,6 +1737,7 @@ void fill_fwd_params(IgemmParams& p, const sg_conv_desc* d, const void* x, const
   p.stats = nullptr;
   p.perm2 = 0;
   p.res = nullptr;
+  p.ws_room = 0;
 }
 
 void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, const void* wt, const void* bias, void* dx,
@@ -1742,6 +1763,7 @@ void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, co
   p.stats = nullptr;
   p.perm2 = 0;
   p.res = nullptr;
+  p.ws_room = 0;
 }
 
 // any-shape fallback for bf16 storage: the native fp32-MFMA kernel with widening loads (TA) and a rounding store (TY).
@@ -1823,9 +1845,28 @@ int sg_set_conv_x6(int on) {
   return prev;
 }
 
+// scratch of a split-K launch of the 256-wide bf16 kernel for this geometry (0: none), behind the weight planes
+static size_t b16w_ws_extra(const sg_conv_desc* d, bool dgrad) {
+  if (check_desc(d, "b16w_ws_extra")) return 0;
+  if (dgrad && d->stride != 1) return 0;
+  static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+  IgemmParams p;
+  if (!dgrad) fill_fwd_params(p, d, dummy, dummy, nullptr, nullptr, 0, 2);
+  else fill_dgrad_params(p, d, dummy, dummy, nullptr, nullptr, 0, 2);
+  p.x = (const float*)(uintptr_t)16;
+  p.res = nullptr;
+  if (p.C % BK != 0 && p.K != p.C) {
+    const int Ckp = x6_vpad_c(p.C);
+    p.K = (p.K / p.C) * Ckp;
+    p.C = Ckp;
+  }
+  const int S = b16w_plan(p);
+  return S > 1 ? b16w_scratch_bytes(S, p.M, p.Nout) + 256 : 0;
+}
+
 size_t sg_conv2d_fwd_ws_bytes(const sg_conv_desc* d) {
   if (!d) return 0;
-  return x6_ws_bytes(d->KH * d->KW, d->Cin, d->Cout) + 256;
+  return x6_ws_bytes(d->KH * d->KW, d->Cin, d->Cout) + 256 + b16w_ws_extra(d, false);
 }
 
 int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
@@ -1925,6 +1966,7 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
       p.stats = (float*)stats;
       *tiles_out = (int)sg_cdiv(p.M, BM);
     }
+    p.ws_room = prepared ? SIZE_MAX : ws_bytes;
     if (b16) return run_x6<1, bf16_t>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
     if (x6_mode() == 2) return run_x6<1, float>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
     return run_x6<3, float>(p, (const float*)w, false, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
@@ -2016,6 +2058,14 @@ int sg_conv2d_planes_job(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, in
   out->Npad = x6_npad(p.Nout);
   out->nblocks = (out->Kpad / 32) * (out->Npad / 32);
   *bytes = x6_planes_bytes(K, p.Nout, npl, out->kd);
+  if (b16 && npl == 1 && out->kd == BW_KD) {   // a split-K launch of the 256-wide kernel keeps its partial slabs behind the planes
+    IgemmParams q = p;
+    q.C = Ckp;
+    q.K = K;
+    q.res = nullptr;
+    const int S = b16w_plan(q);
+    if (S > 1) *bytes = ((*bytes + 255) & ~(size_t)255) + b16w_scratch_bytes(S, q.M, q.Nout);
+  }
   return 0;
 }
 
@@ -2058,7 +2108,7 @@ int sg_bn_train_fwd_tiles(sg_ctx* ctx, void* stream, int dtype, int64_t rows, in
 size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d) {
   if (!d) return 0;
   const size_t native = (size_t)d->KH * d->KW * d->Cin * d->Cout * sizeof(float);
-  const size_t x6 = x6_ws_bytes(d->KH * d->KW, d->Cout, d->Cin);
+  const size_t x6 = x6_ws_bytes(d->KH * d->KW, d->Cout, d->Cin) + 256 + b16w_ws_extra(d, true);
   return native > x6 ? native : x6;
 }
 
@@ -2173,6 +2223,7 @@ static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv
       p.fd_hcwc = make_fastdiv((uint32_t)((d->H / 2) * (d->W / 2)));
       p.fd_wc = make_fastdiv((uint32_t)(d->W / 2));
     }
+    p.ws_room = prepared ? SIZE_MAX : ws_bytes;
     if (b16) return run_x6<1, bf16_t>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
     if (x6_mode() == 2) return run_x6<1, float>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);
     return run_x6<3, float>(p, (const float*)w, true, d->Cin, d->Cout, d->KH, d->KW, ws, ctx->num_cus, st, prepared);

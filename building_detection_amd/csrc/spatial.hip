@@ -176,8 +176,10 @@ struct DwRunParams {
 // RELU / MASK are compile-time and the window is branch-free (rows and columns outside the image load a valid address
 // and are zeroed by a select): with the run-time `if (relu_in)` and the `continue` on the row test every load sat in its
 // own basic block behind an s_waitcnt vmcnt(0) - 18..36 serialised memory latencies per run.
+// (SUMS: two workgroups per SIMD-row instead of three - its 40 more live registers spilled 150 of them under the 168-register
+// cap, 590 bytes of scratch per lane, and the kernel lost more than the reduction pass it replaces costs)
 template <int RR, typename T, bool RELU, bool MASK, bool BN = false, bool SUMS = false>
-__global__ __launch_bounds__(256, 3) void dw_s1_run_kernel(const DwRunParams<T> p) {
+__global__ __launch_bounds__(256, SUMS ? 2 : 3) void dw_s1_run_kernel(const DwRunParams<T> p) {
   // p.lc lanes (a power of two <= 64) cover the channel chunks of one run; with few channels (C = 64: 16 chunks)
   // a wave takes several runs instead of idling three quarters of its lanes
   const int lc = p.lc, rpb = 256 / lc;
@@ -618,7 +620,8 @@ constexpr int DW_SUMS_MAX_ROWS = 1024;
 template <typename T>
 int launch_dw_run(const DwRunParams<T>& p_in, hipStream_t st, int* sums_rows = nullptr) {
   DwRunParams<T> p = p_in;
-  const int rr = dw_rows_per_run(p.H, (int64_t)p.N * p.H * p.W, false);
+  int rr = dw_rows_per_run(p.H, (int64_t)p.N * p.H * p.W, false);
+  if (p.bs_part && rr == 4) rr = 2;   // the four-row window plus the BatchNormalization sums does not fit the register file
   p.nruns = (int64_t)p.N * (p.H / rr) * p.runs_per_row;
   p.fd_h = make_fastdiv((uint32_t)(p.H / rr));
   int lc = 1;

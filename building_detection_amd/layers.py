@@ -229,7 +229,9 @@ class _SepConvNode(Node):
             # BatchNormalization then only applies (Model._fuse: bnsum_src / sums_from; sg_dwconv2d_dgrad_bnsums)
             src = self.bnsum_src
             sv = rt._saved.get(id(src)) if src is not None else None
-            if sv is not None and "mean" in sv and e.dwconv_dgrad_acc_ok(ddw) and dt.dtype == x.dtype:
+            # (through a residual add - src.defer_add - the gradient must be complete here: nothing left in the sweep's table)
+            if (sv is not None and "mean" in sv and e.dwconv_dgrad_acc_ok(ddw) and dt.dtype == x.dtype
+                    and (rt._pending is None or id(root) not in rt._pending)):
                 dx = e.dwconv_dgrad_bnsums(dt, rt.param(self.dw), ddw, rt.values[id(src.inputs[0])], sv["mean"], sv["invstd"],
                                            rt.param(src.gamma), rt.param(src.beta), src.relu, rt.grad(src.gamma),
                                            rt.grad(src.beta), x=x, pre_relu=self.pre_relu, res=res)

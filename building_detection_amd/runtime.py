@@ -191,7 +191,28 @@ class Model:
                 _, h, w, c = t.shape
                 if sc.stride == 1 and sc.bnsum_src is None and w % 4 == 0 and c % 4 == 0:
                     n.sums_from, sc.bnsum_src = sc, n
-        if os.environ.get("SG_BN_DEFER", "0") == "1":
+            # The same through a residual Add that applies the layer (defer_add): the Add hands its output gradient on unchanged,
+            # so a BatchNormalization in front of it receives the gradient of the Add's OUTPUT - and where that output opens the
+            # next Xception block, its complete gradient leaves the depthwise dgrad of the block's first SeparableConv2D (which
+            # adds the gradient collected from the block's own residual add: take_pending).  Condition: that SeparableConv2D
+            # (with the ReLU absorbed into its gather) is the LAST consumer of the tensor in the backward sweep, i.e. the first
+            # in node order.
+            for sc in self.nodes:
+                if not isinstance(sc, L._SepConvNode) or sc.bnsum_src is not None or sc.stride != 1:
+                    continue
+                root, first = sc.inputs[0], sc
+                while isinstance(root.node, L._ActNode) and root.node.fused_away and len(root.consumers) == 1:
+                    root, first = root.node.inputs[0], root.node
+                a = root.node
+                if not isinstance(a, L._AddNode) or a.relu or id(root) in outs or len(root.shape) != 4:
+                    continue
+                if any(cn is not first and cn.index < sc.index for cn in root.consumers):
+                    continue
+                cands = [b for b in a.bn_src if b is not None and b.sums_from is None and b.defer_add is a]
+                _, h, w, c = root.shape
+                if cands and w % 4 == 0 and c % 4 == 0:
+                    cands[0].sums_from, sc.bnsum_src = sc, cands[0]
+        if os.environ.get("SG_BN_DEFER", "1") == "1":
             for n in self.nodes:
                 if not isinstance(n, L._BNNode) or len(n.output.shape) != 4 or id(n.output) in outs:
                     continue
@@ -599,7 +620,7 @@ class GraphedTrainStep:
         self.x, self.y = torch.empty_like(xd), torch.empty_like(yd)
         self.lr = eng.zeros(4)
         lanes = os.environ.get("SG_JIT_LANES", "1") != "0" and eng._side_on
-        lane_blocks = max(1, int(os.environ.get("SG_JIT_LANE_BLOCKS", "6")))
+        lane_blocks = max(1, int(os.environ.get("SG_JIT_LANE_BLOCKS", "12")))
         # (the eager sizing steps ran the filter gradients on the side stream with its own scratch; without lanes they run
         # inline here, on the main scratch)
         self.ws = torch.empty(max(eng._ws_peak, eng._ws2_peak, 256) + 256, dtype=torch.uint8, device=eng.device)

@@ -59,6 +59,10 @@ CONV_CASES = [
     ("res34_stem", 1, 64, 64, 3, 64, 3, 1, 1),       # Res34-UNet's real first conv: 3 -> 64, 3x3 s1 (predict_model/res34.py:50)
     ("odd_45", 2, 32, 32, 45, 45, 3, 1, 4),          # BAM reduce dim 45
     ("dense_like", 16, 1, 1, 256, 64, 1, 1, 1),
+    # the 256-wide LDS-DMA kernel (conv_b16w.h, round 4; aspp_d6 above takes it too: forward in four K shares, dgrad whole):
+    ("dec_256_256_3x3", 1, 128, 128, 256, 256, 3, 1, 1),   # 64 tiles per image, one K share, no tap skipping, forward AND dgrad
+    ("aspp_d18_b3", 3, 32, 32, 1024, 256, 3, 1, 18),       # rate 18 on a 32 x 32 map: most taps skipped, shares of a short walk
+    ("sk_like_d12", 2, 32, 32, 512, 512, 3, 1, 12),        # two column tiles, two K shares
 ]
 
 
@@ -94,6 +98,41 @@ def test_conv_bf16_vs_fp64_on_rounded_operands(engine, case):
     ebias = float((db.double().cpu() - dy.double().sum((0, 1, 2))).abs().max() / dy.double().sum((0, 1, 2)).abs().max())
     print(f"{name}: fwd {r_f:.2e} dgrad {r_d:.2e} (of 1 bf16 ulp = {ULP:.2e}); wgrad rel {ew:.2e} bias {ebias:.2e}")
     assert ew <= 2e-5 and ebias <= 2e-5   # fp32 accumulation of exact bf16 products
+
+
+@pytest.mark.parametrize("case", [("split_k", 2, 32, 32, 2048, 256, 3, 6), ("whole_k", 1, 64, 64, 256, 256, 3, 1),
+                                  ("ragged_cols", 1, 64, 64, 128, 224, 3, 2)], ids=lambda c: c[0])
+def test_wide_bf16_kernel_batchnorm_statistics_and_batch_invariance(engine, case):
+    """conv_b16w.h: (a) the per-128-row-tile BatchNormalization statistics (from the accumulators when one workgroup walks
+    the whole K, from b16w_reduce_kernel's registers when the walk is cut into shares) give the mean / variance of the fp32
+    convolution output; (b) an image's result does not depend on its batch (the number of K shares is a function of one
+    image's geometry): bit exact; (c) run to run bit exact."""
+    from oracle import tfops as T
+    e = engine
+    name, N, H, W, Cin, Cout, k, dil = case
+    g = torch.Generator().manual_seed(Cin + Cout + dil)
+    x = rb(torch.randn(N + 1, H, W, Cin, generator=g))
+    w = torch.randn(k, k, Cin, Cout, generator=g) * (1.0 / np.sqrt(k * k * Cin))
+    b = torch.randn(Cout, generator=g) * 0.1
+    xd, wd, bd = x.cuda().to(BF), w.cuda(), b.cuda()
+    d = e.conv_desc(tuple(x.shape), Cout, k, k, 1, dil, "same")
+    y, st = e.conv2d_fwd(xd, wd, bd, desc=d, want_stats=True)
+    assert st is not None, "the launch did not produce statistics"
+    stats, tiles = st
+    assert tiles == (N + 1) * H * W // 128
+    yr = T.conv2d(x.double(), rb(w).double(), b.double(), 1, dil, "same").reshape(-1, Cout)
+    close_bf16(y.reshape(-1, Cout), yr, what=f"{name} fwd")
+    sv = stats.view(tiles, 2, Cout).double().cpu()
+    tr = yr.reshape(tiles, 128, Cout)
+    s_ref = tr.sum(1)
+    q_ref = ((tr - tr.mean(1, keepdim=True)) ** 2).sum(1)
+    assert float((sv[:, 0] - s_ref).abs().max()) <= 2e-5 * float(tr.abs().sum(1).max()), name
+    assert float((sv[:, 1] - q_ref).abs().max()) <= 1e-4 * float(q_ref.max()), name
+    y2, _ = e.conv2d_fwd(xd, wd, bd, desc=d, want_stats=True)
+    assert torch.equal(y, y2)
+    d1 = e.conv_desc((1, H, W, Cin), Cout, k, k, 1, dil, "same")
+    y1 = e.conv2d_fwd(xd[N:N + 1].contiguous(), wd, bd, desc=d1)
+    assert torch.equal(y1[0], y[N]), "an image's bf16 result depends on its batch"
 
 
 def test_conv_transpose_and_head_bf16(engine):

@@ -159,7 +159,9 @@ def _jit_worker(rank, world, port, comm, policy, q):
         g = next(iter(mb._train_graphs.values()))
         weights_equal = all(np.array_equal(a, b) for a, b in zip(ma.get_weights(), mb.get_weights()))
         q.put(dict(rank=rank, same_logs=same, weights_equal=weights_equal, graphed=isinstance(g, GraphedTrainStep),
-                   segments=len(g.segments), buckets=len(db.buckets), eager_graphs=len(getattr(ma, "_train_graphs", {}) or {})))
+                   segments=len(g.segments), buckets=len(db.buckets), eager_graphs=len(getattr(ma, "_train_graphs", {}) or {}),
+                   side_graphs=g.side_graphs, handover_segments=sum(1 for seg in g.segments if seg[1]),
+                   lanes=os.environ.get("SG_JIT_LANES", "1") != "0" and os.environ.get("SG_SIDE_WGRAD", "1") != "0"))
     finally:
         dist.destroy_process_group()
 
@@ -184,16 +186,22 @@ def _run_jit(world, comm, policy):
     assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
     for r in res:
         assert r["graphed"] and r["eager_graphs"] == 0, r
-        # one cut per point of the sweep that completes buckets (<= one per bucket), a tail segment when the sweep goes on
-        # behind the last cut, and the Adam graph
-        assert r["buckets"] >= 2 and 3 <= r["segments"] <= r["buckets"] + 2, r
         assert r["same_logs"] and r["weights_equal"], r
+        # one cut per point of the sweep that completes buckets (<= one per bucket), a tail segment when the sweep goes on
+        # behind the last cut, and the Adam graph; with lanes (round 4: the filter gradients of a segment in a side graph of
+        # their own, replayed on the second stream) further cuts wherever a segment has collected SG_JIT_LANE_BLOCKS of them
+        assert r["buckets"] >= 2 and 1 <= r["handover_segments"] <= r["buckets"] and r["segments"] >= 3, r
+        if r["lanes"]:
+            assert r["side_graphs"] >= 2 and r["segments"] > r["handover_segments"] + 1, r
+        else:
+            assert r["side_graphs"] == 0 and r["segments"] <= r["buckets"] + 2, r
 
 
 @pytest.mark.parametrize("comm,policy", [("sg", "float32"), ("torch", "float32"), ("sg", "mixed_bfloat16")])
 def test_captured_data_parallel_step_is_bit_identical_to_the_eager_one_world1(engine, comm, policy):
-    """compile(jit_compile=True) under DataParallel.  The step is captured as one hipGraph segment per
-    gradient bucket (cut where the backward sweep completes the bucket) plus one graph for Adam; the bucket all-reduces
+    """compile(jit_compile=True) under DataParallel.  The step is captured as hipGraph segments
+    (cut where the backward sweep completes a gradient bucket, and - lanes - where a segment has collected enough filter
+    gradients, which are captured into side graphs replayed on the second stream) plus one graph for Adam; the bucket all-reduces
     (sg_comm_allreduce_sum / torch.distributed nccl) are issued eagerly between the segment launches, the loss and the
     confusion counts are reduced as in the eager step.  Seven steps against the eager data-parallel model on the same
     weights and batches: identical logs at every step and identical weights at the end, to the bit, with a validation batch

@@ -553,33 +553,42 @@ def test_segmented_data_parallel_step_gloo_world2():
 
 
 def test_depthwise_dgrad_takes_over_the_batchnorm_backward_sums(monkeypatch):
-    """Model._fuse (round 4): a 4-D BatchNormalization whose output reaches exactly one stride-1 SeparableConv2D (through the
-    ReLU absorbed into either of them) has its backward column sums produced by that layer's depthwise dgrad
-    (sg_dwconv2d_dgrad_bnsums; layers._BNNode.sums_from / _SepConvNode.bnsum_src).  Graph-level check on the CPU: the 39
-    such layers of DeepLabv3+ (32 in the middle flow, 7 in the entry / exit flows), none in the U-Nets (their BatchNormalization
-    layers feed ordinary convolutions), SG_BN_SUMS=0 switches the pass off, and a layer the residual add applies (defer_add)
-    is never taken."""
+    """Model._fuse (round 4): a 4-D BatchNormalization whose output gradient is written by the depthwise dgrad of ONE stride-1
+    SeparableConv2D has its backward column sums produced by that kernel (sg_dwconv2d_dgrad_bnsums; layers._BNNode.sums_from /
+    _SepConvNode.bnsum_src): (a) the layer's only consumer is that SeparableConv2D (through the ReLU absorbed into either of
+    them): 39 layers of DeepLabv3+, 32 in the middle flow and 7 in the entry / exit flows; (b) the layer is applied by a residual
+    Add (defer_add) whose output opens the next Xception block, and that block's first SeparableConv2D is the last consumer of
+    the tensor in the backward sweep: the inputs of the 16 middle-flow blocks and of the exit flow.  None in the U-Nets (their BatchNormalization layers
+    feed ordinary convolutions); SG_BN_SUMS=0 switches the pass off."""
     sys.path.insert(0, ROOT)
     from building_detection_amd import zoo, layers as L
 
     def count(m):
         pairs = [(n, n.sums_from) for n in m.nodes if isinstance(n, L._BNNode) and n.sums_from is not None]
+        direct = through_add = 0
         for bn, sc in pairs:
-            assert isinstance(sc, L._SepConvNode) and sc.bnsum_src is bn and sc.stride == 1 and bn.defer_add is None
+            assert isinstance(sc, L._SepConvNode) and sc.bnsum_src is bn and sc.stride == 1
             t = bn.output
-            while t.consumers and isinstance(t.consumers[0], L._ActNode):
-                assert len(t.consumers) == 1 and t.consumers[0].fused_away
+            while t.consumers and isinstance(t.consumers[0], L._ActNode) and t.consumers[0].fused_away and len(t.consumers) == 1:
                 t = t.consumers[0].output
-            assert t.consumers == [sc]
+            if bn.defer_add is None:
+                assert t.consumers == [sc]
+                direct += 1
+            else:
+                add = bn.defer_add
+                assert add in t.consumers and bn in add.bn_src and not add.relu
+                r = add.output
+                firsts = [c for c in r.consumers if c.index <= sc.index]
+                assert len(firsts) == 1   # the SeparableConv2D (or the ReLU absorbed into it) comes first in node order
+                through_add += 1
         assert sum(1 for n in m.nodes if isinstance(n, L._SepConvNode) and n.bnsum_src is not None) == len(pairs)
-        return len(pairs)
+        return direct, through_add
 
     monkeypatch.delenv("SG_BN_SUMS", raising=False)
-    assert count(zoo.BUILDERS["v3plus"]((128, 128, 3), 2, aspp_pool=8)) == 39
-    assert count(zoo.BUILDERS["bam"]((128, 128, 3), 2, aspp_pool=8)) == 39
-    assert count(zoo.BUILDERS["res34"]((64, 64, 3))) == 0
+    assert count(zoo.BUILDERS["v3plus"]((128, 128, 3), 2, aspp_pool=8)) == (39, 17)
+    assert count(zoo.BUILDERS["res34"]((64, 64, 3))) == (0, 0)
     monkeypatch.setenv("SG_BN_SUMS", "0")
-    assert count(zoo.BUILDERS["v3plus"]((128, 128, 3), 2, aspp_pool=8)) == 0
+    assert count(zoo.BUILDERS["v3plus"]((128, 128, 3), 2, aspp_pool=8)) == (0, 0)
 
 
 def test_residual_adds_take_over_their_batchnorm_layers(monkeypatch):

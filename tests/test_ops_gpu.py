@@ -507,8 +507,9 @@ def test_depthwise_dgrad_sums_the_batchnorm_backward(engine, bn_relu, pre_relu, 
     dy0, dg0, db0 = engine.bn_train_bwd(yd, zd, dz0, gd, mean, invstd, relu=bn_relu, beta=bd)
     assert torch.equal(dz, dz0), "the gradient tensor itself must not change"
     tol = RTOL if dtype == torch.float32 else 2 ** -7
-    close(dgam, dg0, rtol=1e-5, what="dgamma vs the unfused path")
-    close(dbet, db0, rtol=1e-5, what="dbeta vs the unfused path")
+    # (bf16 storage: the fused sums see the gradient before its rounding to bf16, the unfused reduction reads it rounded)
+    close(dgam, dg0, rtol=1e-5 if dtype == torch.float32 else 2 ** -7, what="dgamma vs the unfused path")
+    close(dbet, db0, rtol=1e-5 if dtype == torch.float32 else 2 ** -7, what="dbeta vs the unfused path")
     close(dy.float(), dy0.float(), rtol=1e-5 if dtype == torch.float32 else 2 ** -7, what="dy vs the unfused path")
     close(dgam, gr.grad, rtol=tol, what="dgamma vs oracle")
     close(dbet, br.grad, rtol=tol, what="dbeta vs oracle")
