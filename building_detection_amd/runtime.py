@@ -620,7 +620,7 @@ class GraphedTrainStep:
         self.x, self.y = torch.empty_like(xd), torch.empty_like(yd)
         self.lr = eng.zeros(4)
         lanes = os.environ.get("SG_JIT_LANES", "1") != "0" and eng._side_on
-        lane_blocks = max(1, int(os.environ.get("SG_JIT_LANE_BLOCKS", "12")))
+        lane_blocks = max(1, int(os.environ.get("SG_JIT_LANE_BLOCKS", "24")))
         # (the eager sizing steps ran the filter gradients on the side stream with its own scratch; without lanes they run
         # inline here, on the main scratch)
         self.ws = torch.empty(max(eng._ws_peak, eng._ws2_peak, 256) + 256, dtype=torch.uint8, device=eng.device)
