@@ -29,6 +29,10 @@ constexpr int BW_LDS = (2 * BW_STAGE > BW_M * BW_TP ? 2 * BW_STAGE : BW_M * BW_T
 
 __device__ __forceinline__ int bw_swz(int row) { return (row >> 1) & 7; }   // B16L<4>::swz
 
+// VAR (SG_B16W_VAR; A/B switch): 0 = the eight DMA instructions of stage s + 1 issued at the top of stage s, in front of its
+// MFMAs; 1 = woven - two of them behind the MFMAs of each of the four k-steps, so that the matrix pipe starts right behind the
+// barrier and the address unit works beside it.
+template <int VAR>
 __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, const int S, float* __restrict__ part) {
   constexpr unsigned OOB = 0x80000000u;
   constexpr int WGN = 4, WM = 128, WN = 64, TM = 4, TN = 2;
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, 
 
   int cur_tap = -1;
   unsigned a_voff[4] = {OOB, OOB, OOB, OOB};
-  auto issue = [&](int L, int stage) {
+  int soff_a = 0, soff_b = 0;
+  auto prepare = [&](int L) {   // scalar / per-tap work of a stage's DMA: offsets of the stage, the lane's row offsets on a tap change
     const int k0 = k0_of(L);
     const int tap = (int)fd_div((uint32_t)k0, p.fd_c);
     if (tap != cur_tap) {   // uniform
@@ -138,14 +143,18 @@ __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, 
         a_voff[i] = ok ? (unsigned)pix * (unsigned)p.x_ld * 2u + (unsigned)a_chunk[i] : OOB;
       }
     }
-    const int soff_a = (k0 - tap * p.C) * 2;
-    const int soff_b = (k0 / BW_KD) * p.Npad * BW_KD * 2;
+    soff_a = (k0 - tap * p.C) * 2;
+    soff_b = (k0 / BW_KD) * p.Npad * BW_KD * 2;
+  };
+  auto dma_piece = [&](int i, int stage) {   // piece i of A and of B (1 KB each)
     char* sa = smem + stage * BW_STAGE;
-    char* sb = sa + BW_M * BW_RB;
+    pw_lds_dma16(rsrc_x, sa + (wave + 8 * i) * 1024, a_voff[i], soff_a);
+    pw_lds_dma16(rsrc_w, sa + BW_M * BW_RB + (wave + 8 * i) * 1024, b_voff[i], soff_b);
+  };
+  auto issue = [&](int L, int stage) {
+    prepare(L);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) pw_lds_dma16(rsrc_x, sa + (wave + 8 * i) * 1024, a_voff[i], soff_a);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) pw_lds_dma16(rsrc_w, sb + (wave + 8 * i) * 1024, b_voff[i], soff_b);
+    for (int i = 0; i < 4; ++i) dma_piece(i, stage);
   };
 
   // ---- MFMA side -----------------------------------------------------------------------------------------------------------
@@ -161,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int sw = bw_swz(lr);   // wm, wn and the 32-row sub-tile offsets are multiples of 32: the swizzle depends on lr only
   const int a_lane = (wm + lr) * BW_RB, b_lane = BW_M * BW_RB + (wn + lr) * BW_RB;
-  auto compute = [&](int stage) {
+  auto compute = [&](int stage, int nxt, bool weave) {
     const char* sbuf = smem + stage * BW_STAGE;
     bf16x8_t af[2][TM], bf[2][TN];
     auto frags = [&](int ks, bf16x8_t (&a)[TM], bf16x8_t (&b)[TN]) {
@@ -180,6 +189,13 @@ __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, 
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+      if constexpr (VAR == 1) {
+        if (weave) {   // uniform
+          __builtin_amdgcn_sched_barrier(0);
+          dma_piece(ks, nxt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
     }
   };
 
@@ -189,11 +205,13 @@ __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, 
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < nk; ++s) {
       const int cur = s & 1;
-      if (s + 1 < nk) {   // stage cur ^ 1 was last read before the previous barrier
-        issue(st_begin + s + 1, cur ^ 1);
+      const bool more = s + 1 < nk;
+      if (more) {   // stage cur ^ 1 was last read before the previous barrier
+        if constexpr (VAR == 1) prepare(st_begin + s + 1);
+        else issue(st_begin + s + 1, cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      compute(cur);
+      compute(cur, cur ^ 1, more);
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
@@ -406,9 +424,11 @@ inline int b16w_plan(const IgemmParams& p) {
 inline size_t b16w_scratch_bytes(int S, int64_t M, int N) { return S > 1 ? (size_t)S * (size_t)M * (size_t)N * sizeof(float) : 0; }
 
 inline int launch_b16w(const IgemmParams& p, int S, float* scratch, hipStream_t st) {
+  static const int var = getenv("SG_B16W_VAR") ? atoi(getenv("SG_B16W_VAR")) : 0;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(conv_b16w_kernel, (size_t)BW_LDS);
+    int rc = set_dyn_lds(conv_b16w_kernel<0>, (size_t)BW_LDS);
+    if (!rc) rc = set_dyn_lds(conv_b16w_kernel<1>, (size_t)BW_LDS);
     if (rc) return rc;
     attr_done = true;
   }
@@ -421,7 +441,8 @@ inline int launch_b16w(const IgemmParams& p, int S, float* scratch, hipStream_t 
     sg_set_error("conv_b16w: an operand of %lld rows does not fit one 2 GiB buffer descriptor", (long long)p.M);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL(conv_b16w_kernel, dim3((unsigned)(tiles * S)), dim3(512), (size_t)BW_LDS, st, p, S, scratch);
+  if (var == 1) hipLaunchKernelGGL(conv_b16w_kernel<1>, dim3((unsigned)(tiles * S)), dim3(512), (size_t)BW_LDS, st, p, S, scratch);
+  else hipLaunchKernelGGL(conv_b16w_kernel<0>, dim3((unsigned)(tiles * S)), dim3(512), (size_t)BW_LDS, st, p, S, scratch);
   SG_LAUNCH_CHECK("conv_b16w_kernel");
   if (S > 1) {
     dim3 grid((unsigned)sg_cdiv(p.M, 128), (unsigned)sg_cdiv(p.Nout, 64));

@@ -1103,7 +1103,6 @@ thread_local bool g_sub_batch = false;
 #include "conv_x6wp.h"
 #include "conv_pw.h"
 #include "conv_b16w.h"
-#include "conv_stem.h"
 
 template <int NPL, typename TA>
 int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
@@ -1936,10 +1935,6 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
       return 0;
     }
   }
-  if (!head32 && stem3_ok(d) && aligned16(w) && aligned16(y) && (!(flags & SG_EPI_BIAS) || aligned16(bias))) {
-    // the RGB stem: a bandwidth-bound stencil kernel (conv_stem.h); fp32 results bit-identical to the fp32-MFMA kernel's
-    return b16 ? launch_stem3_fwd<bf16_t>(d, x, w, bias, y, flags, st) : launch_stem3_fwd<float>(d, x, w, bias, y, flags, st);
-  }
   if (thin_ok(d) && aligned16(x)) {
     if (!b16) {
 #define CALL(CO) thin_fwd_t<CO, float, float>(d, (const float*)x, (const float*)w, (const float*)bias, (float*)y, flags, st)
@@ -2258,12 +2253,7 @@ size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
   // the query does not know the storage type: the larger of the fp32 and the bf16 plan
   const WgradPlan pl = plan_wgrad(ctx->num_cus, d, false), pb = plan_wgrad(ctx->num_cus, d, true);
   const size_t a = pl.dw_part_bytes + pl.bias_part_bytes, b = pb.dw_part_bytes + pb.bias_part_bytes;
-  size_t m = (a > b ? a : b) + 512;
-  if (!check_desc(d, "sg_conv2d_wgrad_ws_bytes") && stem3_ok(d)) {
-    const size_t s3 = stem3_wgrad_ws_bytes(ctx->num_cus, d) + 512;
-    if (s3 > m) m = s3;
-  }
-  return m;
+  return (a > b ? a : b) + 512;
 }
 
 int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
@@ -2293,15 +2283,6 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     if (!b16 || head32) return launch_colsum<float>(ctx->num_cus, (const float*)dy, rows_y, d->Cout, yl_, (float*)dbias, bias_part, st);
     return launch_colsum<bf16_t>(ctx->num_cus, (const bf16_t*)dy, rows_y, d->Cout, yl_, (float*)dbias, bias_part, st);
   };
-  if (!head32 && stem3_ok(d) && ws_bytes >= stem3_wgrad_ws_bytes(ctx->num_cus, d)) {   // the RGB stem (conv_stem.h)
-    int blocks = 0;
-    rc = b16 ? launch_stem3_wgrad<bf16_t>(ctx->num_cus, d, x, dy, (float*)ws, blocks, st)
-             : launch_stem3_wgrad<float>(ctx->num_cus, d, x, dy, (float*)ws, blocks, st);
-    if (rc) return rc;
-    rc = launch_stem3_reduce((const float*)ws, (float*)dw, 27 * d->Cout, blocks, st);
-    if (rc) return rc;
-    return bias_grad();   // (after the reduction: its partial sums share the workspace)
-  }
   if (thin) {
     auto run = [&]() -> int {
       if (!b16) {

@@ -14,6 +14,7 @@ from building_detection_amd.ops import get_engine  # noqa: E402
 e = get_engine(0)
 N = int(os.environ.get("BATCH", "16"))
 iters = int(os.environ.get("ITERS", "5"))
+BF = os.environ.get("DTYPE", "f32") == "bf16"   # DTYPE=bf16: activations in bf16 storage (BASELINE configs[2]'s kernels)
 g = torch.Generator(device="cpu").manual_seed(0)
 
 
@@ -36,14 +37,16 @@ tot_ms = tot_fl = 0.0
 for name, cin, cout, k, dil in cases:
     h = 32 if name != "dec64" else 256
     x = (torch.rand(N, h, h, cin, generator=g) * 2 - 1).cuda()
+    if BF:
+        x = x.to(torch.bfloat16)
     w = ((torch.rand(k, k, cin, cout, generator=g) * 2 - 1) * 0.02).cuda()
     b = torch.zeros(cout).cuda()
     d = e.conv_desc(tuple(x.shape), cout, k, k, 1, dil, "same")
     y = e.conv2d_fwd(x, w, b, desc=d)
-    dy = (torch.rand(*y.shape, generator=g) * 2 - 1).cuda()
+    dy = (torch.rand(*y.shape, generator=g) * 2 - 1).cuda().to(y.dtype)
     fl = 2.0 * N * h * h * cout * k * k * cin / 1e12
     t_f = timed(lambda: e.conv2d_fwd(x, w, b, desc=d, out=y))
-    dx = e.empty(*x.shape)
+    dx = e.empty(*x.shape, dtype=x.dtype)
     t_d = timed(lambda: e.conv2d_dgrad(dy, w, d, out=dx))
     dw, db = e.empty(*w.shape), e.empty(cout)
     t_w = timed(lambda: e.conv2d_wgrad(x, dy, d, dw=dw, db=db))
@@ -53,4 +56,4 @@ for name, cin, cout, k, dil in cases:
         tot_ms += t_f + t_d + t_w
         tot_fl += 3 * fl
 print(f"dilated set: {tot_fl:.3f} TFLOP in {tot_ms:.3f} ms = {tot_fl / tot_ms * 1e3:.1f} TFLOP/s = "
-      f"{tot_fl / tot_ms * 1e3 / 157.3:.3f} of the fp32 MFMA peak")
+      + (f"{tot_fl / tot_ms * 1e3 / 2500.0:.3f} of the bf16 MFMA peak" if BF else f"{tot_fl / tot_ms * 1e3 / 157.3:.3f} of the fp32 MFMA peak"))

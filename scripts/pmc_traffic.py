@@ -16,6 +16,7 @@ src, dst = sys.argv[1], sys.argv[2]
 # helpers and adds the six layers' share of the batched preparation instead (4 B read + 12 B written per weight: three bf16
 # planes for the forward and three for the dgrad orientation).
 PREPARED = "--prepared" in sys.argv
+BF16 = "--bf16" in sys.argv   # DTYPE=bf16 passes: conv_b16w / conv_b16 forward and dgrad kernels, every activation 2 bytes
 N_WEIGHTS = 3 * 9 * 2048 * 256 + 3 * 9 * 256 * 256
 names = ["aspp_d6", "aspp_d12", "aspp_d18", "sk_d6", "sk_d12", "sk_d18"]
 out = {}
@@ -27,7 +28,7 @@ for kind, mul in (("fetch", 2 * 1024), ("write", 1024)):
     helpers = split = 0.0
     for r in rows:
         k, v = r["Kernel_Name"], float(r["Counter_Value"]) * mul
-        if "igemm_conv_kernel" in k or "conv_x6_kernel" in k:  # per case: 3 forward launches (1 + warm-up + 1 timed), then 2 dgrad
+        if "igemm_conv_kernel" in k or "conv_x6_kernel" in k or "conv_b16_kernel" in k or "conv_b16w_kernel" in k:  # per case: 3 forward launches (1 + warm-up + 1 timed), then 2 dgrad
             per["fwd" if ci % 5 < 3 else "dgrad"].setdefault(ci // 5, []).append(v)
             ci += 1
         elif "igemm_wgrad_kernel" in k or "wgrad_x6_kernel" in k:
@@ -48,9 +49,11 @@ if PREPARED:
     tot += out["fetch"]["prepare_share_per_step"] + out["write"]["prepare_share_per_step"]
 MiB = 2 ** 20
 alg = (3 * 3 * (128 + 18 + 16) + 3 * 3 * (16 + 2.25 + 16)) * MiB
+if BF16:   # each operand once, activations and weight planes in bf16 (the filter gradient itself stays fp32)
+    alg = (3 * (2 * (64 + 9 + 8) + (64 + 8 + 18)) + 3 * (2 * (8 + 1.125 + 8) + (8 + 8 + 2.25))) * MiB
 json.dump({"source": f"{src}/pmc_fetch + pmc_write: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE -- python3 scripts/dilated_bench.py (ONLY_DILATED=1 ITERS=1)",
            "correction": "FETCH_SIZE x2 (gfx950) x1024; WRITE_SIZE x1024; fabric-side bytes, Infinity-Cache hits included",
-           "cases": names, "per_launch_bytes": out, "set_bytes_per_step": tot, "algorithmic_bytes_per_step": alg}, open(dst, "w"), indent=1)
+           "dtype": "bf16 storage" if BF16 else "fp32", "cases": names, "per_launch_bytes": out, "set_bytes_per_step": tot, "algorithmic_bytes_per_step": alg}, open(dst, "w"), indent=1)
 for t in ("fwd", "dgrad", "wgrad"):
     print(t, " ".join(f"{n}: {out['fetch'][t][i] / MiB:.0f}+{out['write'][t][i] / MiB:.0f}" for i, n in enumerate(names)), "MiB (fetch+write)")
 print(f"set total per step {tot / MiB:.0f} MiB; algorithmic {alg / MiB:.0f} MiB")

@@ -191,8 +191,8 @@ def _run_jit(world, comm, policy):
         # behind the last cut, and the Adam graph; with lanes (round 4: the filter gradients of a segment in a side graph of
         # their own, replayed on the second stream) further cuts wherever a segment has collected SG_JIT_LANE_BLOCKS of them
         assert r["buckets"] >= 2 and 1 <= r["handover_segments"] <= r["buckets"] and r["segments"] >= 3, r
-        if r["lanes"]:
-            assert r["side_graphs"] >= 2 and r["segments"] > r["handover_segments"] + 1, r
+        if r["lanes"]:   # (with 24 buckets the bucket cuts come before a segment has collected 24 filter gradients)
+            assert r["side_graphs"] >= 2 and r["segments"] >= r["handover_segments"] + 1, r
         else:
             assert r["side_graphs"] == 0 and r["segments"] <= r["buckets"] + 2, r
 
