@@ -376,7 +376,7 @@ def main():
         # --pmc runs of scripts/dilated_bench.py at this very configuration; scripts/pmc_traffic.py)
         traffic, traffic_note = None, "PMC passes exist for the 512x512 bs16 fp32 configuration only"
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        tj = next((os.path.join(pdir, n) for n in ("r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n))), None)
+        tj = next((os.path.join(pdir, n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n))), None)
         if args.batch == 16 and args.size == 512 and tj and not b16:
             with open(tj) as f:
                 tr = json.load(f)

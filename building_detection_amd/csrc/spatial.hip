@@ -417,8 +417,11 @@ struct DwWgradRunOp {
 // BN: x is the raw output of the producing convolution and the training-mode BatchNormalization (+ ReLU = PRE) in front of
 // this depthwise convolution is applied where a row is consumed, with bn_apply_kernel's expression (SG_BN_DEFER, as
 // DwWgradRunOp<.., BN = true>); the zero padding then has to be put back by masks, since BN(0) != 0.
-template <typename T, bool PRE, bool BN>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void dw_wgrad_strip_kernel(
+// (BN: held to two waves per SIMD - left to itself the variant takes a few registers more than 256, i.e. ONE wave per SIMD,
+// and ran 110 us where the plain kernel takes 50 (profiles/r04_bench_kernel_stats_final.csv))
+// OCC2 (SG_DW_STRIP_OCC2, A/B switch for the BN variants): two waves per SIMD with 12 - 62 spilled registers
+template <typename T, bool PRE, bool BN, bool OCC2 = false>
+__global__ __launch_bounds__(256, OCC2 ? 2 : 1) __attribute__((amdgpu_waves_per_eu(1, 2))) void dw_wgrad_strip_kernel(
     const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ part, const int H, const int W, const int C,
     const int x_ld, const int y_ld, const int HS, const int nstrips, const int S, const unsigned x_bytes, const unsigned y_bytes,
     const FastDiv fd_q, const FastDiv fd_hs, const float* __restrict__ bn_gamma, const float* __restrict__ bn_beta,
@@ -1257,6 +1260,12 @@ static int dwconv2d_wgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_co
       const unsigned yb_ = (unsigned)((int64_t)d->N * d->H * d->W * op.y_ld * (int64_t)sizeof(T));
       auto strip = [&](auto pre_, auto bn_) {
         constexpr bool PRE_ = decltype(pre_)::value, BN_ = decltype(bn_)::value;
+        static const int occ2 = getenv("SG_DW_STRIP_OCC2") ? atoi(getenv("SG_DW_STRIP_OCC2")) : 0;
+        if (BN_ && occ2)
+          hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, PRE_, BN_, BN_>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy,
+                             (float*)ws, d->H, d->W, op.C, op.x_ld, op.y_ld, sp.HS, sp.nstrips, sp.S, xb_, yb_, fq, fh,
+                             (const float*)bn_gamma, (const float*)bn_beta, (const float*)bn_mean, (const float*)bn_invstd);
+        else
         hipLaunchKernelGGL((dw_wgrad_strip_kernel<T, PRE_, BN_>), grid, dim3(256), 0, (hipStream_t)stream, (const T*)x, (const T*)dy,
                            (float*)ws, d->H, d->W, op.C, op.x_ld, op.y_ld, sp.HS, sp.nstrips, sp.S, xb_, yb_, fq, fh,
                            (const float*)bn_gamma, (const float*)bn_beta, (const float*)bn_mean, (const float*)bn_invstd);
