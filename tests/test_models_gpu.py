@@ -602,6 +602,59 @@ def test_filter_gradients_on_the_second_stream_change_nothing(engine, name):
         assert np.array_equal(wa, wb)
 
 
+def test_side_stream_operands_are_released_during_the_backward_pass(engine):
+    """ADVICE r3 (ops.py:180): the operands of the side stream's filter gradients (a layer's input and output gradient) were
+    held until the join at the END of the backward pass - every layer's output gradient alive for the whole sweep.  Now a
+    group of them goes when the side stream has passed its event, and past `_side_keep_bound` bytes the main stream joins
+    the side stream (a device-side wait) and everything held is dropped.  With a small bound: the held bytes never pass
+    bound + one block's operands, the peak of the step is lower than with an unlimited bound, and loss / gradients are
+    the same bits."""
+    from building_detection_amd import zoo
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss
+    m = zoo.BUILDERS["v3plus"]((128, 128, 3), aspp_pool=8)
+    m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
+    x, y = synthetic_batch(4, 128, 128, seed=9)
+    xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    w0 = m.get_weights()
+    saved = engine._side_keep_bound
+    seen = []
+    orig = engine.side
+
+    def watched(*a, **k):
+        seen.append(engine._side_kept)
+        return orig(*a, **k)
+    try:
+        out = {}
+        for bound in (1 << 60, 8 << 20):
+            engine._side_keep_bound = bound
+            m.set_weights(w0)
+            m.optimizer.iterations = 0
+            rt = m._runtime()
+            rt.adam_m.zero_(); rt.adam_v.zero_()
+            m.train_on_batch(xd, yd)          # allocator warm-up at this bound
+            m.set_weights(w0)
+            m.optimizer.iterations = 0
+            rt.adam_m.zero_(); rt.adam_v.zero_()
+            torch.cuda.synchronize()
+            torch.cuda.reset_peak_memory_stats()
+            seen.clear()
+            engine.side = watched
+            logs = m.train_on_batch(xd, yd)
+            engine.side = orig
+            torch.cuda.synchronize()
+            out[bound] = (logs["loss"], [g.copy() for g in m.get_gradients()], torch.cuda.max_memory_allocated(), max(seen))
+        (la, ga, pa, ka), (lb, gb, pb, kb) = out[1 << 60], out[8 << 20]
+        print(f"side-stream operands held: unlimited bound {ka / 2 ** 20:.0f} MiB (peak {pa / 2 ** 20:.0f} MiB), 8 MiB bound "
+              f"{kb / 2 ** 20:.0f} MiB (peak {pb / 2 ** 20:.0f} MiB)")
+        assert la == lb and all(np.array_equal(a, b) for a, b in zip(ga, gb))
+        assert ka > 4 * kb and kb <= (8 << 20) + (64 << 20)
+        assert pb < pa
+    finally:
+        engine.side = orig
+        engine._side_keep_bound = saved
+
+
 @pytest.mark.parametrize("policy", ["float32", "mixed_bfloat16"])
 def test_batchnorm_applied_in_the_depthwise_gather(engine, policy, monkeypatch):
     """Fusion BatchNormalization(+ReLU) -> SeparableConv2D (training): the depthwise gather normalises the raw tensor with
