@@ -159,13 +159,18 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
 // Second stage: a 64 (channels) x 4 (split lanes) block adds the S partial rows of its channels in fp64 — each
 // lane a fixed subset z = lane, lane+4, ..., the four lane sums combined in fixed order through LDS — and
 // hands the NOUT totals of each channel to op.finalize.  Reads are coalesced along C.
-template <class Op>
+// LANES = 16 (round 4; seg_finalize_launch picks it for S >= 32): 16 channels x 16 lanes per block.  With 4 lanes a launch over
+// 256 partial rows x 728 channels is 12 workgroups whose lanes each walk 64 rows one behind the other: 16 - 19 us for 1.5 MB
+// (profiles/r04_bench_kernel_stats_final.csv: 140 such launches per step); 16 lanes walk 16 rows each in 46 workgroups.  The
+// lane sums are added in lane order: deterministic, but another order than with 4 lanes - a launch's LANES depends on S only.
+template <class Op, int LANES = 4>
 __global__ __launch_bounds__(256) void seg_finalize_kernel(const Op op, const int nseg, const int C, const int S,
                                                            const float* __restrict__ part) {
   constexpr int NO = Op::NOUT;
-  __shared__ double red[4][64][NO];
-  const int tx = threadIdx.x & 63, zl = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + tx, seg = blockIdx.y;
+  constexpr int CH = 256 / LANES;   // channels per block
+  __shared__ double red[LANES][CH][NO];
+  const int tx = threadIdx.x % CH, zl = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + tx, seg = blockIdx.y;
   double s[NO];
 #pragma unroll
   for (int o = 0; o < NO; ++o) s[o] = 0.0;
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void seg_finalize_kernel(const Op op, const in
     // backward's finalize 15 -> 6 us; with NOUT = 9 (depthwise wgrad) the same unroll spills and runs 5x slower
     constexpr int UNROLL = NO <= 2 ? 8 : 1;
 #pragma unroll UNROLL
-    for (int z = zl; z < S; z += 4) {
+    for (int z = zl; z < S; z += LANES) {
       const float* p = part + (((int64_t)seg * S + z) * NO) * C + c;
 #pragma unroll
       for (int o = 0; o < NO; ++o) s[o] += (double)p[(int64_t)o * C];
@@ -185,9 +190,24 @@ __global__ __launch_bounds__(256) void seg_finalize_kernel(const Op op, const in
   __syncthreads();
   if (zl == 0 && c < C) {
 #pragma unroll
-    for (int o = 0; o < NO; ++o) s[o] = ((red[0][tx][o] + red[1][tx][o]) + red[2][tx][o]) + red[3][tx][o];
+    for (int o = 0; o < NO; ++o) {
+      double t = red[0][tx][o];
+#pragma unroll
+      for (int l = 1; l < LANES; ++l) t += red[l][tx][o];   // ((0 + 1) + 2) + 3 ...
+      s[o] = t;
+    }
     op.finalize(seg, c, s);
   }
+}
+
+// the finalize launch: 16 lanes per channel where there are many partial rows
+template <class Op>
+static inline void seg_finalize_launch(const Op& op, int nseg, int C, int S, const float* part, hipStream_t st) {
+  static const int wide = getenv("SG_FINALIZE_LANES") ? atoi(getenv("SG_FINALIZE_LANES")) : 16;   // A/B switch: 4 = rounds 1 - 3
+  if (S >= 32 && wide == 16)
+    hipLaunchKernelGGL((seg_finalize_kernel<Op, 16>), dim3((unsigned)sg_cdiv(C, 16), (unsigned)nseg), dim3(256), 0, st, op, nseg, C, S, part);
+  else
+    hipLaunchKernelGGL((seg_finalize_kernel<Op, 4>), dim3((unsigned)sg_cdiv(C, 64), (unsigned)nseg), dim3(256), 0, st, op, nseg, C, S, part);
 }
 
 struct SegPlan {
@@ -284,8 +304,7 @@ static inline int seg_reduce_launch(const Op& op, const SegPlan& pl, int nseg, i
     hipLaunchKernelGGL((seg_reduce_kernel<Op, 1>), grid, block, lds, st, op, rows, C, pl.S, part, cnt, fuse);
   SG_LAUNCH_CHECK(name);
   if (!fuse) {
-    hipLaunchKernelGGL((seg_finalize_kernel<Op>), dim3((unsigned)sg_cdiv(C, 64), (unsigned)nseg), dim3(256), 0, st, op, nseg,
-                       C, pl.S, (const float*)part);
+    seg_finalize_launch(op, nseg, C, pl.S, (const float*)part, st);
     SG_LAUNCH_CHECK(name);
   }
   return 0;

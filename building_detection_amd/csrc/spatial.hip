@@ -1202,8 +1202,7 @@ int sg_dwconv2d_dgrad_bnsums(sg_ctx* ctx, void* stream, int dtype, const sg_conv
     if (rc) return rc;
     BnSumsFinalOp op;
     op.dgamma = (float*)dgamma; op.dbeta = (float*)dbeta;
-    hipLaunchKernelGGL((seg_finalize_kernel<BnSumsFinalOp>), dim3((unsigned)sg_cdiv(d->Cin, 64), 1u), dim3(256), 0, st, op, 1, d->Cin,
-                       rows, (const float*)ws);
+    seg_finalize_launch(op, 1, d->Cin, rows, (const float*)ws, st);
   });
   SG_LAUNCH_CHECK("sg_dwconv2d_dgrad_bnsums");
   return 0;
@@ -1278,8 +1277,7 @@ static int dwconv2d_wgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_co
       SG_LAUNCH_CHECK("dw_wgrad_strip_kernel");
       DwWgradRunOp<1, T, false> fin;   // finalize() only: dw[t][c] = the fp64 sum of the S partial rows
       fin.dw = (float*)dw; fin.C = op.C;
-      hipLaunchKernelGGL((seg_finalize_kernel<DwWgradRunOp<1, T, false>>), dim3((unsigned)sg_cdiv(op.C, 64), 1u), dim3(256), 0,
-                         (hipStream_t)stream, fin, 1, op.C, sp.S, (const float*)ws);
+      seg_finalize_launch(fin, 1, op.C, sp.S, (const float*)ws, (hipStream_t)stream);
       SG_LAUNCH_CHECK("dw_wgrad_strip finalize");
       return 0;
     }

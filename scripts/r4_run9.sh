@@ -16,7 +16,10 @@ run() { name=$1; shift; env "$@" $BB ${EXTRA:-} > $OUT/bench_$name.json 2> $OUT/
 for rep in 1 2 3; do
   EXTRA="--no-jit" run rr_default_$rep A=1
   EXTRA="--no-jit" run rr2_$rep SG_DW_RR=2
+  EXTRA="--no-jit" run fin4_$rep SG_FINALIZE_LANES=4
 done
+EXTRA="--no-jit --dtype bf16" run bf16_fin16 A=1
+EXTRA="--no-jit --dtype bf16" run bf16_fin4 SG_FINALIZE_LANES=4
 for rep in 1 2; do
   EXTRA="--jit" run lanes16_$rep SG_JIT_LANE_BLOCKS=16
   EXTRA="--jit" run lanes24_$rep SG_JIT_LANE_BLOCKS=24
