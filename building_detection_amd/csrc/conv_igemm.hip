@@ -946,6 +946,39 @@ __global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restr
   }
 }
 
+// The same with FOUR lanes per output quad (round 4; for S >= 8): lane zl adds slabs zl, zl + 4, ... in order, the four lane sums
+// are added ((0 + 1) + 2) + 3 through LDS - deterministic.  A 21-slab reduction of a 728 x 728 gradient (44 MB) is 518
+// workgroups of the kernel above whose threads each walk 21 loads, eight in flight: 20 - 29 us, 2.2 TB/s
+// (profiles/r04_bench_kernel_stats_final.csv: 90 launches per step); four times the threads walk five loads each.
+__global__ __launch_bounds__(256) void reduce_splits_z4_kernel(const float* __restrict__ part, float* __restrict__ out, int64_t n, int S) {
+  __shared__ f32x4 red[4][64];
+  const int q = threadIdx.x & 63, zl = threadIdx.x >> 6;
+  const int64_t stride = (int64_t)gridDim.x * 64 * 4;
+  for (int64_t i0 = (int64_t)blockIdx.x * 64 * 4; i0 < n; i0 += stride) {   // (uniform trip count per workgroup: barriers inside)
+    const int64_t i = i0 + (int64_t)q * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < n) {
+#pragma unroll 4
+      for (int z = zl; z < S; z += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(part + (int64_t)z * n + i);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += v[k];
+      }
+    }
+    red[zl][q] = s;
+    __syncthreads();
+    if (zl == 0 && i < n) {
+      f32x4 t = red[0][q];
+#pragma unroll
+      for (int l = 1; l < 4; ++l)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] += red[l][q][k];
+      *reinterpret_cast<f32x4*>(out + i) = t;
+    }
+    __syncthreads();
+  }
+}
+
 // bias gradient = column sums of dy[rows][C] (pixel stride ld), through the fixed-order segmented reducer
 template <typename T>
 struct ColSumOp {
@@ -2411,7 +2444,12 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     const bool v4 = (n % 4 == 0) && aligned16(ws) && aligned16(dw);
     int64_t blocks = sg_cdiv(n, v4 ? 1024 : 256);
     if (blocks > 2048) blocks = 2048;
-    if (v4)
+    static const int z4 = getenv("SG_REDUCE_Z4") ? atoi(getenv("SG_REDUCE_Z4")) : 1;   // A/B switch: 0 = the one-lane kernel of rounds 1 - 3
+    if (v4 && z4 && total_parts >= 8) {
+      int64_t b4 = sg_cdiv(n, 256);
+      if (b4 > 4096) b4 = 4096;
+      hipLaunchKernelGGL(reduce_splits_z4_kernel, dim3((unsigned)b4), dim3(256), 0, st, (const float*)ws, (float*)dw, n, total_parts);
+    } else if (v4)
       hipLaunchKernelGGL(reduce_splits_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, (float*)dw, n, total_parts);
     else
       hipLaunchKernelGGL(reduce_splits_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, (float*)dw, n, total_parts);

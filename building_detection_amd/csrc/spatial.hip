@@ -614,7 +614,9 @@ inline bool dw_strip_ok(const sg_conv_desc* d) {
 inline int dw_rows_per_run(int H, int64_t pixels, bool wgrad) {
   static const int force = getenv("SG_DW_RR") ? atoi(getenv("SG_DW_RR")) : 0;  // A/B switch: 1, 2 or 4
   const bool small = pixels <= 32768;
-  const int want = force ? force : (wgrad ? (small ? 1 : 2) : (small ? 4 : 2));
+  // (round 4: two rows per stencil run on the small maps too - the four-row window runs at the 168-register cap with 47 - 73
+  // spilled registers; three alternating repetitions on one box: 75.90 -> 75.04 ms per step, profiles/r04_ab_runs.txt)
+  const int want = force ? force : (wgrad ? (small ? 1 : 2) : 2);
   return (want >= 4 && H % 4 == 0) ? 4 : ((want >= 2 && H % 2 == 0) ? 2 : 1);
 }
 

@@ -826,8 +826,8 @@ def run_segments(segments, arena, transport, lanes=None):
     gradients W_k: on the side stream (`lanes`: _StreamLanes) behind everything queued on the main stream so far, i.e.
     beside M_(k+1); the main stream waits for W_(k-2) before M_k (W_(k-2)'s operands may be overwritten from M_k on: the
     capture held them that long).  Each arena range a segment completed then goes to the transport's asynchronous
-    sum-all-reduce - issued from the side stream when the segment has a side graph (the range holds gradients W_k writes; the
-    side stream is behind M_k too) - which runs beside the next segment; at the end the main stream joins the side stream
+    sum-all-reduce - with lanes ALWAYS issued from the side stream, behind M_k (a fork) and behind every side graph launched so
+    far: the range holds gradients that W_k or the side graph of an earlier segment writes - which runs beside the next segment; at the end the main stream joins the side stream
     and the transport before whatever follows (Adam).  Device-agnostic: the CPU tests drive it over gloo with callables that
     write gradients and `lanes` = an in-line stand-in (or None: side launches run in line)."""
     import contextlib
@@ -852,6 +852,12 @@ def run_segments(segments, arena, transport, lanes=None):
                 side_launch()
         marks.append(mark)
         if transport is not None and ready:
+            if lanes is not None and side_launch is None:
+                # a bucket may hold gradients that the side graph of an EARLIER segment writes (a bucket spans several
+                # segments when the lanes cut between two hand-overs) and that graph may still be running: the hand-over
+                # always goes through the side stream, behind this segment's main graph and every side graph so far
+                lanes.fork()
+                ctx = lanes.on_side()
             with ctx:
                 for s, e in ready:
                     transport.allreduce_async(arena[s:e])

@@ -520,12 +520,14 @@ def _segments_worker(rank, world, port, q):
         i_main = log.index(("main", k))
         if has_side[k]:
             order_ok = order_ok and log[i_main + 1] == ("fork",) and log[i_main + 2] == ("side", k, True)
+        elif segs[k][1]:   # no side graph of its own, but buckets to hand over: from the side lane, behind a fork
+            order_ok = order_ok and log[i_main + 1] == ("fork",) and log[i_main + 2] == ("allreduce", True)
         if k >= 2 and has_side[k - 2]:
             order_ok = order_ok and ("wait", marks_of[k - 2]) in log[:i_main]
     waits = [e[1] for e in log if e[0] == "wait"]
     order_ok = order_ok and sorted(waits) == list(range(nmark))
     ar_sides = [e[1] for e in log if e[0] == "allreduce"]
-    want_sides = [has_side[k] for k, (_, ready) in enumerate(segs) for _ in ready]
+    want_sides = [True for k, (_, ready) in enumerate(segs) for _ in ready]   # every hand-over goes through the side lane
     order_ok = order_ok and ar_sides == want_sides
     q.put((rank, bool(ok and ok2 and order_ok), len(segs), fired_eager == fired_seg, len(buckets)))
     dist.destroy_process_group()
