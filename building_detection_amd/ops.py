@@ -155,6 +155,7 @@ class Engine:
         self._side_free_events = []
         self._side_group_blocks = 0
         self._side_kept = 0          # bytes of operands held (an operand listed twice counts twice: an upper bound)
+        self._side_blocks_since_join = 0
         self._side_keep_bound = int(float(os.environ.get("SG_SIDE_KEEP_GIB", "4")) * 2 ** 30)
         self._in_side = False
         self.lane = None         # set while a training step is captured with a side lane (side_run defers into it)
@@ -209,12 +210,16 @@ class Engine:
                 self._side_free_events.append(ev)
             # The host queues a step well ahead of the device, so completed events alone release late.  Past SG_SIDE_KEEP_GIB
             # (default 4) of held operands the main stream joins the side stream - a device-side wait, no host sync - and
-            # everything held is dropped: the peak of a DeepLabv3+ 512 x 512 bs 16 step falls from 35.5 to ~29 GiB (25.2
-            # without the second stream) for ~8 joins per backward pass.
-            if self._side_kept > self._side_keep_bound:
+            # everything held is dropped: the peak of a DeepLabv3+ 512 x 512 bs 16 step falls from 35.5 to ~24 GiB (25.2
+            # without the second stream) for ~8 joins per backward pass.  Not more often than every 16 side blocks: a
+            # join makes the chain wait for the filter gradients queued so far, and the U-Nets' full-resolution layers hold
+            # 2 GiB per block (a join every other layer cost Res34-UNet 3 % of its step).
+            self._side_blocks_since_join += 1
+            if self._side_kept > self._side_keep_bound and self._side_blocks_since_join >= self._SIDE_JOIN_MIN_BLOCKS:
                 self.join_side()
 
     _SIDE_GROUP = 4   # side blocks per release event (an event costs the host a few microseconds)
+    _SIDE_JOIN_MIN_BLOCKS = 16
 
     def side_run(self, tag, tensors, fn, kind=2):
         """`fn()` - the launches of one filter gradient - beside the input-gradient chain.  Eager step: inside side() (second
@@ -257,6 +262,7 @@ class Engine:
                 self._side_free_events.append(self._side_groups.popleft()[0])
             self._side_group_blocks = 0
             self._side_kept = 0
+            self._side_blocks_since_join = 0
 
     def ws(self, nbytes: int):
         nbytes = int(nbytes)

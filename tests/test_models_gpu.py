@@ -617,7 +617,8 @@ def test_side_stream_operands_are_released_during_the_backward_pass(engine):
     x, y = synthetic_batch(4, 128, 128, seed=9)
     xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
     w0 = m.get_weights()
-    saved = engine._side_keep_bound
+    saved, saved_min = engine._side_keep_bound, engine._SIDE_JOIN_MIN_BLOCKS
+    engine._SIDE_JOIN_MIN_BLOCKS = 1   # (the engine joins at most once per 16 side blocks; here every block may)
     seen = []
     orig = engine.side
 
@@ -653,6 +654,7 @@ def test_side_stream_operands_are_released_during_the_backward_pass(engine):
     finally:
         engine.side = orig
         engine._side_keep_bound = saved
+        engine._SIDE_JOIN_MIN_BLOCKS = saved_min
 
 
 @pytest.mark.parametrize("policy", ["float32", "mixed_bfloat16"])
