@@ -621,3 +621,39 @@ def test_residual_adds_take_over_their_batchnorm_layers(monkeypatch):
     assert count(zoo.BUILDERS["res34"]((64, 64, 3))) == 20   # its blocks activate before they add: the Add applies BN and ReLU
     monkeypatch.setenv("SG_BN_ADD", "0")
     assert count(zoo.BUILDERS["v3plus"]((128, 128, 3), 2, aspp_pool=8)) == 0
+
+
+def test_bench_bf16_leg_folds_the_child_line(monkeypatch):
+    """bench.py (round 4): BASELINE configs[2]'s per-GPU workload rides in the fp32 line as config.bf16_leg - a CHILD process
+    `bench.py --dtype bf16` after and outside the fp32 timed region (started, never exec'ed).  Host logic only: the command the
+    parent builds, what it keeps of the child's JSON line, and that a failing child leaves an error entry instead of an
+    exception (the fp32 line must not depend on it)."""
+    import json
+    import subprocess
+    import types
+    sys.path.insert(0, ROOT)
+    import bench
+    seen = {}
+    line = {"metric": "m", "value": 505.0, "ms_per_step": 31.7, "steps": 10, "warmup": 3, "dtype": "bf16", "dtype_note": "n",
+            "roofline": {"frac": 0.33, "achieved": 840.0, "peak": 2500.0, "unit": "TFLOP/s", "ms_per_step": 1.86,
+                         "family": {"frac": 0.2, "achieved": 490.0, "ms_per_step": 19.7}},
+            "config": {"train_step": "eager launches", "train_step_choice": None, "final_loss": 0.02, "host_enqueue_ms_per_step": 23.0,
+                       "peak_device_memory_gib": 13.5}}
+
+    def fake_run(cmd, **kw):
+        seen["cmd"] = cmd
+        return types.SimpleNamespace(returncode=0, stdout=("noise\n" + json.dumps(line) + "\n").encode(), stderr=b"")
+    monkeypatch.setattr(subprocess, "run", fake_run)
+    args = types.SimpleNamespace(batch=16, size=512, model="v3plus")
+    leg = bench.bf16_leg(args)
+    cmd = seen["cmd"]
+    assert cmd[0] == sys.executable and cmd[1].endswith("bench.py")
+    for flag in ("--dtype", "bf16", "--no-cpu-baseline", "--no-bf16-leg", "--steps", "10", "--warmup", "3"):
+        assert flag in cmd, (flag, cmd)
+    assert leg["ms_per_step"] == 31.7 and leg["tiles_per_s"] == 505.0 and leg["dtype"] == "bf16"
+    assert leg["roofline"]["frac"] == 0.33 and leg["family"]["frac"] == 0.2 and leg["steps"] == 10
+
+    def failing_run(cmd, **kw):
+        return types.SimpleNamespace(returncode=3, stdout=b"", stderr=b"boom")
+    monkeypatch.setattr(subprocess, "run", failing_run)
+    assert "error" in bench.bf16_leg(args)
