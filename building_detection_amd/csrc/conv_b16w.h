@@ -333,8 +333,10 @@ __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, 
 // (deterministic); one workgroup per (128 rows, 64 columns): a thread holds 8 rows x 4 columns, so the per-128-row-tile
 // BatchNormalization statistics (sum, then centred sum of squares around the tile mean - the conv epilogues' two passes) come
 // from registers.
+// (TY = bf16_t: conv_b16w_kernel's launches; float: conv_x6w_kernel's)
+template <typename TY>
 __global__ __launch_bounds__(256) void b16w_reduce_kernel(const float* __restrict__ part, const float* __restrict__ bias,
-                                                          bf16_t* __restrict__ y, float* __restrict__ stats, int M, int N, int y_ld,
+                                                          TY* __restrict__ y, float* __restrict__ stats, int M, int N, int y_ld,
                                                           int S, int relu) {
   __shared__ float red[16][64];
   __shared__ float tmean[64];
@@ -365,7 +367,7 @@ __global__ __launch_bounds__(256) void b16w_reduce_kernel(const float* __restric
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = fmaxf(o[e], 0.f);
       }
-      st4<bf16_t>(y + (int64_t)row * y_ld + col, o);
+      st4<TY>(y + (int64_t)row * y_ld + col, o);
     }
     v[k] = a;   // (statistics are taken before an activation never requested together with them; rows past M hold zeros)
   }
@@ -446,7 +448,7 @@ inline int launch_b16w(const IgemmParams& p, int S, float* scratch, hipStream_t 
   SG_LAUNCH_CHECK("conv_b16w_kernel");
   if (S > 1) {
     dim3 grid((unsigned)sg_cdiv(p.M, 128), (unsigned)sg_cdiv(p.Nout, 64));
-    hipLaunchKernelGGL(b16w_reduce_kernel, grid, dim3(256), 0, st, (const float*)scratch,
+    hipLaunchKernelGGL(b16w_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const float*)scratch,
                        (p.flags & SG_EPI_BIAS) ? p.bias : nullptr, reinterpret_cast<bf16_t*>(p.y), p.stats, p.M, p.Nout, p.y_ld, S,
                        (p.flags & SG_EPI_RELU) ? 1 : 0);
     SG_LAUNCH_CHECK("b16w_reduce_kernel");

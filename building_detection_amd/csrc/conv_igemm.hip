@@ -1136,6 +1136,7 @@ thread_local bool g_sub_batch = false;
 #include "conv_x6wp.h"
 #include "conv_pw.h"
 #include "conv_b16w.h"
+#include "conv_x6w.h"
 
 template <int NPL, typename TA>
 int dispatch_x6(const IgemmParams& p_in, int num_cus, hipStream_t st) {
@@ -1264,6 +1265,22 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
       hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, Ck,
                          Cin * Cout, 1, Cout, NPL, Ckp, p.kd);
     SG_LAUNCH_CHECK("split3_weights_kernel");
+  }
+  if constexpr (NPL == 3 && std::is_same<TA, float>::value) {
+    // the dilated long-K convolutions: the activation split once into bf16 planes, then 128 x 256 tiles with both operands by
+    // LDS-DMA (conv_x6w.h); planes of A and split-K partial slabs lie behind the weight planes
+    const int S = p.kd == XW_KD ? x6w_plan(p) : 0;
+    if (S > 0) {
+      const size_t planes_end = ((size_t)p.w_bytes + 255) & ~(size_t)255;
+      const size_t need = planes_end + x6w_scratch_bytes(p, S);
+      if (p.ws_room != SIZE_MAX && p.ws_room < need) {
+        sg_set_error("conv_x6w: workspace %zu < %zu (weight planes + activation planes + %d partial slabs)", p.ws_room, need, S);
+        return SG_EWORKSPACE;
+      }
+      IgemmParams q = p;
+      plan_common(q, true, 128, true, 4);
+      return launch_x6w(q, S, (char*)ws + planes_end, st);
+    }
   }
   if constexpr (NPL == 1 && !std::is_same<TA, float>::value) {
     static const bool deep = !(getenv("SG_B16_DEEP") && atoi(getenv("SG_B16_DEEP")) == 0);  // A/B switch
@@ -1894,7 +1911,24 @@ static size_t b16w_ws_extra(const sg_conv_desc* d, bool dgrad) {
     p.C = Ckp;
   }
   const int S = b16w_plan(p);
-  return S > 1 ? b16w_scratch_bytes(S, p.M, p.Nout) + 256 : 0;
+  size_t extra = S > 1 ? b16w_scratch_bytes(S, p.M, p.Nout) + 256 : 0;
+  // the fp32 planes-in kernel (conv_x6w.h): same geometry seen as fp32 storage
+  IgemmParams q;
+  if (!dgrad) fill_fwd_params(q, d, dummy, dummy, nullptr, nullptr, 0, 4);
+  else fill_dgrad_params(q, d, dummy, dummy, nullptr, nullptr, 0, 4);
+  q.x = (const float*)(uintptr_t)16;
+  q.res = nullptr;
+  if (q.C % BK != 0 && q.K != q.C) {
+    const int Ckp = x6_vpad_c(q.C);
+    q.K = (q.K / q.C) * Ckp;
+    q.C = Ckp;
+  }
+  const int S3 = x6w_plan(q);
+  if (S3 > 0) {
+    const size_t e3 = x6w_scratch_bytes(q, S3) + 256;
+    if (e3 > extra) extra = e3;
+  }
+  return extra;
 }
 
 size_t sg_conv2d_fwd_ws_bytes(const sg_conv_desc* d) {
@@ -2091,6 +2125,14 @@ int sg_conv2d_planes_job(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, in
   out->Npad = x6_npad(p.Nout);
   out->nblocks = (out->Kpad / 32) * (out->Npad / 32);
   *bytes = x6_planes_bytes(K, p.Nout, npl, out->kd);
+  if (!b16 && npl == 3 && out->kd == XW_KD) {   // conv_x6w.h: the activation's planes and split-K partial slabs behind the weight planes
+    IgemmParams q = p;
+    q.C = Ckp;
+    q.K = K;
+    q.res = nullptr;
+    const int S = x6w_plan(q);
+    if (S > 0) *bytes = ((*bytes + 255) & ~(size_t)255) + x6w_scratch_bytes(q, S);
+  }
   if (b16 && npl == 1 && out->kd == BW_KD) {   // a split-K launch of the 256-wide kernel keeps its partial slabs behind the planes
     IgemmParams q = p;
     q.C = Ckp;

@@ -464,6 +464,44 @@ def test_depthwise_dgrad_adds_a_collected_gradient(engine, pre_relu):
     assert not engine.dwconv_dgrad_acc_ok(engine.conv_desc((n, h, w, c), c, 3, 3, 2, 1, "same"))
 
 
+@pytest.mark.parametrize("case", [("aspp_fwd_two_shares", 2, 32, 32, 2048, 256, 6), ("aspp_like_d18_b3", 3, 32, 32, 1024, 256, 18),
+                                  ("whole_k_two_column_tiles", 1, 64, 64, 256, 512, 2)], ids=lambda c: c[0])
+def test_planes_in_x6_kernel(engine, case):
+    """conv_x6w.h (round 4): the dilated long-K fp32 convolutions with the activation split once into bf16 planes and both
+    operands by LDS-DMA.  Forward (two K shares for the ASPP shape: statistics from the reduction's registers; whole K for a
+    64 x 64 map: statistics from the accumulators), dgrad and the per-128-row-tile BatchNormalization statistics against
+    the fp64 oracle at the x6 kernels' tolerance; an image's result does not depend on its batch and repeats run to run, bit
+    for bit."""
+    name, N, H, W, Cin, Cout, dil = case
+    g = torch.Generator().manual_seed(Cin + Cout + dil)
+    x = rnd(g, N + 1, H, W, Cin)
+    w = rnd(g, 3, 3, Cin, Cout) * (1.0 / np.sqrt(9 * Cin))
+    b = rnd(g, Cout) * 0.1
+    xd, wd, bd = x.cuda(), w.cuda(), b.cuda()
+    d = engine.conv_desc(tuple(x.shape), Cout, 3, 3, 1, dil, "same")
+    y, st = engine.conv2d_fwd(xd, wd, bd, desc=d, want_stats=True)
+    assert st is not None
+    stats, tiles = st
+    assert tiles == (N + 1) * H * W // 128
+    xr = x.double().requires_grad_()
+    yr = T.conv2d(xr, w.double(), b.double(), 1, dil, "same")
+    close(y, yr.detach(), what=f"{name} fwd")
+    tr = yr.detach().reshape(tiles, 128, Cout)
+    sv = stats.view(tiles, 2, Cout).double().cpu()
+    assert float((sv[:, 0] - tr.sum(1)).abs().max()) <= 2e-5 * float(tr.abs().sum(1).max())
+    q_ref = ((tr - tr.mean(1, keepdim=True)) ** 2).sum(1)
+    assert float((sv[:, 1] - q_ref).abs().max()) <= 1e-4 * float(q_ref.max())
+    dy = rnd(g, *yr.shape)
+    yr.backward(dy.double())
+    dx = engine.conv2d_dgrad(dy.cuda(), wd, d)
+    close(dx, xr.grad, what=f"{name} dgrad")
+    y2, _ = engine.conv2d_fwd(xd, wd, bd, desc=d, want_stats=True)
+    assert torch.equal(y, y2) and torch.equal(dx, engine.conv2d_dgrad(dy.cuda(), wd, d))
+    d1 = engine.conv_desc((1, H, W, Cin), Cout, 3, 3, 1, dil, "same")
+    y1 = engine.conv2d_fwd(xd[N:N + 1].contiguous(), wd, bd, desc=d1)
+    assert torch.equal(y1[0], y[N]), "an image's result depends on its batch"
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("bn_relu,pre_relu,with_res,shape", [(True, False, False, (2, 12, 16, 728)), (False, True, True, (3, 8, 8, 128)),
                                                           (False, False, False, (2, 6, 20, 36)), (True, False, True, (1, 64, 32, 64))])
