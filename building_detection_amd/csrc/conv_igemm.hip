@@ -1279,6 +1279,10 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
       }
       IgemmParams q = p;
       plan_common(q, true, 128, true, 4);
+      {
+        static const int abl = getenv("SG_X6W_ABLATE") ? atoi(getenv("SG_X6W_ABLATE")) : 0;
+        q.ablate = abl;
+      }
       return launch_x6w(q, S, (char*)ws + planes_end, st);
     }
   }

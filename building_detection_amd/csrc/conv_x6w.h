@@ -25,7 +25,7 @@ constexpr int XW_M = 128, XW_N = 256, XW_KD = 32, XW_RB = 64;
 constexpr int XW_A = 3 * XW_M * XW_RB;                    // 24576
 constexpr int XW_B = 3 * XW_N * XW_RB;                    // 49152
 constexpr int XW_STAGE = XW_A + XW_B;                     // 73728
-constexpr int XW_LDS = 2 * XW_STAGE + 256;                // + tapinfo
+constexpr int XW_LDS = 2 * XW_STAGE;
 
 __device__ __forceinline__ int xw_swz(int row) { return (row >> 2) & 3; }   // 64-byte rows: B16L<2>::swz
 
@@ -49,13 +49,18 @@ __global__ __launch_bounds__(256) void x6w_split_kernel(const float* __restrict_
   }
 }
 
+// VAR (SG_X6W_VAR): 0 = wait + barrier at the END of a stage, DMA of the next stage at its top (the MFMA pipe idles from the last
+// MFMA of a stage through barrier, DMA issue and the first fragment reads of the next: the timing ablations of
+// LAB_NOTEBOOK.md 11.9 put that skeleton at 0.49 of the forward's 0.84 ms); 1 = the barrier in the MIDDLE of a stage - stage
+// s + 1 is published between the two k-steps of stage s, its first fragments are read under the MFMAs of k-step 1, the DMA of
+// stage s + 2 goes into the buffer just released: the pipe only waits for the barrier itself.
+template <int VAR>
 __global__ __launch_bounds__(512, 2) void conv_x6w_kernel(const IgemmParams p, const unsigned short* __restrict__ aq,
                                                           const uint32_t aq_bytes, const uint32_t a_plane_bytes, const int S,
                                                           float* __restrict__ part) {
   constexpr unsigned OOB = 0x80000000u;
   constexpr int WGN = 4, WM = 64, WN = 64, TM = 2, TN = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages] x { A [3][128][64 B], B [3][256][64 B] }; tapinfo [64]
-  int* tapinfo = reinterpret_cast<int*>(smem + 2 * XW_STAGE);
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages] x { A [3][128][64 B], B [3][256][64 B] }
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const uint32_t ntn = (p.Nout + XW_N - 1) / XW_N;
@@ -113,26 +118,25 @@ __global__ __launch_bounds__(512, 2) void conv_x6w_kernel(const IgemmParams p, c
   };
 
   // ---- the K walk (conv_b16w_kernel's): active taps, channel-block order, this share's range ------------------------------------
+  // The active taps are a 64-bit mask in SGPRs (x6w_plan: at most 64 taps), the position of the walk is (channel block, tap, slab
+  // in the block), advanced with scalar selects only: nothing in the stage loop branches, reads LDS or divides for the walk.
   const int ntaps = p.K / p.C;
   const int spt = p.C / XW_KD;
-  int nact = ntaps;
-  bool use_map = false;
-  if (p.skip_taps && ntaps > 1) {   // uniform
-    nact = 0;
+  uint64_t tapmask = ntaps >= 64 ? ~0ull : ((1ull << ntaps) - 1);
+  if (p.skip_taps) {   // uniform
+    tapmask = 0;
     for (int tap = 0; tap < ntaps; ++tap) {
       uint32_t kh, kw;
       fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
       int pix;
       const bool any = tap_valid((int)kh * p.k_mul, (int)kw * p.k_mul, pix);
-      if (__syncthreads_or(any ? 1 : 0)) {
-        if (t == 0) tapinfo[nact] = tap;
-        ++nact;
-      }
+      if (__syncthreads_or(any ? 1 : 0)) tapmask |= 1ull << tap;
     }
-    __syncthreads();
-    nact = __builtin_amdgcn_readfirstlane(nact);
-    use_map = true;
   }
+  // (a vote's result counts as divergent for the compiler: say it is uniform, or every LDS-DMA below becomes a waterfall loop)
+  tapmask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tapmask >> 32)) << 32) |
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tapmask);
+  const int nact = __builtin_popcountll(tapmask);
   const int nstage = nact * spt;
   int it_run = spt;
   if (p.cb > 0) {
@@ -141,40 +145,70 @@ __global__ __launch_bounds__(512, 2) void conv_x6w_kernel(const IgemmParams p, c
     if (spt % it_run != 0) it_run = spt;
   }
   const int per = it_run * nact;
-  const int st_begin = (int)(((int64_t)split * nstage) / S), st_end = (int)(((int64_t)(split + 1) * nstage) / S);
-  const int nk = st_end - st_begin;
-  auto k0_of = [&](int L) -> int {
-    if (ntaps <= 1) return L * XW_KD;
-    const int cbk = L / per, rem = L - cbk * per;
-    const int ti = rem / it_run, ci = rem - ti * it_run;
-    const int tap = use_map ? __builtin_amdgcn_readfirstlane(tapinfo[ti]) : ti;
-    return tap * p.C + (cbk * it_run + ci) * XW_KD;
+  const int st_begin = __builtin_amdgcn_readfirstlane((int)(((int64_t)split * nstage) / S));
+  const int st_end = __builtin_amdgcn_readfirstlane((int)(((int64_t)(split + 1) * nstage) / S));
+  const int nk = nact > 0 ? st_end - st_begin : 0;
+  auto tap_after = [&](int tap, bool& wrapped) -> int {   // the next active tap behind `tap` (cyclic)
+    const uint64_t above = tap >= 63 ? 0ull : (tapmask & ~((2ull << tap) - 1));
+    wrapped = above == 0;
+    return __builtin_ctzll(wrapped ? tapmask : above);
   };
-
-  int cur_tap = -1;
-  unsigned a_voff = OOB;
-  auto issue = [&](int L, int stage) {
-    const int k0 = k0_of(L);
-    const int tap = (int)fd_div((uint32_t)k0, p.fd_c);
-    if (tap != cur_tap) {   // uniform
-      cur_tap = tap;
-      uint32_t kh, kw;
-      fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
-      int pix;
-      const bool ok = tap_valid((int)kh * p.k_mul, (int)kw * p.k_mul, pix);
-      a_voff = ok ? (unsigned)pix * (unsigned)p.C * 2u + (unsigned)a_chunk : OOB;   // planes are dense: pixel pitch = C
+  int it_cb = 0, it_tap = 0, it_ci = 0;
+  if (nk > 0) {
+    it_cb = st_begin / per;
+    const int rem = st_begin - it_cb * per;
+    const int ti = rem / it_run;
+    it_ci = rem - ti * it_run;
+    it_tap = __builtin_ctzll(tapmask);
+    for (int i = 0; i < ti; ++i) {
+      bool w;
+      it_tap = tap_after(it_tap, w);
     }
-    const int soff_a = (k0 - tap * p.C) * 2;
-    const int soff_b = (k0 >> 5) * p.Npad * XW_RB;
+    it_cb = __builtin_amdgcn_readfirstlane(it_cb);
+    it_tap = __builtin_amdgcn_readfirstlane(it_tap);
+    it_ci = __builtin_amdgcn_readfirstlane(it_ci);
+  }
+
+  // the DMA of the NEXT stage of the walk into LDS buffer `stage`; !live: a stage behind the share's end (every piece out of range:
+  // zeros into a buffer nobody reads again - cheaper than a branch that would cut the loop body into scheduling regions)
+  auto issue = [&](bool first, int stage, bool live) {
+    const int tap = it_tap, slab = it_cb * it_run + it_ci;
+    {   // advance
+      const bool run_end = it_ci + 1 == it_run;
+      bool wrapped;
+      const int nt = tap_after(it_tap, wrapped);
+      it_ci = run_end ? 0 : it_ci + 1;
+      it_tap = run_end ? nt : it_tap;
+      it_cb = (run_end && wrapped) ? it_cb + 1 : it_cb;
+    }
+    uint32_t kh, kw;
+    fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+    int pix;
+    const bool ok = tap_valid((int)kh * p.k_mul, (int)kw * p.k_mul, pix);
+    const unsigned a_voff = (ok && live) ? (unsigned)pix * (unsigned)p.C * 2u + (unsigned)a_chunk : OOB;   // dense planes: pitch C
+    const int soff_a = slab * (XW_KD * 2);
+    const int soff_b = (tap * spt + slab) * p.Npad * XW_RB;
     char* sa = smem + stage * XW_STAGE;
     char* sb = sa + XW_A;
+    // experiment build only (-DSG_X6W_ABL; timing diagnostics, results wrong; SG_X6W_ABLATE): 1 = no A DMA behind the first stage,
+    // 2 = no B DMA behind the first stage, 4 = no MFMAs (the fragment reads stay).  A run-time flag here would put a branch in front
+    // of every MFMA of the product build.
+#ifdef SG_X6W_ABL
+    const int abl = p.ablate;
+#else
+    constexpr int abl = 0;
+#endif
+    if (!((abl & 1) && !first)) {
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-      pw_lds_dma16(rsrc_a, sa + pl * (XW_M * XW_RB) + wave * 1024, a_voff, soff_a + pl * (int)a_plane_bytes);
+      for (int pl = 0; pl < 3; ++pl)
+        pw_lds_dma16(rsrc_a, sa + pl * (XW_M * XW_RB) + wave * 1024, a_voff, soff_a + pl * (int)a_plane_bytes);
+    }
+    if (!((abl & 2) && !first)) {
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      const int idx = wave + 8 * j;
-      pw_lds_dma16(rsrc_w, sb + (idx >> 4) * (XW_N * XW_RB) + (idx & 15) * 1024, b_voff[j], soff_b);
+      for (int j = 0; j < 6; ++j) {
+        const int idx = wave + 8 * j;
+        pw_lds_dma16(rsrc_w, sb + (idx >> 4) * (XW_N * XW_RB) + (idx & 15) * 1024, live ? b_voff[j] : OOB, soff_b);
+      }
     }
   };
 
@@ -191,52 +225,98 @@ __global__ __launch_bounds__(512, 2) void conv_x6w_kernel(const IgemmParams p, c
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int sw = xw_swz(lr);
   const int a_lane = (wm + lr) * XW_RB, b_lane = XW_A + (wn + lr) * XW_RB;
-  auto compute = [&](int stage) {
+  auto frags = [&](int stage, int ks, bf16x8_t (&a)[TM][3], bf16x8_t (&b)[TN][3]) {
     const char* sbuf = smem + stage * XW_STAGE;
-    bf16x8_t af[2][TM][3], bf[2][TN][3];
-    auto frags = [&](int ks, bf16x8_t (&a)[TM][3], bf16x8_t (&b)[TN][3]) {
-      const int ko = ((2 * ks + lh) ^ sw) << 4;
+    const int ko = ((2 * ks + lh) ^ sw) << 4;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          a[i][pl] = *reinterpret_cast<const bf16x8_t*>(sbuf + a_lane + pl * (XW_M * XW_RB) + 32 * i * XW_RB + ko);
+      for (int pl = 0; pl < 3; ++pl)
+        a[i][pl] = *reinterpret_cast<const bf16x8_t*>(sbuf + a_lane + pl * (XW_M * XW_RB) + 32 * i * XW_RB + ko);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          b[j][pl] = *reinterpret_cast<const bf16x8_t*>(sbuf + b_lane + pl * (XW_N * XW_RB) + 32 * j * XW_RB + ko);
-    };
-    frags(0, af[0], bf[0]);
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      if (ks == 0) frags(1, af[1], bf[1]);   // one k-step of look-ahead
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first (conv_x6_kernel's order)
-#pragma unroll
-          for (int u = 0; u < 6; ++u)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][i][PA_[u]], bf[ks][j][PB_[u]], acc[i][j], 0, 0, 0);
-        }
-    }
+      for (int pl = 0; pl < 3; ++pl)
+        b[j][pl] = *reinterpret_cast<const bf16x8_t*>(sbuf + b_lane + pl * (XW_N * XW_RB) + 32 * j * XW_RB + ko);
   };
+  auto mfmas = [&](const bf16x8_t (&a)[TM][3], const bf16x8_t (&b)[TN][3]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first (conv_x6_kernel's order)
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+#ifdef SG_X6W_ABL
+          if (p.ablate & 4) {
+            asm volatile("" ::"v"(a[i][PA_[u]]), "v"(b[j][PB_[u]]));
+            continue;
+          }
+#endif
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA_[u]], b[j][PB_[u]], acc[i][j], 0, 0, 0);
+        }
+      }
+  };
+  bf16x8_t af0[TM][3], bf0[TN][3], af1[TM][3], bf1[TN][3];
 
   if (nk > 0) {
-    issue(st_begin, 0);
+    issue(true, 0, true);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int s = 0; s < nk; ++s) {
-      const int cur = s & 1;
-      if (s + 1 < nk) {   // stage cur ^ 1 was last read before the previous barrier
-        issue(st_begin + s + 1, cur ^ 1);
+    if constexpr (VAR == 0) {
+      for (int s = 0; s < nk; ++s) {
+        const int cur = s & 1;
+        if (s + 1 < nk) {   // stage cur ^ 1 was last read before the previous barrier
+          issue(false, cur ^ 1, true);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        frags(cur, 0, af0, bf0);
+        frags(cur, 1, af1, bf1);   // one k-step of look-ahead
+        mfmas(af0, bf0);
+        mfmas(af1, bf1);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    } else {
+      // One basic block per stage, woven by hand (sched_group_barrier: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read):
+      //   A: the 24 MFMAs of k-step 0 with the 12 fragment reads of k-step 1 between them;
+      //   wait + barrier: stage s + 1 (its DMA went out one whole stage ago) is published, stage s is free;
+      //   B: the 24 MFMAs of k-step 1 with the 12 fragment reads of k-step 0 of stage s + 1 and the 9 DMA pieces of stage s + 2
+      //      (into the buffer of stage s) between them.
+      issue(false, 1, nk > 1);
+      frags(0, 0, af0, bf0);
+      for (int s = 0; s < nk; ++s) {
+        const int cur = s & 1;
+        __builtin_amdgcn_sched_barrier(0);
+        frags(cur, 1, af1, bf1);
+        mfmas(af0, bf0);
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        frags(cur ^ 1, 0, af0, bf0);   // (behind the last stage: stale bytes nobody uses)
+        issue(false, cur, s + 2 < nk);   // (program order = the order the scheduler keeps between LDS reads and LDS-DMA writes)
+        mfmas(af1, bf1);
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {   // the reads first: the next stage's first MFMA waits for the last of them
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 9; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
-      compute(cur);
-      __builtin_amdgcn_sched_barrier(0);
-      asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last (all out of range) DMA still writes zeros into LDS
     }
   }
 
@@ -315,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void conv_x6w_kernel(const IgemmParams p, c
 inline int x6w_plan(const IgemmParams& p) {
   static const int on = getenv("SG_X6_WIDE") ? atoi(getenv("SG_X6_WIDE")) : 1;
   if (!on) return 0;
-  if (p.div != 1 || p.perm2 || p.res || p.C % XW_KD != 0 || p.K == p.C || p.K < 2048) return 0;
+  if (p.div != 1 || p.perm2 || p.res || p.C % XW_KD != 0 || p.K == p.C || p.K < 2048 || p.K / p.C > 64) return 0;
   if (!(p.k_mul > 1 || p.k_mul < -1)) return 0;   // dilated taps only: there the im2col kernel re-stages A most often
   if (p.x_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0 || p.x_bytes == 0 || p.Nout % 4 != 0) return 0;
   const int64_t ntn = sg_cdiv(p.Nout, XW_N);
@@ -341,7 +421,8 @@ inline size_t x6w_scratch_bytes(const IgemmParams& p, int S) {
 inline int launch_x6w(const IgemmParams& p, int S, char* scratch, hipStream_t st) {
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(conv_x6w_kernel, (size_t)XW_LDS);
+    int rc = set_dyn_lds(conv_x6w_kernel<0>, (size_t)XW_LDS);
+    if (!rc) rc = set_dyn_lds(conv_x6w_kernel<1>, (size_t)XW_LDS);
     if (rc) return rc;
     attr_done = true;
   }
@@ -361,8 +442,13 @@ inline int launch_x6w(const IgemmParams& p, int S, char* scratch, hipStream_t st
     SG_LAUNCH_CHECK("x6w_split_kernel");
   }
   float* part = S > 1 ? reinterpret_cast<float*>(scratch + a_bytes) : nullptr;
-  hipLaunchKernelGGL(conv_x6w_kernel, dim3((unsigned)(tiles * S)), dim3(512), (size_t)XW_LDS, st, p, (const unsigned short*)scratch,
-                     (uint32_t)(3 * plane), (uint32_t)plane, S, part);
+  static const int var = getenv("SG_X6W_VAR") ? atoi(getenv("SG_X6W_VAR")) : 1;
+  if (var == 1)
+    hipLaunchKernelGGL(conv_x6w_kernel<1>, dim3((unsigned)(tiles * S)), dim3(512), (size_t)XW_LDS, st, p, (const unsigned short*)scratch,
+                       (uint32_t)(3 * plane), (uint32_t)plane, S, part);
+  else
+    hipLaunchKernelGGL(conv_x6w_kernel<0>, dim3((unsigned)(tiles * S)), dim3(512), (size_t)XW_LDS, st, p, (const unsigned short*)scratch,
+                       (uint32_t)(3 * plane), (uint32_t)plane, S, part);
   SG_LAUNCH_CHECK("conv_x6w_kernel");
   if (S > 1) {
     dim3 grid((unsigned)sg_cdiv(p.M, 128), (unsigned)sg_cdiv(p.Nout, 64));
