@@ -391,7 +391,7 @@ def main():
         # shapes only, not on the run.
         exec_ratio, exec_note = None, "no PMC pass for this configuration"
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        pj = next((q for q in (os.path.join(pdir, n) for n in ("r03_pmc_mfma.json", "r01_pmc_mfma.json")) if os.path.exists(q)),
+        pj = next((q for q in (os.path.join(pdir, n) for n in ("r04_pmc_mfma.json", "r03_pmc_mfma.json", "r01_pmc_mfma.json")) if os.path.exists(q)),
                   os.path.join(pdir, "r01_pmc_mfma.json"))
         if args.batch == 16 and args.size == 512 and x6 and os.path.exists(pj):
             with open(pj) as f:
@@ -401,7 +401,7 @@ def main():
                         + k["x6_wgrad"]["bf16_mfma_flops"] * 6 / k["x6_wgrad"]["launches"]) / 6.0  # fp32-equivalent
             exec_ratio = executed / (dil_tflop * 1e12)
             exec_note = ("NOT measured in this run: a committed constant from a separate counter pass (SQ_INSTS_VALU_MFMA_MOPS_BF16 x "
-                         "512, profiles/%s; it depends on the layer shapes only - round 1 and round 3 count the same operations) "
+                         "512, profiles/%s; it depends on the layer shapes only - rounds 1, 3 and 4 count the same operations) "
                          "/ 6 / nominal FLOPs: padding taps of the dilated convs are skipped, not multiplied" % os.path.basename(pj))
         out = {
             "metric": f"{args.size}x{args.size} tiles/sec fwd+bwd {LABEL.get(args.model, args.model)} (full train step: fwd+loss+bwd+Adam)",
@@ -432,15 +432,16 @@ def main():
                          "frac_executed": None if (achieved is None or exec_ratio is None) else round(achieved * exec_ratio / peak, 4),
                          "frac_executed_note": exec_note,
                          "traffic": traffic, "traffic_note": traffic_note,
-                         "kernel": (("conv_x6_kernel<NPL=1,bf16> / wgrad_x6_kernel<NPL=1,bf16>" if b16 else "conv_x6_kernel / wgrad_x6_kernel") if x6
+                         "kernel": (("conv_b16w_kernel / conv_b16_kernel / wgrad_x6_kernel<NPL=1,bf16>" if b16
+                                     else "conv_x6w_kernel (ASPP forward + dgrad, activation planes by x6w_split_kernel) / conv_x6_kernel / wgrad_x6_kernel") if x6
                                     else "igemm_conv_kernel / igemm_wgrad_kernel") + " on the 6 dilated 3x3 convs (fwd+dgrad+wgrad)",
                          "ms_per_step": round(dil_ms, 3), "launches_per_step": prof.get("dilated_conv_launches", 0) // max(args.steps, 1)},
         }
         fam_ms = fam.get("gemm_conv", 0.0) / 2
         if fam_ms > 0:  # every convolution / pointwise / transposed-convolution GEMM launch of the step, same peak
             out["roofline"]["family"] = {
-                "kernel": "all GEMM convolution launches of the step (conv_x6 / conv_x6p / wgrad_x6 / thin kernels + their weight-split "
-                          "and split-K reduce helpers), measured in 2 extra steps after the timed region",
+                "kernel": "all GEMM convolution launches of the step (pw_wide / conv_x6 / conv_x6w / conv_x6p / wgrad_x6 / wgrad_pw_wide / "
+                          "thin kernels + their plane-split and split-K reduce helpers), measured in 2 extra steps after the timed region",
                 "achieved": round(step_tflop / (fam_ms / 1e3), 2), "frac": round(step_tflop / (fam_ms / 1e3) / peak, 4),
                 "ms_per_step": round(fam_ms, 3), "launches_per_step": fam.get("gemm_conv_launches", 0) // 2}
         if world == 1 and not args.no_cpu_baseline:

@@ -25,7 +25,7 @@
 constexpr int BW_M = 256, BW_N = 256, BW_KD = 64, BW_RB = 128;
 constexpr int BW_STAGE = (BW_M + BW_N) * BW_RB;           // 65536
 constexpr int BW_TP = BW_N * 2 + 16;                      // LDS pitch of the staged bf16 output tile
-constexpr int BW_LDS = (2 * BW_STAGE > BW_M * BW_TP ? 2 * BW_STAGE : BW_M * BW_TP) + 256;
+constexpr int BW_LDS = (2 * BW_STAGE > BW_M * BW_TP ? 2 * BW_STAGE : BW_M * BW_TP);
 
 __device__ __forceinline__ int bw_swz(int row) { return (row >> 1) & 7; }   // B16L<4>::swz
 
@@ -36,8 +36,7 @@ template <int VAR>
 __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, const int S, float* __restrict__ part) {
   constexpr unsigned OOB = 0x80000000u;
   constexpr int WGN = 4, WM = 128, WN = 64, TM = 4, TN = 2;
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages] x { A [256][128 B], B [256][128 B] } | staged tile; tapinfo
-  int* tapinfo = reinterpret_cast<int*>(smem + BW_LDS - 256);    // [64]
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages] x { A [256][128 B], B [256][128 B] } | staged tile
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const uint32_t ntn = (p.Nout + BW_N - 1) / BW_N;
@@ -82,12 +81,13 @@ __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, 
   };
 
   // ---- the K walk of this tile: active taps (padding-tap elimination), channel-block order, this share's range -----------------
+  // As in conv_x6w_kernel: the active taps are a 64-bit mask in SGPRs (b16w_plan: at most 64 taps), the position of the walk is
+  // (channel block, tap, slab in the block) and advances with scalar selects - no LDS table, no division, no branch per stage.
   const int ntaps = p.K / p.C;
   const int spt = p.C / BW_KD;          // stages per tap
-  int nact = ntaps;
-  bool use_map = false;
+  uint64_t tapmask = ntaps >= 64 ? ~0ull : ((1ull << ntaps) - 1);
   if (p.skip_taps && ntaps > 1) {   // uniform
-    nact = 0;
+    tapmask = 0;
     for (int tap = 0; tap < ntaps; ++tap) {
       uint32_t kh, kw;
       fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
@@ -98,15 +98,13 @@ __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, 
         int pix;
         any = any || tap_valid(i, dh, dw, pix);
       }
-      if (__syncthreads_or(any ? 1 : 0)) {
-        if (t == 0) tapinfo[nact] = tap;
-        ++nact;
-      }
+      if (__syncthreads_or(any ? 1 : 0)) tapmask |= 1ull << tap;
     }
-    __syncthreads();
-    nact = __builtin_amdgcn_readfirstlane(nact);
-    use_map = true;
   }
+  // (a vote's result counts as divergent for the compiler: say it is uniform)
+  tapmask = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(tapmask >> 32)) << 32) |
+            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tapmask);
+  const int nact = __builtin_popcountll(tapmask);
   const int nstage = nact * spt;
   int it_run = spt;
   if (p.cb > 0) {
@@ -115,44 +113,61 @@ __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, 
     if (spt % it_run != 0) it_run = spt;
   }
   const int per = it_run * nact;
-  const int st_begin = (int)(((int64_t)split * nstage) / S), st_end = (int)(((int64_t)(split + 1) * nstage) / S);
-  const int nk = st_end - st_begin;
-  auto k0_of = [&](int L) -> int {   // stage index of the tile's walk -> first reduction index (uniform arithmetic)
-    if (ntaps <= 1) return L * BW_KD;
-    const int cbk = L / per, rem = L - cbk * per;
-    const int ti = rem / it_run, ci = rem - ti * it_run;
-    const int tap = use_map ? __builtin_amdgcn_readfirstlane(tapinfo[ti]) : ti;
-    return tap * p.C + (cbk * it_run + ci) * BW_KD;
+  const int st_begin = __builtin_amdgcn_readfirstlane((int)(((int64_t)split * nstage) / S));
+  const int st_end = __builtin_amdgcn_readfirstlane((int)(((int64_t)(split + 1) * nstage) / S));
+  const int nk = nact > 0 ? st_end - st_begin : 0;
+  auto tap_after = [&](int tap, bool& wrapped) -> int {   // the next active tap behind `tap` (cyclic)
+    const uint64_t above = tap >= 63 ? 0ull : (tapmask & ~((2ull << tap) - 1));
+    wrapped = above == 0;
+    return __builtin_ctzll(wrapped ? tapmask : above);
   };
+  int it_cb = 0, it_tap = 0, it_ci = 0;
+  if (nk > 0) {
+    it_cb = st_begin / per;
+    const int rem = st_begin - it_cb * per;
+    const int ti = rem / it_run;
+    it_ci = rem - ti * it_run;
+    it_tap = __builtin_ctzll(tapmask);
+    for (int i = 0; i < ti; ++i) {
+      bool w;
+      it_tap = tap_after(it_tap, w);
+    }
+    it_cb = __builtin_amdgcn_readfirstlane(it_cb);
+    it_tap = __builtin_amdgcn_readfirstlane(it_tap);
+    it_ci = __builtin_amdgcn_readfirstlane(it_ci);
+  }
 
-  int cur_tap = -1;
   unsigned a_voff[4] = {OOB, OOB, OOB, OOB};
   int soff_a = 0, soff_b = 0;
-  auto prepare = [&](int L) {   // scalar / per-tap work of a stage's DMA: offsets of the stage, the lane's row offsets on a tap change
-    const int k0 = k0_of(L);
-    const int tap = (int)fd_div((uint32_t)k0, p.fd_c);
-    if (tap != cur_tap) {   // uniform
-      cur_tap = tap;
-      uint32_t kh, kw;
-      fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
-      const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        int pix;
-        const bool ok = tap_valid(i, dh, dw, pix);
-        a_voff[i] = ok ? (unsigned)pix * (unsigned)p.x_ld * 2u + (unsigned)a_chunk[i] : OOB;
-      }
+  auto prepare = [&]() {   // scalar / per-lane work of the NEXT stage's DMA: offsets of the stage, the lane's row offsets under its tap
+    const int tap = it_tap, slab = it_cb * it_run + it_ci;
+    {   // advance
+      const bool run_end = it_ci + 1 == it_run;
+      bool wrapped;
+      const int nt = tap_after(it_tap, wrapped);
+      it_ci = run_end ? 0 : it_ci + 1;
+      it_tap = run_end ? nt : it_tap;
+      it_cb = (run_end && wrapped) ? it_cb + 1 : it_cb;
     }
-    soff_a = (k0 - tap * p.C) * 2;
-    soff_b = (k0 / BW_KD) * p.Npad * BW_KD * 2;
+    uint32_t kh, kw;
+    fd_divmod((uint32_t)tap, p.fd_kw, kh, kw);
+    const int dh = (int)kh * p.k_mul, dw = (int)kw * p.k_mul;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int pix;
+      const bool ok = tap_valid(i, dh, dw, pix);
+      a_voff[i] = ok ? (unsigned)pix * (unsigned)p.x_ld * 2u + (unsigned)a_chunk[i] : OOB;
+    }
+    soff_a = slab * (BW_KD * 2);
+    soff_b = (tap * spt + slab) * p.Npad * BW_KD * 2;
   };
   auto dma_piece = [&](int i, int stage) {   // piece i of A and of B (1 KB each)
     char* sa = smem + stage * BW_STAGE;
     pw_lds_dma16(rsrc_x, sa + (wave + 8 * i) * 1024, a_voff[i], soff_a);
     pw_lds_dma16(rsrc_w, sa + BW_M * BW_RB + (wave + 8 * i) * 1024, b_voff[i], soff_b);
   };
-  auto issue = [&](int L, int stage) {
-    prepare(L);
+  auto issue = [&](int stage) {
+    prepare();
 #pragma unroll
     for (int i = 0; i < 4; ++i) dma_piece(i, stage);
   };
@@ -200,15 +215,15 @@ __global__ __launch_bounds__(512, 2) void conv_b16w_kernel(const IgemmParams p, 
   };
 
   if (nk > 0) {
-    issue(st_begin, 0);
+    issue(0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     for (int s = 0; s < nk; ++s) {
       const int cur = s & 1;
       const bool more = s + 1 < nk;
       if (more) {   // stage cur ^ 1 was last read before the previous barrier
-        if constexpr (VAR == 1) prepare(st_begin + s + 1);
-        else issue(st_begin + s + 1, cur ^ 1);
+        if constexpr (VAR == 1) prepare();
+        else issue(cur ^ 1);
         __builtin_amdgcn_sched_barrier(0);
       }
       compute(cur, cur ^ 1, more);
@@ -408,7 +423,7 @@ __global__ __launch_bounds__(256) void b16w_reduce_kernel(const float* __restric
 inline int b16w_plan(const IgemmParams& p) {
   static const int on = getenv("SG_B16_WIDE") ? atoi(getenv("SG_B16_WIDE")) : 1;
   if (!on) return 0;
-  if (p.div != 1 || p.perm2 || p.res || p.C % BW_KD != 0 || p.K < 1024) return 0;
+  if (p.div != 1 || p.perm2 || p.res || p.C % BW_KD != 0 || p.K < 1024 || p.K / p.C > 64) return 0;
   if ((p.x_ld % 8) != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0 || p.x_bytes == 0) return 0;
   if (p.Nout % 4 != 0) return 0;
   const int64_t ntn = sg_cdiv(p.Nout, BW_N);

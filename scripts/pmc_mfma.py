@@ -20,7 +20,7 @@ for sub in ("pmc_mfma", "pmc_lds"):
     seen = set()
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"]
-        fam = ("x6_fwd_dgrad" if "conv_x6_kernel" in k else "x6_wgrad" if "wgrad_x6_kernel" in k
+        fam = ("x6_fwd_dgrad" if ("conv_x6_kernel" in k or "conv_x6w_kernel" in k) else "x6_wgrad" if "wgrad_x6_kernel" in k
                else "x6_patch" if "conv_x6p_kernel" in k else None)
         if fam is None:
             continue

@@ -28,7 +28,8 @@ for kind, mul in (("fetch", 2 * 1024), ("write", 1024)):
     helpers = split = 0.0
     for r in rows:
         k, v = r["Kernel_Name"], float(r["Counter_Value"]) * mul
-        if "igemm_conv_kernel" in k or "conv_x6_kernel" in k or "conv_b16_kernel" in k or "conv_b16w_kernel" in k:  # per case: 3 forward launches (1 + warm-up + 1 timed), then 2 dgrad
+        if ("igemm_conv_kernel" in k or "conv_x6_kernel" in k or "conv_x6w_kernel" in k or "conv_b16_kernel" in k
+                or "conv_b16w_kernel" in k):  # per case: 3 forward launches (1 + warm-up + 1 timed), then 2 dgrad
             per["fwd" if ci % 5 < 3 else "dgrad"].setdefault(ci // 5, []).append(v)
             ci += 1
         elif "igemm_wgrad_kernel" in k or "wgrad_x6_kernel" in k:
@@ -37,7 +38,7 @@ for kind, mul in (("fetch", 2 * 1024), ("write", 1024)):
         elif PREPARED and "split3_weights" in k:
             split += v
         elif "copyBuffer" not in k:
-            helpers += v  # kernel transpose, split reduce, bias column sum: each runs twice
+            helpers += v  # kernel transpose, split reduce, bias column sum, round 4: x6w_split (activation planes): each runs twice
     o = {t: [sum(x) / len(x) for _, x in sorted(per[t].items())] for t in per}
     o["helpers_per_step"] = helpers / 2
     if PREPARED:
