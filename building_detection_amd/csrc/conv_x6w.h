@@ -389,14 +389,15 @@ __global__ __launch_bounds__(512, 2) void conv_x6w_kernel(const IgemmParams p, c
   }
 }
 
-// Which fp32 launches take it, and in how many K shares (0: none): the dilated (tap-skipping) multi-tap convolutions with
-// >= 192 output columns and a long reduction - the ASPP forward (two shares) and dgrad (whole) - from ONE image's geometry.
-// SG_X6_WIDE=0 switches it off.
+// Which fp32 launches take it, and in how many K shares (0: none): the multi-tap convolutions with a long reduction (K >= 2048)
+// and >= 192 output columns - the ASPP forward (two shares) and dgrad (whole), the 3x3 convolutions of the decoder at 256 / 512
+// channels - from ONE image's geometry.  SG_X6_WIDE: 0 off, 1 the dilated ones only (round 4's first form), 2 (default) all of them
+// (step -0.26 ms on alternating runs, profiles/r04_ab_runs.txt block r4t).
 inline int x6w_plan(const IgemmParams& p) {
-  static const int on = getenv("SG_X6_WIDE") ? atoi(getenv("SG_X6_WIDE")) : 1;
+  static const int on = getenv("SG_X6_WIDE") ? atoi(getenv("SG_X6_WIDE")) : 2;
   if (!on) return 0;
   if (p.div != 1 || p.perm2 || p.res || p.C % XW_KD != 0 || p.K == p.C || p.K < 2048 || p.K / p.C > 64) return 0;
-  if (!(p.k_mul > 1 || p.k_mul < -1)) return 0;   // dilated taps only: there the im2col kernel re-stages A most often
+  if (on < 2 && !(p.k_mul > 1 || p.k_mul < -1)) return 0;   // 1: dilated taps only
   if (p.x_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0 || p.x_bytes == 0 || p.Nout % 4 != 0) return 0;
   const int64_t ntn = sg_cdiv(p.Nout, XW_N);
   if ((double)p.Nout / (double)(ntn * XW_N) < 0.75) return 0;
