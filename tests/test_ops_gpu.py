@@ -465,10 +465,11 @@ def test_depthwise_dgrad_adds_a_collected_gradient(engine, pre_relu):
 
 
 @pytest.mark.parametrize("case", [("aspp_fwd_two_shares", 2, 32, 32, 2048, 256, 6), ("aspp_like_d18_b3", 3, 32, 32, 1024, 256, 18),
-                                  ("whole_k_two_column_tiles", 1, 64, 64, 256, 512, 2)], ids=lambda c: c[0])
+                                  ("whole_k_two_column_tiles", 1, 64, 64, 256, 512, 2), ("plain_3x3_decoder_256", 1, 64, 64, 256, 256, 1),
+                                  ("plain_3x3_512_two_shares_odd_stage_count", 2, 32, 32, 480, 192, 1)], ids=lambda c: c[0])
 def test_planes_in_x6_kernel(engine, case):
-    """conv_x6w.h (round 4): the dilated long-K fp32 convolutions with the activation split once into bf16 planes and both
-    operands by LDS-DMA.  Forward (two K shares for the ASPP shape: statistics from the reduction's registers; whole K for a
+    """conv_x6w.h (round 4): the long-K multi-tap fp32 convolutions (dilated or not: SG_X6_WIDE=2) with the activation split once
+    into bf16 planes and both operands by LDS-DMA.  Forward (two K shares for the ASPP shape: statistics from the reduction's registers; whole K for a
     64 x 64 map: statistics from the accumulators), dgrad and the per-128-row-tile BatchNormalization statistics against
     the fp64 oracle at the x6 kernels' tolerance; an image's result does not depend on its batch and repeats run to run, bit
     for bit."""
