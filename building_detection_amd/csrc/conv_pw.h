@@ -275,6 +275,99 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
     __builtin_amdgcn_s_barrier();
   };
 
+  // ---- x6, second form (p.stagger = SG_PW_VAR = 1, default): the barrier in the MIDDLE of the k-step (conv_x6w_kernel's finding:
+  // with the barrier at the end, every wave opens the next k-step by waiting for its 15 fragment reads - with all eight waves in
+  // step the matrix pipe idles for an LDS round trip per k-step).  A k-step's 36 MFMAs are two halves of 18 (row sub-tile 0, 1):
+  //   first half   MFMAs on af[0] x bf[0..2]; bf[0] and af[0] were PREFETCHED in the previous k-step, the other nine fragments are
+  //                read here, woven behind the first MFMAs (stage s is still whole);
+  //   middle       wait: B(s+1)'s DMA (issued a whole k-step ago) and this thread's A(s+1) stores; barrier: stage s+1 is published,
+  //                every wave holds all fragments of stage s in registers - its buffer is free;
+  //   second half  MFMAs on af[1] x bf[0..2] with, woven: split + stores of A(s+2) and the DMA of B(s+2) into the buffer of stage
+  //                s, the fp32 load of A(s+3), the six prefetch reads (af[0], bf[0]) of stage s+1.
+  // Same products in the same order as step3: the results are bit-identical (tests/test_ops_gpu.py).
+  // MODE 3: everything; 2: no fp32 load (s + 3 >= nk); 1: prefetch only (s + 2 >= nk); 0: the last k-step.
+  auto step3m = [&](int s, auto MODE_, bf16x8_t (&ca0)[3], bf16x8_t (&cb0)[3], bf16x8_t (&na0)[3], bf16x8_t (&nb0)[3]) {
+    constexpr int MODE = decltype(MODE_)::value;
+    const int cur = s & 1, nxt = cur ^ 1;
+    const char* sb = smem + cur * G::STAGE;
+    const char* sn = smem + nxt * G::STAGE;
+    const int ko = (lh ^ sw) << 4;
+    bf16x8_t a1[3], b1[3], b2[3];
+    unsigned hh[2], mm[2], ll[2];
+    char* adst = smem + cur * G::STAGE + a_row * RB + (((a_kq >> 1) ^ G::swz(a_row)) << 4) + (a_kq & 1) * 8;   // stage s+2 -> buffer of s
+    char* bbase = smem + cur * G::STAGE + NPL * G::A_PLANE;
+    auto rest = [&](int w) {   // first half: the nine fragments not prefetched, in the order the MFMAs want them
+      if (w < 3) b1[w] = *reinterpret_cast<const bf16x8_t*>(sb + b_lane + w * G::B_PLANE + 32 * 1 * RB + ko);
+      else if (w < 6) b2[w - 3] = *reinterpret_cast<const bf16x8_t*>(sb + b_lane + (w - 3) * G::B_PLANE + 32 * 2 * RB + ko);
+      else if (w < 9) a1[w - 6] = *reinterpret_cast<const bf16x8_t*>(sb + a_lane + (w - 6) * G::A_PLANE + 32 * RB + ko);
+    };
+    // second half, in this order: the DMA pieces of B(s+2) (longest flight), the six prefetch reads of stage s+1 (the next k-step
+    // opens with them), split + stores of A(s+2), the fp32 load of A(s+3)
+    auto piece = [&](int w) {
+      if (w < NBW) {
+        if (MODE >= 2) {
+          const int i = w, g = wave + 8 * i;
+          if (i < NBW - 1 || NBP % 8 == 0 || g < NBP) {   // only the last round of pieces is ragged (36 pieces, 8 waves)
+            const int pl = g / PPP, rb = g - pl * PPP;
+            pw_lds_dma16(rsrc_w, bbase + pl * G::B_PLANE + rb * 1024, b_voff[i], (s + 2) * b_step);
+          }
+        }
+      } else if (w < NBW + 3) {
+        if (MODE >= 1) na0[w - NBW] = *reinterpret_cast<const bf16x8_t*>(sn + a_lane + (w - NBW) * G::A_PLANE + ko);
+      } else if (w < NBW + 6) {
+        if (MODE >= 1) nb0[w - NBW - 3] = *reinterpret_cast<const bf16x8_t*>(sn + b_lane + (w - NBW - 3) * G::B_PLANE + ko);
+      } else if (MODE >= 2) {
+        const int v = w - (NBW + 6);
+        if (v < 2) {
+          const f32x4 f = __builtin_bit_cast(f32x4, ra);
+          split3_pair(f[2 * v], f[2 * v + 1], hh[v], mm[v], ll[v]);
+        } else if (v == 2) {
+          *reinterpret_cast<u32x2_t*>(adst) = (u32x2_t){hh[0], hh[1]};
+        } else if (v == 3) {
+          *reinterpret_cast<u32x2_t*>(adst + G::A_PLANE) = (u32x2_t){mm[0], mm[1]};
+        } else if (v == 4) {
+          *reinterpret_cast<u32x2_t*>(adst + 2 * G::A_PLANE) = (u32x2_t){ll[0], ll[1]};
+        } else if (v == 5) {
+          if (MODE == 3) ra = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff, (s + 3) * BKW * 4, 0);
+        }
+      }
+    };
+    static_assert(NBW + 6 + 6 <= 18, "the second half has 18 MFMA gaps");
+    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first (conv_x6_kernel's order)
+    int q = 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const bf16x8_t bv = j == 0 ? cb0[PB_[u]] : (j == 1 ? b1[PB_[u]] : b2[PB_[u]]);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0[PA_[u]], bv, acc[0][j], 0, 0, 0);
+        rest(q);
+        ++q;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (MODE >= 1) {
+      // B(s+1) is older than the fp32 load of A(s+2) in the queue: vmcnt(1) retires it and leaves that load in flight
+      if (MODE >= 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    q = 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const bf16x8_t bv = j == 0 ? cb0[PB_[u]] : (j == 1 ? b1[PB_[u]] : b2[PB_[u]]);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA_[u]], bv, acc[1][j], 0, 0, 0);
+        piece(q);
+        ++q;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+
   // ---- the k loop: one barrier per stage -------------------------------------------------------------------------------------
   // p.ablate (SG_PW_ABLATE; timing-only diagnostics, results wrong): 1 = no A path (load, split, LDS store), 2 = no B DMA,
   // 4 = no MFMAs (the fragment reads stay), 8 = no fragment reads and no MFMAs, 16 = no barrier
@@ -289,7 +382,36 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
       asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // B(0) has landed; A(1) may still fly
       if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (p.ablate == 0) {           // the woven step (the plain loop below serves the timing ablations)
+      if (p.ablate == 0 && p.stagger == 1) {   // the woven step with the barrier in the middle of the k-step
+        bf16x8_t pa0[3], pb0[3], pa1[3], pb1[3];
+        // stage 1 is staged before the loop (the loop stages s + 2 during k-step s), A(2) goes into flight
+        if (nk > 1) {
+          issue_B(1, 1);
+          store_A(1);                // (the compiler waits for ra = A(1) here)
+          if (nk > 2) load_A(2);
+        }
+        {
+          const char* sb = smem;
+          const int ko = (lh ^ sw) << 4;
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) pa0[pl] = *reinterpret_cast<const bf16x8_t*>(sb + a_lane + pl * G::A_PLANE + ko);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) pb0[pl] = *reinterpret_cast<const bf16x8_t*>(sb + b_lane + pl * G::B_PLANE + ko);
+        }
+        auto run = [&](int s, auto MODE_) {
+          step3m(s, MODE_, pa0, pb0, pa1, pb1);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {   // (register moves the allocator folds away where it can)
+            pa0[pl] = pa1[pl];
+            pb0[pl] = pb1[pl];
+          }
+        };
+        int s = 0;
+        for (; s + 3 < nk; ++s) run(s, IC<3>{});
+        if (s + 2 < nk) { run(s, IC<2>{}); ++s; }
+        if (s + 1 < nk) { run(s, IC<1>{}); ++s; }
+        run(s, IC<0>{});
+      } else if (p.ablate == 0) {    // the woven step, barrier at the end of the k-step (SG_PW_VAR=0; the plain loop below serves the timing ablations)
         int s = 0;
         for (; s + 2 < nk; ++s) step3(s, IC<2>{});
         if (s + 1 < nk) { step3(s, IC<1>{}); ++s; }
@@ -480,6 +602,8 @@ int launch_pw_wide(const IgemmParams& p, hipStream_t st) {
     static int abl = -1;
     if (abl < 0) abl = getenv("SG_PW_ABLATE") ? atoi(getenv("SG_PW_ABLATE")) : 0;
     q.ablate = abl;
+    static const int var = getenv("SG_PW_VAR") ? atoi(getenv("SG_PW_VAR")) : 1;
+    q.stagger = var;   // (the field is free in this kernel) 1: barrier in the middle of the k-step, 0: at its end
   }
   hipLaunchKernelGGL((pw_wide_kernel<NPL, TA>), dim3((unsigned)tiles), dim3(512), lds, st, q);
   SG_LAUNCH_CHECK("pw_wide_kernel");
@@ -535,6 +659,7 @@ constexpr int WPW_PA = 2 * PW_BM + 64;   // 320: LDS pitch of an A' pixel row (1
 constexpr int WPW_PB = 2 * PW_BN + 64;   // 832
 constexpr int WPW_STAGE = 3 * 16 * (WPW_PA + WPW_PB);   // 55296
 
+template <int VAR>   // SG_WPW_VAR: 1 (default) = the barrier in the middle of the k-step (step_m below), 0 = at its end
 __global__ __launch_bounds__(512, 2) void wgrad_pw_wide_kernel(const WgradParams p) {
   constexpr int WGN = 4, WM = 64, WN = 96, TM = 2, TN = 3;
   constexpr unsigned OOB = 0x80000000u;
@@ -667,6 +792,98 @@ __global__ __launch_bounds__(512, 2) void wgrad_pw_wide_kernel(const WgradParams
     __builtin_amdgcn_s_barrier();   // raw: the loads of k-step s+2 stay in flight across it
   };
 
+  // ---- second form (VAR = 1): the barrier in the MIDDLE of the k-step (pw_wide_kernel's step3m; conv_x6w_kernel's finding).
+  //   first half   18 MFMAs on af[0] x bf[0..2]: af[0] and bf[0] were PREFETCHED in the previous k-step, the other nine fragments
+  //                (18 transposed reads) are read here, one per MFMA; chunks 2 and 3 of stage s+1 are split and stored, their
+  //                registers reloaded for stage s+2;
+  //   middle       lgkmcnt(0) + barrier: stage s+1 is published, every wave holds all of stage s in registers: its buffer is free;
+  //   second half  18 MFMAs on af[1] x bf[0..2]: the six prefetch fragments of stage s+1; chunks 0 and 1 of stage s+2 split and
+  //                stored into the buffer of stage s, reloaded for stage s+3.
+  // The same products in the same order: bit-identical to the first form.
+  // MODE 3: s + 3 < nk (everything); 2: s + 2 < nk; 1: s + 1 < nk; 0: the last k-step.
+  auto chunk_pieces = [&](int c, int sub, int stage, int ks_load, bool do_load) {   // sub 0, 1: split halves; 2: store; 3: reload
+    if (sub < 2) {
+      split_piece(c == 0 ? ra : rb[c - 1 < 0 ? 0 : c - 1], sub);
+    } else if (sub == 2) {
+      if (c == 0) write_piece(a_dst(stage), WPW_PA);
+      else write_piece(b_dst(stage, c - 1), WPW_PB);
+    } else if (do_load) {
+      load_piece(ks_load, c);
+    }
+  };
+  auto step_m = [&](int s, auto MODE_, bf16x8_t (&ca0)[3], bf16x8_t (&cb0)[3], bf16x8_t (&na0)[3], bf16x8_t (&nb0)[3]) {
+    constexpr int MODE = decltype(MODE_)::value;
+    const int cur = s & 1, nxt = cur ^ 1;
+    const char* sb = smem + cur * WPW_STAGE;
+    const char* sn = smem + nxt * WPW_STAGE;
+    bf16x8_t a1[3], b1[3], b2[3];
+    constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first
+    // first half: gap q reads one of the nine remaining fragments (order of use: bf[1], bf[2], af[1]) on even q, and carries one
+    // of the eight pieces of chunks 2, 3 of stage s+1 on odd q
+    auto first = [&](int q) {
+      if ((q & 1) == 0) {
+        const int w = q >> 1;   // 0 .. 8
+        if (w < 3) {
+          const char* b = sb + b_lane + w * 16 * WPW_PB + 64 * 1;
+          b1[w] = tr_frag(b, b + 4 * WPW_PB);
+        } else if (w < 6) {
+          const char* b = sb + b_lane + (w - 3) * 16 * WPW_PB + 64 * 2;
+          b2[w - 3] = tr_frag(b, b + 4 * WPW_PB);
+        } else {
+          const char* a = sb + a_lane + (w - 6) * 16 * WPW_PA + 64;
+          a1[w - 6] = tr_frag(a, a + 4 * WPW_PA);
+        }
+      } else if (MODE >= 1) {
+        const int w = q >> 1;   // 0 .. 8: pieces 0 .. 7 used
+        if (w < 8) chunk_pieces(2 + (w >> 2), w & 3, nxt, ks_begin + s + 2, MODE >= 2);
+      }
+    };
+    // second half: the six prefetch fragments of stage s+1 first (the next k-step opens with them), then chunks 0, 1 of stage s+2
+    auto second = [&](int q) {
+      if (q < 6) {
+        if (MODE >= 1) {
+          if (q < 3) {
+            const char* a = sn + a_lane + q * 16 * WPW_PA;
+            na0[q] = tr_frag(a, a + 4 * WPW_PA);
+          } else {
+            const char* b = sn + b_lane + (q - 3) * 16 * WPW_PB;
+            nb0[q - 3] = tr_frag(b, b + 4 * WPW_PB);
+          }
+        }
+      } else if (MODE >= 2) {
+        const int w = q - 6;   // 0 .. 11: pieces 0 .. 7 used
+        if (w < 8) chunk_pieces(w >> 2, w & 3, cur, ks_begin + s + 3, MODE >= 3);
+      }
+    };
+    int q = 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const bf16x8_t bv = j == 0 ? cb0[PB_[u]] : (j == 1 ? b1[PB_[u]] : b2[PB_[u]]);
+        acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0[PA_[u]], bv, acc[0][j], 0, 0, 0);
+        first(q);
+        ++q;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    if (MODE >= 1) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // raw: the loads in flight stay in flight across it
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    q = 0;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int u = 0; u < 6; ++u) {
+        const bf16x8_t bv = j == 0 ? cb0[PB_[u]] : (j == 1 ? b1[PB_[u]] : b2[PB_[u]]);
+        acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA_[u]], bv, acc[1][j], 0, 0, 0);
+        second(q);
+        ++q;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+  };
+
   if (nk > 0) {
 #pragma unroll
     for (int w = 0; w < 4; ++w) load_piece(ks_begin, w);
@@ -683,10 +900,43 @@ __global__ __launch_bounds__(512, 2) void wgrad_pw_wide_kernel(const WgradParams
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    int s = 0;
-    for (; s + 2 < nk; ++s) step(s, IC<2>{});
-    if (s + 1 < nk) { step(s, IC<1>{}); ++s; }
-    step(s, IC<0>{});
+    if constexpr (VAR == 0) {
+      int s = 0;
+      for (; s + 2 < nk; ++s) step(s, IC<2>{});
+      if (s + 1 < nk) { step(s, IC<1>{}); ++s; }
+      step(s, IC<0>{});
+    } else {
+      bf16x8_t pa0[3], pb0[3], pa1[3], pb1[3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const char* a = smem + a_lane + pl * 16 * WPW_PA;
+        pa0[pl] = tr_frag(a, a + 4 * WPW_PA);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const char* b = smem + b_lane + pl * 16 * WPW_PB;
+        pb0[pl] = tr_frag(b, b + 4 * WPW_PB);
+      }
+      if (nk > 1) {   // chunks 0, 1 of stage 1 before the loop (the loop stages them in the second half of k-step s - 2)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+          for (int sub = 0; sub < 4; ++sub) chunk_pieces(c, sub, 1, ks_begin + 2, nk > 2);
+      }
+      auto run = [&](int s, auto MODE_) {
+        step_m(s, MODE_, pa0, pb0, pa1, pb1);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {   // (register moves the allocator folds away where it can)
+          pa0[pl] = pa1[pl];
+          pb0[pl] = pb1[pl];
+        }
+      };
+      int s = 0;
+      for (; s + 3 < nk; ++s) run(s, IC<3>{});
+      if (s + 2 < nk) { run(s, IC<2>{}); ++s; }
+      if (s + 1 < nk) { run(s, IC<1>{}); ++s; }
+      run(s, IC<0>{});
+    }
   }
 
   // ---- the partial slab of this split: out[split][ci][co], branch-free buffer stores ---------------------------------------
@@ -893,7 +1143,8 @@ inline int launch_wgrad_pw_wide(const WgradParams& p, int S, hipStream_t st) {
   constexpr size_t lds = 2 * (size_t)WPW_STAGE;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(wgrad_pw_wide_kernel, lds);
+    int rc = set_dyn_lds(wgrad_pw_wide_kernel<0>, lds);
+    if (!rc) rc = set_dyn_lds(wgrad_pw_wide_kernel<1>, lds);
     if (rc) return rc;
     attr_done = true;
   }
@@ -902,7 +1153,9 @@ inline int launch_wgrad_pw_wide(const WgradParams& p, int S, hipStream_t st) {
     sg_set_error("wgrad_pw_wide: bad grid (%lld tiles, %d splits)", (long long)tiles, S);
     return SG_EINVAL;
   }
-  hipLaunchKernelGGL(wgrad_pw_wide_kernel, dim3((unsigned)tiles, 1, (unsigned)S), dim3(512), lds, st, p);
+  static const int var = getenv("SG_WPW_VAR") ? atoi(getenv("SG_WPW_VAR")) : 1;
+  if (var == 1) hipLaunchKernelGGL(wgrad_pw_wide_kernel<1>, dim3((unsigned)tiles, 1, (unsigned)S), dim3(512), lds, st, p);
+  else hipLaunchKernelGGL(wgrad_pw_wide_kernel<0>, dim3((unsigned)tiles, 1, (unsigned)S), dim3(512), lds, st, p);
   SG_LAUNCH_CHECK("wgrad_pw_wide_kernel");
   return 0;
 }
