@@ -1,0 +1,27 @@
+"""Round 4: the hand-scheduled stage loops come in two forms each (barrier at the end of a stage / in its middle with prefetched
+fragments): conv_x6w_kernel (SG_X6W_VAR), pw_wide_kernel<3,float> (SG_PW_VAR), wgrad_pw_wide_kernel (SG_WPW_VAR).  Both forms
+issue the same MFMAs in the same order, so every output must agree bit for bit.  The switches are read once per process: each
+form runs scripts/pw_var_check.py in a child process (started before this process needs anything from it; the children use the
+GPU one after the other) and the digests are compared line by line."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _digests(var: str):
+    env = dict(os.environ, SG_PW_WIDE="2", SG_PW_VAR=var, SG_WPW_VAR=var, SG_X6W_VAR=var)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pw_var_check.py")], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [ln for ln in out.stdout.splitlines() if "->" in ln]
+
+
+def test_both_barrier_placements_give_the_same_bits():
+    end, mid = _digests("0"), _digests("1")
+    assert len(end) == 17 and len(mid) == 17, (len(end), len(mid))
+    assert end == mid, [(a, b) for a, b in zip(end, mid) if a != b]
