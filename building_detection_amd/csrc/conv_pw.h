@@ -434,6 +434,55 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!ab_bar) __builtin_amdgcn_s_barrier();
       }
+    } else if (p.stagger == 1) {
+      // bf16 storage, second form: the barrier between k-steps 2 and 3 of the 64-deep stage (every fragment of the stage is in
+      // registers or in flight by then), the DMA of stage s+2 and the first fragments of stage s+1 behind it, under the MFMAs of
+      // k-step 3 - the next stage opens on fragments that are already there.  Same MFMAs in the same order as the first form.
+      static_assert(NPL == 3 || KS == 4, "the bf16 stage has four k-steps");
+      bf16x8_t af[2][TM], bf[2][TN];
+      auto frags = [&](int stage, int ks, bf16x8_t (&a)[TM], bf16x8_t (&b)[TN]) {
+        const char* sb = smem + stage * G::STAGE;
+        const int ko = ((2 * ks + lh) ^ sw) << 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const bf16x8_t*>(sb + a_lane + 32 * i * RB + ko);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const bf16x8_t*>(sb + b_lane + 32 * j * RB + ko);
+      };
+      auto mfmas = [&](const bf16x8_t (&a)[TM], const bf16x8_t (&b)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+      };
+      issue_A16(0, 0);
+      issue_B(0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (nk > 1) {
+        issue_A16(1, 1);
+        issue_B(1, 1);
+      }
+      frags(0, 0, af[0], bf[0]);
+      for (int s = 0; s < nk; ++s) {
+        const int cur = s & 1, nxt = cur ^ 1;
+        frags(cur, 1, af[1], bf[1]);
+        mfmas(af[0], bf[0]);
+        frags(cur, 2, af[0], bf[0]);
+        mfmas(af[1], bf[1]);
+        frags(cur, 3, af[1], bf[1]);
+        mfmas(af[0], bf[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 2 < nk) {   // uniform; the buffer of stage s is free
+          issue_A16(s + 2, cur);
+          issue_B(s + 2, cur);
+        }
+        if (s + 1 < nk) frags(nxt, 0, af[0], bf[0]);
+        mfmas(af[1], bf[1]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       issue_A16(0, 0);
       issue_B(0, 0);

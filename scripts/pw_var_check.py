@@ -54,3 +54,18 @@ for (n, h, cin, cout, dil) in ((2, 32, 2048, 256, 6), (1, 64, 256, 512, 2), (2, 
     for t in (y, st[0] if st is not None else y[:0], dx):
         dig.update(t.detach().cpu().numpy().tobytes())
     print(f"x6w {n}x{h}x{h} {cin}->{cout} d{dil}: {dig.hexdigest()[:24]}", flush=True)
+
+# pw_wide_kernel<1, bf16>: bf16 storage, 64-deep stages (1, 2, 3 and many stages, a ragged last stage)
+for (n, h, cin, cout) in ((2, 32, 64, 384), (2, 32, 128, 384), (1, 32, 192, 400), (6, 32, 728, 728), (2, 32, 1000, 1536)):
+    x = (torch.rand(n, h, h, cin, generator=g) * 2 - 1).cuda().bfloat16()
+    w = ((torch.rand(1, 1, cin, cout, generator=g) * 2 - 1) * 0.05).cuda()
+    b = (torch.rand(cout, generator=g) - 0.5).cuda()
+    d = e.conv_desc(tuple(x.shape), cout, 1, 1, 1, 1, "same")
+    y, st = e.conv2d_fwd(x, w, b, desc=d, want_stats=True)
+    dy = (torch.rand(*y.shape, generator=g) * 2 - 1).cuda().bfloat16()
+    dx = e.conv2d_dgrad(dy, w, d)
+    torch.cuda.synchronize()
+    dig = hashlib.sha256()
+    for t in (y.float(), st[0] if st is not None else y[:0].float(), dx.float()):
+        dig.update(t.detach().cpu().numpy().tobytes())
+    print(f"bf16 {n}x{h}x{h} {cin}->{cout}: {dig.hexdigest()[:24]}", flush=True)

@@ -1,5 +1,5 @@
 """Round 4: the hand-scheduled stage loops come in two forms each (barrier at the end of a stage / in its middle with prefetched
-fragments): conv_x6w_kernel (SG_X6W_VAR), pw_wide_kernel<3,float> (SG_PW_VAR), wgrad_pw_wide_kernel (SG_WPW_VAR).  Both forms
+fragments): conv_x6w_kernel (SG_X6W_VAR), pw_wide_kernel<3,float> and <1,bf16> (SG_PW_VAR), wgrad_pw_wide_kernel (SG_WPW_VAR).  Both forms
 issue the same MFMAs in the same order, so every output must agree bit for bit.  The switches are read once per process: each
 form runs scripts/pw_var_check.py in a child process (started before this process needs anything from it; the children use the
 GPU one after the other) and the digests are compared line by line."""
@@ -23,5 +23,5 @@ def _digests(var: str):
 
 def test_both_barrier_placements_give_the_same_bits():
     end, mid = _digests("0"), _digests("1")
-    assert len(end) == 17 and len(mid) == 17, (len(end), len(mid))
+    assert len(end) == 22 and len(mid) == 22, (len(end), len(mid))
     assert end == mid, [(a, b) for a, b in zip(end, mid) if a != b]
