@@ -622,9 +622,272 @@ inline int dw_rows_per_run(int H, int64_t pixels, bool wgrad) {
 
 constexpr int DW_SUMS_MAX_ROWS = 1024;
 
+// ---- the stencil as column strips (round 4; maps of 64 rows and more - dw_fstrip_ok; SG_DW_FSTRIP=0 restores the run kernel) ------
+// dw_s1_run_kernel fetches its window once per run of RR x 4 outputs: 3 loads of 16 bytes per output chunk at RR = 2 (the
+// four-row window needs more registers than three workgroups per CU leave), and was measured at 38 us (forward with the
+// BatchNormalization in the gather) / 47 us (dgrad with the BatchNormalization sums) on the 47.7 MB middle-flow tensors that a
+// copy moves in 20.6 us - load-issue bound like the filter gradient before dw_wgrad_strip_kernel.  Here, as there, a lane owns 4
+// channels of a strip of 4 columns x HS rows and walks DOWN it with the window's three input rows in registers (transformed once:
+// widening, BatchNormalization, ReLU, the zero padding put back): one new input row (6 loads) per 4 outputs, requested one row
+// ahead; the epilogue's operands (ReLU mask, collected gradient, the BatchNormalization's raw input) are requested at the top of
+// the step.  Rows and columns outside the image are offsets beyond the buffer descriptor (bit 31 / bit 30): no select in front of
+// a load.  Same products in the same order as the run kernel (kernel rows 0..2, columns 0..2, one fp32 accumulator per output):
+// bit-identical outputs; the BatchNormalization sums are added in another (fixed) order.
+template <typename T>
+struct DwStripGeom {
+  int HS, nstrips;
+  unsigned in_bytes;
+  FastDiv fd_q, fd_hs;
+};
+
+template <typename T, bool RELU, bool MASK, bool BN, bool SUMS>
+__global__ __launch_bounds__(256, 2) void dw_strip_kernel(const DwRunParams<T> p, const DwStripGeom<T> gm_) {
+  constexpr int TX = 16, TY = 16, EB = (int)sizeof(T);
+  constexpr unsigned OOB = 0x80000000u;
+  typedef typename std::conditional<EB == 4, u32x4_c, u32x2_c>::type raw_t;
+  const int tx = threadIdx.x & (TX - 1), ty = threadIdx.x >> 4;
+  const int c_raw = (blockIdx.x * TX + tx) * 4;
+  if constexpr (!SUMS) {
+    if (c_raw >= p.C) return;
+  }
+  const bool live = c_raw < p.C;   // SUMS: every thread reaches the reduction; a lane past the last chunk walks chunk 0 and drops its results
+  const int c = live ? c_raw : 0;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+  const __amdgpu_buffer_rsrc_t rsrc_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(p.in), 0, (int)gm_.in_bytes, 0x00020000);
+  auto ldraw = [&](unsigned off) -> raw_t {
+    if constexpr (EB == 4) return __builtin_amdgcn_raw_buffer_load_b128(rsrc_in, (int)off, 0, 0);
+    else return __builtin_amdgcn_raw_buffer_load_b64(rsrc_in, (int)off, 0, 0);
+  };
+  auto widen = [&](const raw_t r) -> f32x4 {
+    if constexpr (EB == 4) {
+      return __builtin_bit_cast(f32x4, r);
+    } else {
+      return (f32x4){__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                     __uint_as_float(r[1] & 0xffff0000u)};
+    }
+  };
+  f32x4 wt[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) wt[t] = *reinterpret_cast<const f32x4*>(p.w + (p.flip ? 8 - t : t) * p.C + c);
+  f32x4 gm = zero, bt = zero, mv = zero, iv = zero;
+  if constexpr (BN) {
+    gm = *reinterpret_cast<const f32x4*>(p.bn_gamma + c);
+    bt = *reinterpret_cast<const f32x4*>(p.bn_beta + c);
+    mv = *reinterpret_cast<const f32x4*>(p.bn_mean + c);
+    iv = *reinterpret_cast<const f32x4*>(p.bn_invstd + c);
+  }
+  f32x4 s1 = zero, s2 = zero, bmv = zero, biv = zero, bgm = zero, bbt = zero;
+  if constexpr (SUMS) {
+    bmv = *reinterpret_cast<const f32x4*>(p.bs_mean + c);
+    biv = *reinterpret_cast<const f32x4*>(p.bs_invstd + c);
+    bgm = *reinterpret_cast<const f32x4*>(p.bs_gamma + c);
+    bbt = *reinterpret_cast<const f32x4*>(p.bs_beta + c);
+  }
+  const int HS = gm_.HS;
+  for (int s = blockIdx.y * TY + ty; s < gm_.nstrips; s += gridDim.y * TY) {
+    uint32_t rowi, q, n, hs;
+    fd_divmod((uint32_t)s, gm_.fd_q, rowi, q);       // strips of one row band lie side by side: neighbours share their halo columns
+    fd_divmod(rowi, gm_.fd_hs, n, hs);
+    const int ow0 = (int)q * 4, h0 = (int)hs * HS;
+    const int h1 = h0 + HS < p.H ? h0 + HS : p.H;
+    const bool lok = ow0 > 0, rok = ow0 + 4 < p.W;
+    const unsigned pix0 = (unsigned)n * p.H * p.W + ow0, inrow = (unsigned)p.W * p.in_ld * EB;
+    const unsigned inoff0 = (pix0 * p.in_ld + c) * EB;
+    unsigned coff[6];
+#pragma unroll
+    for (int b = 0; b < 6; ++b) coff[b] = (unsigned)((b - 1) * p.in_ld * EB);
+    coff[0] = lok ? coff[0] : 0x40000000u;
+    coff[5] = rok ? coff[5] : 0x40000000u;
+    auto load_row = [&](int ih, raw_t (&v)[6]) {
+      const unsigned flag = ((unsigned)ih < (unsigned)p.H && ih <= h1) ? 0u : OOB;   // (the row behind the halo is never used)
+      const unsigned ro = inoff0 + (unsigned)ih * inrow;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) v[b] = ldraw((ro + coff[b]) | flag);
+    };
+    // a raw row -> the six window values the products use (the run kernel's expressions, in its order)
+    auto transform = [&](const raw_t (&r)[6], f32x4 (&v)[6], int ih) {
+      const bool rowok = (unsigned)ih < (unsigned)p.H;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        f32x4 t = widen(r[b]);
+        if constexpr (BN) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = fmaf((t[e] - mv[e]) * iv[e], gm[e], bt[e]);
+          t = (rowok && (b == 0 ? lok : (b == 5 ? rok : true))) ? t : zero;   // zero padding of the NORMALISED tensor
+        }
+        if constexpr (RELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], 0.f);
+        }
+        v[b] = t;
+      }
+    };
+    // V[j]: the three transformed rows of the window, roles rotating with the (unrolled by three) row step; R: the raw row in flight
+    f32x4 V[3][6];
+    raw_t R[6];
+    {
+      raw_t r0[6], r1[6];
+      load_row(h0 - 1, r0);
+      load_row(h0, r1);
+      load_row(h0 + 1, R);
+      transform(r0, V[0], h0 - 1);
+      transform(r1, V[1], h0);
+    }
+    auto step = [&](auto I_, int oh) {
+      constexpr int I = decltype(I_)::value;
+      // row oh + 1 has arrived (requested one step ago): transform it into the buffer of row oh - 2, then request row oh + 2 into
+      // the same raw registers
+      transform(R, V[(I + 2) % 3], oh + 1);
+      load_row(oh + 2, R);
+      const int64_t opix = (int64_t)(n * p.H + oh) * p.W + ow0;
+      f32x4 acc[4] = {zero, zero, zero, zero};
+#pragma unroll
+      for (int ta = 0; ta < 3; ++ta) {
+        const f32x4 (&v)[6] = V[(I + ta) % 3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int b = 0; b < 3; ++b) acc[k] += v[k + b] * wt[ta * 3 + b];
+      }
+      // the epilogue in two halves of two output pixels (its operands - ReLU mask, collected gradient, the BatchNormalization's raw
+      // input - would hold 48 registers if all four were requested together)
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {
+        f32x4 m[2], rv[2], bx[2];
+        if constexpr (MASK) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) m[k] = ld4<T>(p.mask + (opix + 2 * hf + k) * p.mask_ld + c);
+        }
+        if (p.res) {   // uniform
+#pragma unroll
+          for (int k = 0; k < 2; ++k) rv[k] = ld4<T>(p.res + (opix + 2 * hf + k) * p.out_ld + c);
+        }
+        if constexpr (SUMS) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) bx[k] = ld4<T>(p.bs_x + (opix + 2 * hf + k) * p.bs_ld + c);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          f32x4 o = acc[2 * hf + k];
+          if constexpr (MASK) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = m[k][e] > 0.f ? o[e] : 0.f;
+          }
+          if (p.res) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += rv[k][e];
+          }
+          if constexpr (SUMS) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float xh = (bx[k][e] - bmv[e]) * biv[e];
+              const bool on = !p.bs_relu || fmaf(xh, bgm[e], bbt[e]) > 0.f;
+              const float g = on ? o[e] : 0.f;
+              s1[e] += g;
+              s2[e] = fmaf(g, xh, s2[e]);
+            }
+          }
+          if (SUMS && !live) continue;
+          st4<T>(p.out + (opix + 2 * hf + k) * p.out_ld + c, o);
+        }
+      }
+    };
+    for (int oh = h0; oh < h1; oh += 3) {
+      step(std::integral_constant<int, 0>{}, oh);
+      if (oh + 1 >= h1) break;
+      step(std::integral_constant<int, 1>{}, oh + 1);
+      if (oh + 2 >= h1) break;
+      step(std::integral_constant<int, 2>{}, oh + 2);
+    }
+  }
+  if constexpr (SUMS) {
+    // the 16 strip slots of this workgroup are added in slot order; the partial row of this workgroup goes to
+    // bs_part[blockIdx.y], the rows are added in fp64 by the finalize launch (fixed order: deterministic)
+    __shared__ float red[256 * 8];
+    float* mine = red + threadIdx.x * 8;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mine[e] = s1[e]; mine[4 + e] = s2[e]; }
+    __syncthreads();
+    if (ty == 0 && live) {
+      f32x4 t1 = zero, t2 = zero;
+      for (int j = 0; j < TY; ++j) {
+        const float* qq = red + (j * TX + tx) * 8;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { t1[e] += qq[e]; t2[e] += qq[4 + e]; }
+      }
+      float* row = p.bs_part + (int64_t)blockIdx.y * 2 * p.C + c;
+      *reinterpret_cast<f32x4*>(row) = t1;
+      *reinterpret_cast<f32x4*>(row + p.C) = t2;
+    }
+  }
+}
+
+template <typename T>
+inline bool dw_fstrip_ok(const DwRunParams<T>& p) {
+  // SG_DW_FSTRIP: 0 never, 1 (default) maps of 64 rows and more, 2 every map.  Measured (profiles/r04_dw_fstrip_ab.txt): 64x64x256
+  // 34.0 -> 30.7 us, 128x128x128 62.0 -> 54.9, 256x256x64 115.0 -> 106.1 (strips of 16 rows); the 32x32 maps of the middle flow run
+  // no faster (27.2 -> 31.8 us alone, +-0.1 ms in the step at any strip height): with 1.4 waves per SIMD the strips are
+  // latency-bound there, and the run kernel was not load-issue bound to begin with (76 % of copy speed).
+  static const int on = getenv("SG_DW_FSTRIP") ? atoi(getenv("SG_DW_FSTRIP")) : 1;
+  const int64_t pix = (int64_t)p.N * p.H * p.W;
+  if (!on || (on == 1 && p.H < 64)) return false;
+  // byte offsets are 32-bit buffer offsets in which bit 30 / bit 31 mark a column / row outside the image: inputs below 1 GiB
+  return p.H % 4 == 0 && p.W % 4 == 0 && pix * p.in_ld * (int64_t)sizeof(T) < (1ll << 30);
+}
+
+template <typename T>
+int launch_dw_strip(const DwRunParams<T>& p, hipStream_t st, int* sums_rows) {
+  static const int hs_force = getenv("SG_DW_FSTRIP_HS") ? atoi(getenv("SG_DW_FSTRIP_HS")) : 0;
+  DwStripGeom<T> g;
+  g.HS = hs_force > 0 ? hs_force : (p.H >= 64 ? 16 : (p.H >= 16 ? 8 : p.H));
+  if (g.HS % 4 != 0 || g.HS > p.H) g.HS = 4;
+  const int nhs = (int)sg_cdiv(p.H, g.HS);
+  g.nstrips = p.N * nhs * (p.W / 4);
+  g.in_bytes = (unsigned)((int64_t)p.N * p.H * p.W * p.in_ld * (int64_t)sizeof(T));
+  g.fd_q = make_fastdiv((uint32_t)(p.W / 4));
+  g.fd_hs = make_fastdiv((uint32_t)nhs);
+  const unsigned gx = (unsigned)sg_cdiv(p.C / 4, 16);
+  int64_t gy = sg_cdiv(g.nstrips, 16);
+  const int64_t cap = sg_cdiv(16384, gx);
+  if (gy > cap) gy = cap;
+  if (gy < 1) gy = 1;
+  if (p.bs_part && gy > DW_SUMS_MAX_ROWS) gy = DW_SUMS_MAX_ROWS;
+  const dim3 grid(gx, (unsigned)gy);
+  if (p.bs_part) {
+    if (p.mask) hipLaunchKernelGGL((dw_strip_kernel<T, false, true, false, true>), grid, dim3(256), 0, st, p, g);
+    else hipLaunchKernelGGL((dw_strip_kernel<T, false, false, false, true>), grid, dim3(256), 0, st, p, g);
+    SG_LAUNCH_CHECK("dw_strip_kernel<SUMS>");
+    if (sums_rows) *sums_rows = (int)gy;
+    return 0;
+  }
+  if (p.bn_gamma) {
+    if (p.relu_in) hipLaunchKernelGGL((dw_strip_kernel<T, true, false, true, false>), grid, dim3(256), 0, st, p, g);
+    else hipLaunchKernelGGL((dw_strip_kernel<T, false, false, true, false>), grid, dim3(256), 0, st, p, g);
+  } else if (p.mask) {
+    hipLaunchKernelGGL((dw_strip_kernel<T, false, true, false, false>), grid, dim3(256), 0, st, p, g);
+  } else if (p.relu_in) {
+    hipLaunchKernelGGL((dw_strip_kernel<T, true, false, false, false>), grid, dim3(256), 0, st, p, g);
+  } else {
+    hipLaunchKernelGGL((dw_strip_kernel<T, false, false, false, false>), grid, dim3(256), 0, st, p, g);
+  }
+  SG_LAUNCH_CHECK("dw_strip_kernel");
+  return 0;
+}
+
 template <typename T>
 int launch_dw_run(const DwRunParams<T>& p_in, hipStream_t st, int* sums_rows = nullptr) {
   DwRunParams<T> p = p_in;
+  if (dw_fstrip_ok(p)) {
+    if (p.bs_part && (p.relu_in || p.bn_gamma)) {
+      sg_set_error("dw_s1_run: BatchNormalization sums together with relu_in / a fused BatchNormalization");
+      return SG_EINVAL;
+    }
+    if (p.mask && (p.relu_in || p.bn_gamma)) {
+      sg_set_error("dw_s1_run: mask together with relu_in / a fused BatchNormalization");
+      return SG_EINVAL;
+    }
+    return launch_dw_strip(p, st, sums_rows);
+  }
   int rr = dw_rows_per_run(p.H, (int64_t)p.N * p.H * p.W, false);
   if (p.bs_part && rr == 4) rr = 2;   // the four-row window plus the BatchNormalization sums does not fit the register file
   p.nruns = (int64_t)p.N * (p.H / rr) * p.runs_per_row;

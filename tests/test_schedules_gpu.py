@@ -25,3 +25,20 @@ def test_both_barrier_placements_give_the_same_bits():
     end, mid = _digests("0"), _digests("1")
     assert len(end) == 22 and len(mid) == 22, (len(end), len(mid))
     assert end == mid, [(a, b) for a, b in zip(end, mid) if a != b]
+
+
+def _dw_digests(var: str):
+    env = dict(os.environ, SG_DW_FSTRIP=var)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "dw_var_check.py")], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [ln for ln in out.stdout.splitlines() if ": " in ln and "x" in ln]
+
+
+def test_depthwise_stencil_as_runs_and_as_strips_gives_the_same_bits():
+    """dw_s1_run_kernel (SG_DW_FSTRIP=0) and dw_strip_kernel (2: every map) add the same products in the same order: forward
+    (plain, pre-activation ReLU, BatchNormalization in the gather with / without ReLU) and dgrad (plain, ReLU mask, a collected
+    gradient riding along) agree bit for bit in fp32 and bf16 storage over six map sizes."""
+    runs, strips = _dw_digests("0"), _dw_digests("2")
+    assert len(runs) == 12 and len(strips) == 12, (len(runs), len(strips))
+    assert runs == strips, [(a, b) for a, b in zip(runs, strips) if a != b]
