@@ -1227,19 +1227,19 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
   // 1x1 / stride 1 with enough columns for 384-wide tiles (the 728-wide middle flow and the exit flow): conv_pw.h, with its
   // own k-block-major plane layout
   if constexpr ((NPL == 3 && std::is_same<TA, float>::value) || (NPL == 1 && !std::is_same<TA, float>::value)) {
-    if (pw_wide_ok(p, EL<TA>::BYTES)) {
+    if (const int wbn = pw_wide_bn(p, EL<TA>::BYTES)) {
       const int K = p.K, N = p.Nout;
       p.Kpad = pw_kpad(K, NPL);
-      p.Npad = pw_npad(N);
+      p.Npad = pw_npad(N, wbn);
       p.wq = (const unsigned short*)ws;
-      p.w_bytes = (uint32_t)pw_planes_bytes(K, N, NPL);
+      p.w_bytes = (uint32_t)pw_planes_bytes(K, N, NPL, wbn);
       if (!prepared) {
         dim3 grid((unsigned)sg_cdiv(p.Kpad, 32), (unsigned)sg_cdiv(p.Npad, 32));
         hipLaunchKernelGGL(split3_weights_kernel, grid, dim3(256), 0, st, w, (unsigned short*)ws, K, N, p.Kpad, p.Npad, K,
                            Cin * Cout, dgrad ? 1 : Cout, dgrad ? Cout : 1, NPL, K, pw_kd(NPL));
         SG_LAUNCH_CHECK("split3_weights_kernel");
       }
-      return launch_pw_wide<NPL, TA>(p, st);
+      return wbn == 256 ? launch_pw_wide<NPL, TA, 256>(p, st) : launch_pw_wide<NPL, TA, 384>(p, st);
     }
   }
   const int Ck = p.C;
@@ -1313,7 +1313,8 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
 inline size_t x6_ws_bytes(int taps, int C, int N) {
   const int k = taps > 1 ? taps * x6_vpad_c(C) : C;
   const size_t rows = x6_planes_bytes(k, N, 3, 64);   // (the deepest k-block any kernel asks for)
-  const size_t wide = taps == 1 ? pw_planes_bytes(C, N, 3) : 0;   // the wide pointwise kernel pads N to 384s
+  const size_t w384 = taps == 1 ? pw_planes_bytes(C, N, 3, 384) : 0, w256 = taps == 1 ? pw_planes_bytes(C, N, 3, 256) : 0;
+  const size_t wide = w384 > w256 ? w384 : w256;   // the wide pointwise kernel pads N to its tile width
   return rows > wide ? rows : wide;
 }
 
@@ -2103,16 +2104,17 @@ int sg_conv2d_planes_job(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, in
     }
   }
   p.x = (const float*)(uintptr_t)16;
-  if (nb >= d->N && pw_wide_ok(p, eb)) {   // the wide pointwise kernel's k-block-major planes (conv_pw.h); never for sub-batches
+  const int wbn = nb >= d->N ? pw_wide_bn(p, eb) : 0;
+  if (wbn) {   // the wide pointwise kernel's k-block-major planes (conv_pw.h); never for sub-batches
     out->kind = 3;
     out->npl = npl;
     out->K = p.K;
     out->Ckp = p.K;
     out->kd = pw_kd(npl);
     out->Kpad = pw_kpad(p.K, npl);
-    out->Npad = pw_npad(p.Nout);
+    out->Npad = pw_npad(p.Nout, wbn);
     out->nblocks = (int32_t)(sg_cdiv(out->Kpad, 32) * sg_cdiv(out->Npad, 32));
-    *bytes = pw_planes_bytes(p.K, p.Nout, npl);
+    *bytes = pw_planes_bytes(p.K, p.Nout, npl, wbn);
     return 0;
   }
   int Ckp = Ck, K = p.K;

@@ -24,14 +24,14 @@
 
 constexpr int PW_BM = 128, PW_BN = 384;
 
-template <int NPL>
+template <int NPL, int BN = 384>
 struct PwGeom {
   static constexpr int KS = NPL == 3 ? 1 : 4;      // 16-deep k-steps per stage
   static constexpr int BKW = 16 * KS;              // reduction depth of a stage
   static constexpr int RB = 2 * BKW;               // bytes of one LDS row (bf16)
   static constexpr int CPR = RB / 16;              // 16-byte chunks per row
   static constexpr int WSH = RB == 32 ? 3 : (RB == 64 ? 2 : 1);   // log2(rows per 256 bytes)
-  static constexpr int A_PLANE = PW_BM * RB, B_PLANE = PW_BN * RB;
+  static constexpr int A_PLANE = PW_BM * RB, B_PLANE = BN * RB;
   static constexpr int STAGE = NPL * (A_PLANE + B_PLANE);
   // the 16 lanes of a ds_read_b128 group ({0-3,12-15,20-27} / {4-11,16-19,28-31} of 32 rows) hit 16 distinct 16-byte
   // bank groups when chunk c of row r sits at slot c ^ swz(r)
@@ -43,22 +43,25 @@ __device__ __forceinline__ void pw_lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, 
   __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (void __attribute__((address_space(3)))*)lds_wave_base, 16, (int)voff, soff, 0, 0);
 }
 
-template <int NPL, typename TA>
+// BN: columns of the tile - 384 (8 waves of 64 x 96) or 256 (64 x 64: the 1024- and 2048-wide layers of the exit flow and the
+// 256-wide ones at many rows, whose last 384-wide tile would be two thirds / one third empty; round 4)
+template <int NPL, typename TA, int BN = 384>
 __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
   static_assert((NPL == 3 && std::is_same<TA, float>::value) || (NPL == 1 && !std::is_same<TA, float>::value),
                 "x6 on fp32 storage, one plane on bf16 storage");
-  using G = PwGeom<NPL>;
+  static_assert(BN == 384 || BN == 256, "tile width");
+  using G = PwGeom<NPL, BN>;
   constexpr int KS = G::KS, BKW = G::BKW, RB = G::RB, CPR = G::CPR;
-  constexpr int WGM = 2, WGN = 4, WM = 64, WN = 96, TM = 2, TN = 3;
+  constexpr int WGM = 2, WGN = 4, WM = 64, WN = BN / WGN, TM = 2, TN = WN / 32;
   constexpr unsigned OOB = 0x80000000u;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 stages] x { A planes [NPL][128][RB], B planes [NPL][384][RB] }
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);   // in an SGPR: LDS-DMA bases and piece numbers are scalar arithmetic
   const uint32_t bid = xcd_remap(blockIdx.x, gridDim.x);
-  const uint32_t ntn = (p.Nout + PW_BN - 1) / PW_BN;
+  const uint32_t ntn = (p.Nout + BN - 1) / BN;
   const uint32_t tile_m = bid / ntn, tile_n = bid - tile_m * ntn;   // the column tiles of a row tile are neighbours: A from L2
-  const int m0 = tile_m * PW_BM, n0 = tile_n * PW_BN;
+  const int m0 = tile_m * PW_BM, n0 = tile_n * BN;
 
   const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrc_w =
@@ -68,7 +71,7 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
   // ---- operand delivery ------------------------------------------------------------------------------------------------
   // B: DMA pieces of 1 KB = (1024 / RB) rows of one plane; piece g -> plane g / PPP, rows (g % PPP) * RPP ...
   constexpr int RPP = 1024 / RB;                  // rows per piece: 32 (x6) / 8 (bf16)
-  constexpr int PPP = PW_BN / RPP;                // pieces per B plane: 12 / 48
+  constexpr int PPP = BN / RPP;                // pieces per B plane: 12 / 48
   constexpr int NBP = NPL * PPP;                  // B pieces per stage: 36 / 48
   constexpr int NBW = (NBP + 7) / 8;              // per wave: 5 (waves 0-3; 4 for waves 4-7) / 6
   unsigned b_voff[NBW];
@@ -292,14 +295,14 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
     const char* sb = smem + cur * G::STAGE;
     const char* sn = smem + nxt * G::STAGE;
     const int ko = (lh ^ sw) << 4;
-    bf16x8_t a1[3], b1[3], b2[3];
+    bf16x8_t a1[3], bj[TN > 1 ? TN - 1 : 1][3];   // bj[j - 1]: column sub-tile j >= 1
     unsigned hh[2], mm[2], ll[2];
     char* adst = smem + cur * G::STAGE + a_row * RB + (((a_kq >> 1) ^ G::swz(a_row)) << 4) + (a_kq & 1) * 8;   // stage s+2 -> buffer of s
     char* bbase = smem + cur * G::STAGE + NPL * G::A_PLANE;
-    auto rest = [&](int w) {   // first half: the nine fragments not prefetched, in the order the MFMAs want them
-      if (w < 3) b1[w] = *reinterpret_cast<const bf16x8_t*>(sb + b_lane + w * G::B_PLANE + 32 * 1 * RB + ko);
-      else if (w < 6) b2[w - 3] = *reinterpret_cast<const bf16x8_t*>(sb + b_lane + (w - 3) * G::B_PLANE + 32 * 2 * RB + ko);
-      else if (w < 9) a1[w - 6] = *reinterpret_cast<const bf16x8_t*>(sb + a_lane + (w - 6) * G::A_PLANE + 32 * RB + ko);
+    constexpr int NREST = 3 * (TN - 1) + 3;
+    auto rest = [&](int w) {   // first half: the fragments not prefetched, in the order the MFMAs want them
+      if (w < 3 * (TN - 1)) bj[w / 3][w % 3] = *reinterpret_cast<const bf16x8_t*>(sb + b_lane + (w % 3) * G::B_PLANE + 32 * (w / 3 + 1) * RB + ko);
+      else if (w < NREST) a1[w - 3 * (TN - 1)] = *reinterpret_cast<const bf16x8_t*>(sb + a_lane + (w - 3 * (TN - 1)) * G::A_PLANE + 32 * RB + ko);
     };
     // second half, in this order: the DMA pieces of B(s+2) (longest flight), the six prefetch reads of stage s+1 (the next k-step
     // opens with them), split + stores of A(s+2), the fp32 load of A(s+3)
@@ -332,14 +335,15 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
         }
       }
     };
-    static_assert(NBW + 6 + 6 <= 18, "the second half has 18 MFMA gaps");
+    constexpr int NPIECE = NBW + 6 + 6, NGAP = 6 * TN;   // the pieces are spread over the half's MFMA gaps (two in some at BN = 256)
+    static_assert(NPIECE <= 2 * NGAP && NREST <= NGAP, "pieces per MFMA gap");
     constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first (conv_x6_kernel's order)
     int q = 0;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
       for (int u = 0; u < 6; ++u) {
-        const bf16x8_t bv = j == 0 ? cb0[PB_[u]] : (j == 1 ? b1[PB_[u]] : b2[PB_[u]]);
+        const bf16x8_t bv = j == 0 ? cb0[PB_[u]] : bj[j > 0 ? j - 1 : 0][PB_[u]];
         acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ca0[PA_[u]], bv, acc[0][j], 0, 0, 0);
         rest(q);
         ++q;
@@ -359,9 +363,10 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
       for (int u = 0; u < 6; ++u) {
-        const bf16x8_t bv = j == 0 ? cb0[PB_[u]] : (j == 1 ? b1[PB_[u]] : b2[PB_[u]]);
+        const bf16x8_t bv = j == 0 ? cb0[PB_[u]] : bj[j > 0 ? j - 1 : 0][PB_[u]];
         acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1[PA_[u]], bv, acc[1][j], 0, 0, 0);
-        piece(q);
+#pragma unroll
+        for (int w = (q * NPIECE) / NGAP; w < ((q + 1) * NPIECE) / NGAP; ++w) piece(w);
         ++q;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
   } else {
     // the bf16 tile goes through LDS so that it leaves as 16-byte row chunks (conv_b16_kernel's epilogue)
     bf16_t* __restrict__ py = reinterpret_cast<bf16_t*>(p.y);
-    constexpr int TP = PW_BN * 2 + 16;
+    constexpr int TP = BN * 2 + 16;
     const bool wide = (p.y_ld % 8 == 0) && (p.Nout % 8 == 0) && ((reinterpret_cast<uintptr_t>(p.y) & 15) == 0);
     if (wide) {
 #pragma unroll
@@ -554,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
           }
       }
       __syncthreads();
-      constexpr int CPT = PW_BN / 8;
+      constexpr int CPT = BN / 8;
       for (int idx = t; idx < PW_BM * CPT; idx += 512) {
         const int rl = idx / CPT, c = idx - rl * CPT;
         const int row = m0 + rl, col = n0 + 8 * c;
@@ -584,8 +589,8 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
 
   // ---- BatchNormalization statistics of this 128-row tile (conv_x6_kernel's scheme and layout: stats[tile_m][2][Nout]) ---------
   if (p.stats) {
-    float* red = reinterpret_cast<float*>(smem);   // [WGM][PW_BN] partials, then [PW_BN] tile means
-    float* tmean = red + WGM * PW_BN;
+    float* red = reinterpret_cast<float*>(smem);   // [WGM][BN] partials, then [BN] tile means
+    float* tmean = red + WGM * BN;
     const int wrow = wave / WGN;
     const int nvalid = (p.M - m0) < PW_BM ? (p.M - m0) : PW_BM;
     __syncthreads();   // every wave is done with the stage buffers / the staged output tile
@@ -607,13 +612,13 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
             if (row < p.M) sacc += pass ? dlt * dlt : dlt;
           }
         sacc += __shfl_xor(sacc, 32, 64);   // lanes l and l + 32 hold the same column
-        if (lh == 0) red[wrow * PW_BN + cl] = sacc;
+        if (lh == 0) red[wrow * BN + cl] = sacc;
       }
       __syncthreads();
-      for (int cl = t; cl < PW_BN; cl += 512) {
+      for (int cl = t; cl < BN; cl += 512) {
         float tot = 0.f;
 #pragma unroll
-        for (int wq = 0; wq < WGM; ++wq) tot += red[wq * PW_BN + cl];
+        for (int wq = 0; wq < WGM; ++wq) tot += red[wq * BN + cl];
         const int col = n0 + cl;
         if (pass == 0) tmean[cl] = tot / (float)nvalid;
         if (col < p.Nout) p.stats[((int64_t)tile_m * 2 + pass) * p.Nout + col] = tot;
@@ -623,21 +628,21 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
   }
 }
 
-template <int NPL, typename TA>
+template <int NPL, typename TA, int BN = 384>
 int launch_pw_wide(const IgemmParams& p, hipStream_t st) {
-  using G = PwGeom<NPL>;
+  using G = PwGeom<NPL, BN>;
   constexpr size_t stage_lds = 2 * (size_t)G::STAGE;
-  constexpr size_t tile_lds = NPL == 1 ? (size_t)PW_BM * (PW_BN * 2 + 16) : 0;
-  constexpr size_t stat_lds = (size_t)3 * PW_BN * sizeof(float);
+  constexpr size_t tile_lds = NPL == 1 ? (size_t)PW_BM * (BN * 2 + 16) : 0;
+  constexpr size_t stat_lds = (size_t)3 * BN * sizeof(float);
   constexpr size_t m1 = stage_lds > tile_lds ? stage_lds : tile_lds;
   constexpr size_t lds = m1 > stat_lds ? m1 : stat_lds;
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(pw_wide_kernel<NPL, TA>, lds);
+    int rc = set_dyn_lds(pw_wide_kernel<NPL, TA, BN>, lds);
     if (rc) return rc;
     attr_done = true;
   }
-  const int64_t tiles = sg_cdiv(p.M, PW_BM) * sg_cdiv(p.Nout, PW_BN);
+  const int64_t tiles = sg_cdiv(p.M, PW_BM) * sg_cdiv(p.Nout, BN);
   if (tiles <= 0 || tiles > 0x7fffffff) {
     sg_set_error("pw_wide: bad tile count %lld", (long long)tiles);
     return SG_EINVAL;
@@ -654,7 +659,7 @@ int launch_pw_wide(const IgemmParams& p, hipStream_t st) {
     static const int var = getenv("SG_PW_VAR") ? atoi(getenv("SG_PW_VAR")) : 1;
     q.stagger = var;   // (the field is free in this kernel) 1: barrier in the middle of the k-step, 0: at its end
   }
-  hipLaunchKernelGGL((pw_wide_kernel<NPL, TA>), dim3((unsigned)tiles), dim3(512), lds, st, q);
+  hipLaunchKernelGGL((pw_wide_kernel<NPL, TA, BN>), dim3((unsigned)tiles), dim3(512), lds, st, q);
   SG_LAUNCH_CHECK("pw_wide_kernel");
   return 0;
 }
@@ -663,8 +668,8 @@ int launch_pw_wide(const IgemmParams& p, hipStream_t st) {
 // multiple of 384, zero padded; sg_planes_job kind 3 (Ckp carries KD) / split3_weights_kernel(kd) ---------------------------
 inline int pw_kd(int npl) { return npl == 3 ? 16 : 64; }
 inline int pw_kpad(int K, int npl) { return (int)(sg_cdiv(K, pw_kd(npl)) * pw_kd(npl)); }
-inline int pw_npad(int N) { return (int)(sg_cdiv(N, PW_BN) * PW_BN); }
-inline size_t pw_planes_bytes(int K, int N, int npl) { return (size_t)npl * pw_kpad(K, npl) * pw_npad(N) * 2; }
+inline int pw_npad(int N, int bn = PW_BN) { return (int)(sg_cdiv(N, bn) * bn); }
+inline size_t pw_planes_bytes(int K, int N, int npl, int bn = PW_BN) { return (size_t)npl * pw_kpad(K, npl) * pw_npad(N, bn) * 2; }
 
 // Shapes the wide kernel takes: one tap (1x1), stride 1, no gather; a reduction deep enough to amortise the 128 x 384 tile's
 // prologue; a column count whose last 384-wide tile is at least three quarters full (728 -> 2 tiles, 1024 -> 3, 1536 -> 4,
@@ -676,21 +681,29 @@ inline size_t pw_planes_bytes(int K, int N, int npl) { return (size_t)npl * pw_k
 // order (16-deep k-steps ascending, the six x6 terms smallest first, one fp32 accumulator), so a tile's result does not
 // depend on which of them its batch size selected (tests/test_fullsize_gpu.py: batch-slice invariance, bit exact).
 // SG_PW_WIDE=0 switches it off, 2 takes every aligned 1x1 (tests).
-inline bool pw_wide_ok(const IgemmParams& p, int eb) {
+// Tile width (round 4): 384 where the last 384-wide tile is at least three quarters full (728, 1536); else 256 where THAT fits
+// (1024, 2048, 256) and the launch brings at least one 128 x 256 tile per CU (16384 rows x 256 columns are 128 tiles: those stay
+// on conv_x6_kernel's 256 tiles of 128 x 128).  SG_PW_WIDE=3: 384 only.
+inline int pw_wide_bn(const IgemmParams& p, int eb) {
   static int on = -1;
   if (on < 0) on = getenv("SG_PW_WIDE") ? atoi(getenv("SG_PW_WIDE")) : 1;
-  if (!on) return false;
-  if (p.K != p.C || p.a_mul != 1 || p.div != 1 || p.off_h != 0 || p.off_w != 0) return false;
+  if (!on) return 0;
+  if (p.K != p.C || p.a_mul != 1 || p.div != 1 || p.off_h != 0 || p.off_w != 0) return 0;
   // (both activation tensors of a launch are below 2 GiB by construction: larger batches run as sub-batches of whole images,
   // images_per_2gib; launch_pw_wide re-checks)
-  if (eb == 2 && (p.K % 8 != 0 || p.x_ld % 8 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0)) return false;
-  if (eb == 4 && (p.x_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0)) return false;
-  if (g_sub_batch) return false;
-  if (on == 2) return true;
-  if (p.K < 256 || p.M < 6144) return false;
+  if (eb == 2 && (p.K % 8 != 0 || p.x_ld % 8 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0)) return 0;
+  if (eb == 4 && (p.x_ld % 4 != 0 || (reinterpret_cast<uintptr_t>(p.x) & 15) != 0)) return 0;
+  if (g_sub_batch) return 0;
+  if (on == 2) return PW_BN;
+  if (p.K < 256 || p.M < 6144) return 0;
   const int64_t ntn = sg_cdiv(p.Nout, PW_BN);
-  return (double)p.Nout / (double)(ntn * PW_BN) >= 0.75;
+  if ((double)p.Nout / (double)(ntn * PW_BN) >= 0.75) return PW_BN;
+  if (on == 3) return 0;
+  const int64_t ntn2 = sg_cdiv(p.Nout, 256);
+  if ((double)p.Nout / (double)(ntn2 * 256) >= 0.75 && sg_cdiv(p.M, PW_BM) * ntn2 >= 256) return 256;
+  return 0;
 }
+inline bool pw_wide_ok(const IgemmParams& p, int eb) { return pw_wide_bn(p, eb) != 0; }
 
 // =====================================================================================================================
 // The filter gradient of the same layers: dw[ci][co] = sum over pixels x[p][ci] * dy[p][co]   (1x1, stride 1; fp32, x6)

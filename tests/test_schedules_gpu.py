@@ -42,3 +42,20 @@ def test_depthwise_stencil_as_runs_and_as_strips_gives_the_same_bits():
     runs, strips = _dw_digests("0"), _dw_digests("2")
     assert len(runs) == 12 and len(strips) == 12, (len(runs), len(strips))
     assert runs == strips, [(a, b) for a, b in zip(runs, strips) if a != b]
+
+
+def _bn_digests(wide: str):
+    env = dict(os.environ, SG_PW_WIDE=wide)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "pw_bn_check.py")], env=env, cwd=ROOT, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return [ln for ln in out.stdout.splitlines() if "->" in ln]
+
+
+def test_256_wide_pointwise_tiles_give_the_bits_of_the_128_wide_kernels():
+    """pw_wide_kernel<.., BN = 256> (1024 / 2048 / 256 output columns at many rows; SG_PW_WIDE=1) against conv_x6_kernel /
+    conv_b16_kernel on the same layers (SG_PW_WIDE=3: 384-wide tiles only): forward + statistics + dgrad, fp32 and bf16 storage -
+    the same products in the same order, so the same bits, whichever kernel a layer's batch size selects."""
+    narrow, wide = _bn_digests("3"), _bn_digests("1")
+    assert len(narrow) == 10 and len(wide) == 10, (len(narrow), len(wide))
+    assert narrow == wide, [(a, b) for a, b in zip(narrow, wide) if a != b]
