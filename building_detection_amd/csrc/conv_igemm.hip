@@ -1239,6 +1239,9 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
                            Cin * Cout, dgrad ? 1 : Cout, dgrad ? Cout : 1, NPL, K, pw_kd(NPL));
         SG_LAUNCH_CHECK("split3_weights_kernel");
       }
+      if constexpr (NPL == 3) {
+        if (wbn == 512) return launch_pw_wide<NPL, TA, 512>(p, st);
+      }
       return wbn == 256 ? launch_pw_wide<NPL, TA, 256>(p, st) : launch_pw_wide<NPL, TA, 384>(p, st);
     }
   }
@@ -1313,7 +1316,7 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
 inline size_t x6_ws_bytes(int taps, int C, int N) {
   const int k = taps > 1 ? taps * x6_vpad_c(C) : C;
   const size_t rows = x6_planes_bytes(k, N, 3, 64);   // (the deepest k-block any kernel asks for)
-  const size_t w384 = taps == 1 ? pw_planes_bytes(C, N, 3, 384) : 0, w256 = taps == 1 ? pw_planes_bytes(C, N, 3, 256) : 0;
+  const size_t w384 = taps == 1 ? pw_planes_bytes(C, N, 3, 384) : 0, w256 = taps == 1 ? pw_planes_bytes(C, N, 3, 512) : 0;   // (512 >= 256)
   const size_t wide = w384 > w256 ? w384 : w256;   // the wide pointwise kernel pads N to its tile width
   return rows > wide ? rows : wide;
 }

@@ -49,7 +49,7 @@ template <int NPL, typename TA, int BN = 384>
 __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
   static_assert((NPL == 3 && std::is_same<TA, float>::value) || (NPL == 1 && !std::is_same<TA, float>::value),
                 "x6 on fp32 storage, one plane on bf16 storage");
-  static_assert(BN == 384 || BN == 256, "tile width");
+  static_assert(BN == 384 || BN == 256 || BN == 512, "tile width");
   using G = PwGeom<NPL, BN>;
   constexpr int KS = G::KS, BKW = G::BKW, RB = G::RB, CPR = G::CPR;
   constexpr int WGM = 2, WGN = 4, WM = 64, WN = BN / WGN, TM = 2, TN = WN / 32;
@@ -387,7 +387,8 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
       asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // B(0) has landed; A(1) may still fly
       if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      if (p.ablate == 0 && p.stagger == 1) {   // the woven step with the barrier in the middle of the k-step
+      if (p.ablate == 0 && p.stagger == 1 && BN != 512) {   // the woven step with the barrier in the middle of the k-step (512-wide
+                                                              // tiles: its two fragment sets do not fit beside 128 accumulator registers)
         bf16x8_t pa0[3], pb0[3], pa1[3], pb1[3];
         // stage 1 is staged before the loop (the loop stages s + 2 during k-step s), A(2) goes into flight
         if (nk > 1) {
@@ -696,12 +697,28 @@ inline int pw_wide_bn(const IgemmParams& p, int eb) {
   if (g_sub_batch) return 0;
   if (on == 2) return PW_BN;
   if (p.K < 256 || p.M < 6144) return 0;
-  const int64_t ntn = sg_cdiv(p.Nout, PW_BN);
-  if ((double)p.Nout / (double)(ntn * PW_BN) >= 0.75) return PW_BN;
-  if (on == 3) return 0;
-  const int64_t ntn2 = sg_cdiv(p.Nout, 256);
-  if ((double)p.Nout / (double)(ntn2 * 256) >= 0.75 && sg_cdiv(p.M, PW_BM) * ntn2 >= 256) return 256;
-  return 0;
+  // Width by a two-line cost model: one workgroup per CU, so a launch takes ceil(tiles / CUs) rounds of a time proportional to
+  // the tile's width - 728 columns at 16384 rows: 384-wide tiles, one round; 1024 columns: 256-wide, two rounds (384-wide tiles
+  // were 384 workgroups = two rounds with the second half empty: 167 -> 128 us); 2048 and 512 columns: 256-wide.  A width must
+  // fill three quarters of its columns and, below 384, bring at least 192 tiles.  Ties go to 384, then 256.  SG_PW_WIDE=3: 384
+  // only.  SG_PW_512=1 adds 512-wide tiles (fp32 only: 128 accumulator registers, barrier at the end of the k-step): one round of
+  // them measured no better than two rounds of 256-wide ones (1024 -> 1024: 182 vs 178 us), so they are off.
+  static const int w512 = getenv("SG_PW_512") ? atoi(getenv("SG_PW_512")) : 0;
+  const int64_t ntm = sg_cdiv(p.M, PW_BM);
+  int best = 0;
+  int64_t best_cost = 0;
+  const int widths[3] = {384, 256, 512};
+  for (int i = 0; i < 3; ++i) {
+    const int bn = widths[i];
+    if (bn != 384 && on == 3) continue;
+    if (bn == 512 && (!w512 || eb != 4)) continue;
+    const int64_t ntn = sg_cdiv(p.Nout, bn), tiles = ntm * ntn;
+    if ((double)p.Nout / (double)(ntn * bn) < 0.75) continue;
+    if (bn != 384 && tiles < 192) continue;
+    const int64_t cost = sg_cdiv(tiles, 256) * bn;
+    if (!best || cost < best_cost) { best = bn; best_cost = cost; }
+  }
+  return best;
 }
 inline bool pw_wide_ok(const IgemmParams& p, int eb) { return pw_wide_bn(p, eb) != 0; }
 
