@@ -16,7 +16,7 @@ Prints ONE JSON line on rank 0.  Extra objects:
                (all of the model's conv FLOPs / their summed device time), from two extra steps after the timed
                region so that its ~600 event pairs do not sit inside the headline number.
   cpu_baseline the CPU oracle (restatement of the TF2 path; TF itself is unavailable) timed on this box's
-               host cores for the same step at a reduced batch.
+               host cores for the same step at bs 2: median of 5 steps after 2 warm-ups.
 """
 import argparse
 import json
@@ -34,73 +34,68 @@ LABEL = {"v3plus": "DeepLabv3+ (v3plus.py)", "bam": "DeepLabv3+ BAM (bam.py)", "
 DILATED_GFLOP_PER_TILE = 97.84  # fwd + dgrad + wgrad of the 6 dilated convs, SURVEY.md §8d
 
 
-def cpu_baseline(threads, batch, size, steps, model=None):
-    """One oracle training step (fwd + loss + bwd + Adam) per iteration on the host cores.  With `model` (the engine's
-    DeepLabv3+, after its timed steps) the same weights and tiles are also run through both in inference mode: the
-    metric's "mIoU vs TF2 CPU" leg, with the CPU oracle standing in for TF2 (absent here)."""
+def cpu_baseline(threads, batch, size, steps, model=None, warmup=2):
+    """the CPU oracle's training step (fwd + loss + bwd + Adam) on the host cores - `warmup` untimed
+    steps, then the MEDIAN of `steps` (>= 5) timed ones; `nproc`, the CPUs this process may run on and the threads used are
+    stated in the record.  With `model` (the engine's DeepLabv3+, after its timed steps) the same weights and tiles are also
+    run through both in inference mode: the metric's "mIoU vs TF2 CPU" leg, with the CPU oracle standing in for TF2 (absent)."""
+    import statistics
     import torch
     from oracle import models as M
     from building_detection_amd.data import synthetic_batch
-    torch.set_num_threads(threads)
-    x, y = synthetic_batch(batch, size, size, seed=1103)
-    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
-    P = M.Params(seed=1103)
-    times = []
-    m = v = None
-    for it in range(steps + 1):
-        t0 = time.time()
-        p = M.deeplab_v3plus(P, xt, training=True)
-        loss = M.loss_fn("edge_focal_loss", yt, p)
-        tr = P.trainable_tensors()
-        for t in tr:
-            t.grad = None
-        loss.backward()
-        if m is None:
-            m = [torch.zeros_like(t) for t in tr]
-            v = [torch.zeros_like(t) for t in tr]
-        M.adam_step(tr, [t.grad for t in tr], m, v, t=it + 1, lr=1e-3)
-        if it > 0:  # first iteration creates the parameters
-            times.append(time.time() - t0)
-    best = min(times)
-    out = {"value": round(batch / best, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
-           "sample": f"CPU oracle (restated TF2 semantics, torch CPU ops) DeepLabv3+ {size}x{size} bs={batch}, "
-                     f"min of {steps} full steps (fwd+loss+bwd+Adam), {best:.2f} s/step"}
-    # BASELINE.md section 3 extras, bounded: (a) the same step on ONE thread (one 256x256 tile: 1/8 of the bs-2 512x512
-    # sample's work), (b) BASELINE configs[0]: Res34-UNet 256x256 bs 2 on all threads
-    def one_step(fn, xs, ys, threads_, reps):
+
+    def timed_steps(fn, xs, ys, threads_, warm, reps):
+        """-> (Params, per-step seconds of the `reps` steps after `warm` untimed ones)"""
         torch.set_num_threads(threads_)
         Pq = M.Params(seed=1103)
-        best_ = None
+        ts = []
         mq = vq = None
-        for it in range(reps + 1):
+        for it in range(warm + reps):
             t0 = time.time()
-            pq = fn(Pq, xs, training=True)
-            lq = M.loss_fn("edge_focal_loss", ys, pq)
+            lq = M.loss_fn("edge_focal_loss", ys, fn(Pq, xs, training=True))
             trq = Pq.trainable_tensors()
             for t in trq:
                 t.grad = None
             lq.backward()
-            if mq is None:
+            if mq is None:   # the first iteration creates the parameters
                 mq, vq = [torch.zeros_like(t) for t in trq], [torch.zeros_like(t) for t in trq]
             M.adam_step(trq, [t.grad for t in trq], mq, vq, t=it + 1, lr=1e-3)
-            if it > 0:
-                dt_ = time.time() - t0
-                best_ = dt_ if best_ is None else min(best_, dt_)
+            if it >= warm:
+                ts.append(time.time() - t0)
         torch.set_num_threads(threads)
-        return best_
+        return Pq, ts
+
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        affinity = None
+    x, y = synthetic_batch(batch, size, size, seed=1103)
+    xt, yt = torch.from_numpy(x), torch.from_numpy(y)
+    P, times = timed_steps(lambda Pq, x_, training: M.deeplab_v3plus(Pq, x_, training=training), xt, yt, threads, warmup, steps)
+    med = statistics.median(times)
+    out = {"value": round(batch / med, 4), "unit": "tiles/s", "cores": threads, "kind": "port",
+           "nproc": os.cpu_count(), "cpus_allowed": affinity, "threads": threads,
+           "step_seconds": [round(t, 3) for t in times],
+           "bs16_step_seconds_extrapolated_linearly": round(med * 16 / batch, 2),
+           "sample": f"CPU restatement of the TF2 path (TF unavailable; oracle/, torch CPU ops) DeepLabv3+ {size}x{size} bs={batch}: "
+                     f"median of {steps} full steps (fwd+loss+bwd+Adam) after {warmup} warm-ups, {med:.2f} s/step on {threads} threads"}
+    # BASELINE.md section 3 extras, bounded: (a) the same step on ONE thread (one 256x256 tile: 1/8 of the bs-2 512x512
+    # sample's work; one timed step after one warm-up - five would take a minute), (b) BASELINE configs[0]: Res34-UNet
+    # 256x256 bs 2 on all threads, median of 5 after 2, (c) the dilated set alone
     try:
         xs1, ys1 = synthetic_batch(1, 256, 256, seed=1103)
-        t1 = one_step(lambda Pq, x_, training: M.deeplab_v3plus(Pq, x_, training=training, aspp_pool=16), torch.from_numpy(xs1),
-                      torch.from_numpy(ys1), 1, 1)
-        out["one_thread"] = {"value": round(0.25 / t1, 4), "unit": "512x512-tile equivalents/s", "cores": 1,
-                             "sample": f"DeepLabv3+ one 256x256 tile (a quarter of a 512x512 tile's work), full step, {t1:.2f} s"}
+        _, t1 = timed_steps(lambda Pq, x_, training: M.deeplab_v3plus(Pq, x_, training=training, aspp_pool=16), torch.from_numpy(xs1),
+                            torch.from_numpy(ys1), 1, 1, 1)
+        out["one_thread"] = {"value": round(0.25 / t1[0], 4), "unit": "512x512-tile equivalents/s", "cores": 1,
+                             "sample": f"DeepLabv3+ one 256x256 tile (a quarter of a 512x512 tile's work), one full step after one warm-up, {t1[0]:.2f} s"}
         xs2, ys2 = synthetic_batch(2, 256, 256, seed=1103)
-        t2 = one_step(lambda Pq, x_, training: M.res34_unet(Pq, x_, training=training), torch.from_numpy(xs2), torch.from_numpy(ys2),
-                      threads, 2)
-        out["config1_res34_256_bs2"] = {"value": round(2 / t2, 4), "unit": "256x256 tiles/s", "cores": threads,
-                                        "sample": f"BASELINE configs[0]: Res34-UNet 256x256 bs=2 full step, min of 2, {t2:.2f} s/step"}
+        _, t2 = timed_steps(lambda Pq, x_, training: M.res34_unet(Pq, x_, training=training), torch.from_numpy(xs2), torch.from_numpy(ys2),
+                            threads, 2, 5)
+        m2 = statistics.median(t2)
+        out["config1_res34_256_bs2"] = {"value": round(2 / m2, 4), "unit": "256x256 tiles/s", "cores": threads,
+                                        "sample": f"BASELINE configs[0]: Res34-UNet 256x256 bs=2 full step, median of 5 after 2 warm-ups, {m2:.2f} s/step"}
         # (c) the roofline kernel set on the CPU: the six dilated 3x3 convolutions (3 x 2048 -> 256, 3 x 256 -> 256 at 32 x 32,
-        # rates 6 / 12 / 18), forward + both gradients, bs 2, through the oracle's conv2d
+        # rates 6 / 12 / 18), forward + both gradients, bs 2, through the oracle's conv2d; median of 3 after one warm-up
         from oracle import tfops as T
         gq = torch.Generator().manual_seed(3)
         tt = 0.0
@@ -108,14 +103,15 @@ def cpu_baseline(threads, batch, size, steps, model=None):
             for rate in (6, 12, 18):
                 xq = torch.randn(2, 32, 32, cin, generator=gq).requires_grad_()
                 wq = (torch.randn(3, 3, cin, 256, generator=gq) * 0.02).requires_grad_()
-                for rep in range(2):
+                reps = []
+                for rep in range(4):
                     xq.grad = wq.grad = None
                     t0 = time.time()
                     T.conv2d(xq, wq, None, 1, rate, "same").sum().backward()
-                    dtq = time.time() - t0
-                tt += dtq   # the second repetition
+                    reps.append(time.time() - t0)
+                tt += statistics.median(reps[1:])
         out["dilated_set"] = {"value": round(DILATED_GFLOP_PER_TILE * 2 / 1e3 / tt, 4), "unit": "TFLOP/s (nominal)", "cores": threads,
-                              "sample": f"the six dilated 3x3 convolutions fwd + dgrad + wgrad, bs=2, {tt:.2f} s"}
+                              "sample": f"the six dilated 3x3 convolutions fwd + dgrad + wgrad, bs=2 (bs 16 = 8x), median of 3 after 1, {tt:.2f} s"}
     except Exception as e:  # extras never take the main figure down
         out["extras_error"] = repr(e)
     if model is not None:
@@ -447,7 +443,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             threads = args.cpu_threads or min(os.cpu_count() or 1, 16)
             try:
-                out["cpu_baseline"] = cpu_baseline(threads, 2, args.size, 2, model if args.model == "v3plus" else None)
+                out["cpu_baseline"] = cpu_baseline(threads, 2, args.size, 5, model if args.model == "v3plus" else None)
                 if b16 and "parity" in out["cpu_baseline"]:
                     out["cpu_baseline"]["parity"]["what"] += " (bf16 engine vs the fp32 oracle: the tolerance contract of DESIGN.md section 8, not the 1e-3 fp32 bar)"
             except Exception as e:  # the baseline must never take the GPU number down with it

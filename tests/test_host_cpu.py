@@ -76,6 +76,14 @@ def test_abi_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_lib.LIB_PATH)
     for name in declared:
         assert hasattr(lib, name), f"{name} is declared in include/segengine.h but not exported"
+    # ... and the other direction: every sg_* symbol the built library defines is declared in the header
+    # (whatever its return type: sg_mask_split_words returns int64_t, the *_ws_bytes family size_t)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], stdout=subprocess.PIPE, check=True).stdout.decode()
+    exported = {l.split()[-1] for l in nm.splitlines() if l.split() and l.split()[-1].startswith("sg_")}
+    assert exported, "nm found no sg_* symbols"
+    assert exported - declared == set(), f"exported by libsegengine.so but not declared in include/segengine.h: {sorted(exported - declared)}"
+    assert declared - exported == set(), f"declared but not defined by the library: {sorted(declared - exported)}"
     assert _lib.load().sg_abi_version() == 1
     assert ctypes.sizeof(_lib.ConvDesc) == 15 * 4
 
@@ -146,7 +154,19 @@ def test_metrics_float32_arithmetic():
 
     def binary_crossentropy(y_true, y_pred):  # a reference-style callable is recognised by name
         pass
-    assert resolve_loss(binary_crossentropy) == 0
+    import warnings
+    from building_detection_amd.losses import ForeignCallableWarning, MIoU
+    with pytest.warns(ForeignCallableWarning, match="selects its fused kernel by NAME"):   # ... but no longer silently
+        assert resolve_loss(binary_crossentropy) == 0
+
+    def F1_score(y_true, y_pred):
+        pass
+    with pytest.warns(ForeignCallableWarning, match="530-623"):
+        assert resolve_metric(F1_score) == "F1_score"
+    with warnings.catch_warnings():   # the engine's own objects and plain names stay quiet
+        warnings.simplefilter("error")
+        assert resolve_loss(edge_focal_loss) == 2 and resolve_loss("edge_focal_loss") == 2
+        assert resolve_metric(MIoU) == "MIoU"
     assert resolve_metric("MIoU") == "MIoU"
     with pytest.raises(ValueError):
         resolve_loss("mse")
