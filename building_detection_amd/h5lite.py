@@ -1,4 +1,4 @@
-"""A minimal HDF5 reader / writer for Keras weight files (h5py is not available in this image).
+"""A minimal HDF5 reader / writer for Keras weight files (h5py is not available in this image, libhdf5 only as a test-side checker).
 
 The reference loads `resnet34.h5 ... bam.h5` with `model.load_weights` (predict.py:21-49) and writes
 `epoch_N_weights.h5` with `model.save_weights` (train_model/DeepLabv3plus.py:778-780).  Those are HDF5 files in the
@@ -12,10 +12,17 @@ layout h5py writes by default (libver "earliest"), which is all this module cove
     write   superblock v0, object headers v1, old-style groups, contiguous little-endian datasets, attributes v1 holding
             scalars, numeric arrays or arrays of fixed-length byte strings - the subset `keras save_weights` produces.
 
-Written from the HDF5 File Format Specification (version 3.0 of the specification, sections II-IV).  PINNING: there is no
-h5py / libhdf5 here to cross-check against, so what the tests pin is (a) write -> read round trips, (b) a hand-assembled
-byte-level fixture built in the test from the specification's field tables, independent of the writer.  Files written by
-real Keras are expected to load; until one has been tried this is unverified and `weights_io` says so in its errors.
+Written from the HDF5 File Format Specification (version 3.0 of the specification, sections II-IV).  PINNING: h5py and Keras
+are not in this image, but a real HDF5 library is (/opt/conda/lib/libhdf5.so.103 = HDF5 1.10.6, with h5dump) - round 4's
+note here said otherwise and was wrong.  tests/test_h5_libhdf5_cpu.py binds it with ctypes (tests/_libhdf5.py) and checks
+both directions at the scale of the real models: files this writer produces for all five graphs (DeepLabv3+: 203 layer
+groups, 652 datasets) are opened by libhdf5 and every dataset (class, size, byte order, contiguous layout, shape, values)
+and name-list attribute compared, and h5dump walks them; Keras-2-layout files assembled by libhdf5 with the calls h5py
+makes (old format with multi-node symbol-table B-trees, name lists split over layer_names0.., the `model.save()` layout,
+h5py-3 variable-length strings, the newest file format with compact groups) are loaded by this reader; densely stored
+groups (newest format, > 8 links: never what Keras' default writes) are refused with the reason.  Beside that: write ->
+read round trips and two hand-assembled byte-level fixtures (tests/test_weights_io_cpu.py).  What remains unverified is a
+file written by Keras itself (none exists here).
 """
 from __future__ import annotations
 

@@ -12,8 +12,9 @@ path ending in `.h5` / `.hdf5` / `.keras.h5` is written in that layout, so a Ker
 `load_weights` it; any other suffix gets the engine's native container (safetensors, one entry per weight).  Loading
 sniffs the file: HDF5 signature -> Keras layout, else safetensors.  A missing file raises OSError, the only error the
 reference handles (predict.py:23); an HDF5 file outside the supported subset raises OSError / NotImplementedError with the
-reason.  UNPINNED: no real Keras file has been read by this code (none exists here, nor h5py to make one); the tests pin
-the writer against the reader and the reader against a byte-level fixture assembled from the specification.
+reason.  PINNED against a real HDF5 library in both directions (libhdf5 1.10.6 through ctypes, tests/test_h5_libhdf5_cpu.py: the five
+models' files written here read back value for value by libhdf5 / h5dump, and Keras-layout files assembled by libhdf5 at
+DeepLabv3+ scale loaded here); NOT yet against a file written by Keras itself (none exists in this image).
 
 Layer matching: `_match_layers` - exact layer names, else (layer class, ordinal within the class), position only as a
 last resort and with a warning (Keras orders `model.layers` by graph depth, this engine by creation; a positional fit of

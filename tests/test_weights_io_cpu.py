@@ -1,6 +1,7 @@
 """Keras HDF5 weight files without h5py (building_detection_amd/h5lite.py, weights_io.py).
 
-UNPINNED against real Keras / h5py output (neither exists in this image).  What is pinned: the writer against the reader,
+Real Keras / h5py output does not exist in this image; the cross-check against the real HDF5 library that does
+(libhdf5 1.10.6) is tests/test_h5_libhdf5_cpu.py.  What is pinned HERE: the writer against the reader,
 the reader against two byte-level files assembled HERE from the field tables of the HDF5 File Format Specification
 (independent of the writer: one in the old format Keras' files use - superblock 0, symbol-table groups, v1 headers - and one
 in the new format - superblock 2, OHDR headers, link messages, compact data, variable-length string attribute), and the
