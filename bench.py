@@ -158,12 +158,18 @@ def bf16_leg(args):
         return {"error": repr(e)}
 
 
-def spawn_ranks(n: int) -> int:
-    """Start `n` copies of this script as ranks 0..n-1 of one job (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
-    environment, rendezvous on 127.0.0.1), wait for them, return the worst exit code.  Rank 0's stdout (the JSON
-    line) is passed through; the other ranks' stdout goes to stderr."""
+def spawn_ranks(n: int, script: str = None, argv=None, grace_s: float = None) -> int:
+    """Start `n` copies of `script` (default: this file, with this process's arguments) as ranks 0..n-1 of one job (RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1), wait for them, return the worst exit
+    code.  Rank 0's stdout (the JSON line) is passed through; the other ranks' stdout goes to stderr.  A rank that ends with
+    a non-zero code leaves the others inside a collective it will never join: they get `grace_s` seconds (SG_SPAWN_GRACE,
+    default 20) to notice and exit by themselves, then exactly the children started here are terminated (killed if they
+    ignore that) - the job never hangs, and its exit code is the first failure's.  The parent never touches the GPU."""
     import socket
     import subprocess
+    script = os.path.abspath(__file__) if script is None else script
+    argv = sys.argv[1:] if argv is None else list(argv)
+    grace_s = float(os.environ.get("SG_SPAWN_GRACE", "20")) if grace_s is None else grace_s
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -171,16 +177,38 @@ def spawn_ranks(n: int) -> int:
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+        procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
                                       stdout=_JSON_FD if r == 0 else sys.stderr))  # rank 0 gets the REAL stdout
-    rc = 0
+    rc, deadline = 0, None
     try:
-        for p in procs:
-            rc = max(rc, abs(p.wait()))
+        while True:
+            codes = [p.poll() for p in procs]
+            for r, c in enumerate(codes):
+                if c not in (None, 0) and deadline is None:
+                    rc = abs(c) or 1
+                    deadline = time.time() + grace_s
+                    print(f"[bench] rank {r} exited with code {c}; the other ranks have {grace_s:.0f} s to follow", file=sys.stderr)
+            if all(c is not None for c in codes):
+                break
+            if deadline is not None and time.time() > deadline:
+                break
+            time.sleep(0.05)
+        for c in (p.poll() for p in procs):
+            if c not in (None, 0):
+                rc = max(rc, abs(c))
     finally:
-        for p in procs:  # a rank that died leaves the others in a collective: end exactly the children we started
-            if p.poll() is None:
-                p.terminate()
+        left = [p for p in procs if p.poll() is None]
+        for p in left:  # a rank that died leaves the others in a collective: end exactly the children we started
+            p.terminate()
+        for p in left:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+        if left:
+            rc = max(rc, 1)
+            print(f"[bench] terminated {len(left)} rank(s) that were still running", file=sys.stderr)
     return rc
 
 
@@ -280,7 +308,16 @@ def main():
         args.warmup = 3   # two eager steps per shape, the third call captures (and replays) the graph
     if dist is not None:
         from building_detection_amd.dist import DataParallel
-        dp = DataParallel(model, comm="sg_or_torch" if args.comm == "sg" else "torch")
+        from building_detection_amd.dist import CommInitError
+        try:
+            dp = DataParallel(model, comm="sg_or_torch" if args.comm == "sg" else "torch")
+        except CommInitError as e:
+            # ncclCommInitRank failed or timed out on some rank; EVERY rank is here (dist.SgTransport).  A thread of this
+            # process may still sit inside RCCL: no clean-up, no re-exec (this process has touched the GPU) - end it with a
+            # non-zero code; the launcher (spawn_ranks / torchrun) reports the job as failed and fresh processes retry.
+            print(f"[bench] rank {rank}: {e}", file=sys.stderr)
+            sys.stderr.flush()
+            os._exit(13)
         args.comm = dp.tp.name   # what actually carries the gradients ("sg" may have fallen back to "torch")
 
     # rank r takes tiles [16 r, 16 r + 16) of the global synthetic batch (weak scaling)

@@ -133,6 +133,7 @@ _SIGNATURES = {
     "sg_fill_f32": (_i, [_vp, _vp, _vp, _i64, _f]),
     "sg_trace_mark": (_i, [_vp, _vp, _i, _i]),
     "sg_scale_f32": (_i, [_vp, _vp, _vp, _i64, _f]),
+    "sg_comm_probe": (_i, [_vp]),
     "sg_comm_unique_id": (_i, [_vp]),
     "sg_comm_init": (_i, [_vp, _i, _i, _i, _pp]),
     "sg_comm_allreduce_sum": (_i, [_vp, _vp, _i, _vp, _i64]),

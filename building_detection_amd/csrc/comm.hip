@@ -23,6 +23,7 @@ typedef int (*fn_comm_init_rank)(Comm*, int, UniqueId, int);
 typedef int (*fn_all_reduce)(const void*, void*, size_t, int, int, Comm, hipStream_t);
 typedef int (*fn_comm_destroy)(Comm);
 typedef const char* (*fn_get_error_string)(int);
+typedef int (*fn_get_version)(int*);
 
 struct Rccl {
   void* handle = nullptr;
@@ -31,6 +32,7 @@ struct Rccl {
   fn_all_reduce all_reduce = nullptr;
   fn_comm_destroy comm_destroy = nullptr;
   fn_get_error_string get_error_string = nullptr;
+  fn_get_version get_version = nullptr;
 };
 
 Rccl g_rccl;
@@ -50,6 +52,7 @@ void rccl_load() {
   g_rccl.all_reduce = (fn_all_reduce)dlsym(h, "ncclAllReduce");
   g_rccl.comm_destroy = (fn_comm_destroy)dlsym(h, "ncclCommDestroy");
   g_rccl.get_error_string = (fn_get_error_string)dlsym(h, "ncclGetErrorString");
+  g_rccl.get_version = (fn_get_version)dlsym(h, "ncclGetVersion");
   if (!g_rccl.get_unique_id || !g_rccl.comm_init_rank || !g_rccl.all_reduce || !g_rccl.comm_destroy) return;
   g_rccl.handle = h;  // published last: a non-null handle means every entry point above is resolved
 }
@@ -74,6 +77,23 @@ struct sg_comm {
 };
 
 extern "C" {
+
+int sg_comm_probe(int* version_out) {
+  // "is there a usable RCCL in this process": dlopen + symbol resolution + ncclGetVersion - no bootstrap root, no listener
+  // thread, no socket (ncclGetUniqueId creates all three; only the rank that hands its id out should pay for them)
+  const Rccl* r = rccl();
+  if (!r) {
+    sg_set_error("sg_comm_probe: librccl.so.1 not found (dlopen): %s", dlerror());
+    return SG_EUNSUPPORTED;
+  }
+  int v = 0;
+  if (r->get_version) {
+    const int rc = r->get_version(&v);
+    if (rc != 0) return rccl_fail(r, "ncclGetVersion", rc);
+  }
+  if (version_out) *version_out = v;
+  return 0;
+}
 
 int sg_comm_unique_id(void* id_out) {
   SG_CHECK_ARG(id_out != nullptr, "sg_comm_unique_id: null id");

@@ -97,6 +97,16 @@ __global__ __launch_bounds__(256) void seg_reduce_kernel(const Op op, const int6
   if (S > 1) {
     __shared__ int s_last;
     if (wt) {
+      // fuse == 3 (ADVICE r4 asked for a release here, or the reason why none is needed).  The reason: this is the
+      // write-through hand-off of MI355X_MICROARCH.md, "Valid forms", first row of its table - EVERY handed-off byte is
+      // stored sc1 (the agent-scope relaxed atomic stores above compile to global_store_dword ... sc1: they go through to the
+      // fabric, nothing is left dirty in this XCD's L2 for a release to write back), every storing wave drains them
+      // (s_waitcnt vmcnt(0)), the workgroup barrier below puts the ONE signalling lane behind every wave's drain, its
+      // agent-scope atomic add returns the arrival count, and only the workgroup whose add came last reads - behind an agent
+      // ACQUIRE (kept, stricter than the table's sc1 loads).  An agent-scope RELEASE on the add would put buffer_wbl2 (write
+      // back this XCD's whole L2) into ~1000 workgroups per launch - the 25 ms that mode 2 costs and this mode exists to
+      // avoid.  tests/test_ops_gpu.py::test_fused_second_stage_of_the_reductions_is_bit_identical runs mode 3 against mode 0
+      // on multi-slab BatchNormalization / depthwise filter-gradient reductions, bit for bit.  Off by default (no gain).
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores ...
     } else {
       // release only: round 2 used __threadfence() (acquire AND release at agent scope: write back and invalidate this XCD's

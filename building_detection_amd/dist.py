@@ -80,10 +80,65 @@ class TorchTransport:
 
 
 def _unique_id(lib, _lib) -> bytes:
-    """The 128 opaque bytes of an RCCL unique id (sg_comm_unique_id); raises SgError when RCCL cannot be loaded."""
+    """The 128 opaque bytes of an RCCL unique id (sg_comm_unique_id); raises SgError when RCCL cannot be loaded.  Rank 0
+    only: ncclGetUniqueId starts a bootstrap root (listener thread + socket) that lives as long as the process."""
     buf = C.create_string_buffer(_lib.SG_COMM_ID_BYTES)
     _lib.check(lib.sg_comm_unique_id(buf), "sg_comm_unique_id")
     return bytes(buf.raw)
+
+
+def _probe(lib, _lib) -> int:
+    """Can THIS process load a usable RCCL (sg_comm_probe: dlopen + ncclGetVersion)?  Local, no bootstrap root, no socket -
+    what every rank other than 0 calls (they used to draw and discard a unique id, leaking a listener thread
+    and a port per rank, and could fail for network-interface reasons that have nothing to do with "library missing")."""
+    v = C.c_int(0)
+    _lib.check(lib.sg_comm_probe(C.byref(v)), "sg_comm_probe")
+    return int(v.value)
+
+
+class CommInitError(RuntimeError):
+    """sg_comm_init (ncclCommInitRank) failed or timed out on at least one rank.  EVERY rank raises this after the same
+    host-side exchange.  `stuck` is True on a rank whose own call never returned: its thread is still inside RCCL and
+    cannot be cancelled, so the process must END (os._exit in bench.py) - never be re-used or re-exec'ed, it has touched
+    the GPU - and the job be restarted as fresh processes."""
+
+    def __init__(self, msg, stuck=False):
+        super().__init__(msg)
+        self.stuck = stuck
+
+
+def _init_timeout_s() -> float:
+    import os
+    return float(os.environ.get("SG_COMM_INIT_TIMEOUT", "180"))
+
+
+def _comm_init(lib, _lib, uid, rank, world, device_index, timeout_s):
+    """sg_comm_init on a worker thread, bounded by `timeout_s`.  -> (handle | None, error text | None, stuck).
+    ncclCommInitRank is a collective with no timeout of its own: if ONE rank fails inside it (a fabric fault, a device it
+    cannot open) the others wait for ever.  The call therefore runs on a daemon thread (ctypes drops the GIL; sg_comm_init
+    sets the device itself, and a communicator may be used from another thread than the one that made it) while this
+    thread waits with a deadline; sg_last_error() is thread-local, so the message is taken on the worker."""
+    import threading
+    box = {}
+
+    def work():
+        h = C.c_void_p()
+        rc = lib.sg_comm_init(uid, rank, world, device_index, C.byref(h))
+        msg = None
+        if rc != 0:
+            try:
+                msg = lib.sg_last_error().decode("utf-8", "replace")
+            except Exception:
+                msg = "?"
+        box.update(rc=rc, h=h, msg=msg)
+    th = threading.Thread(target=work, name="sg_comm_init", daemon=True)
+    th.start()
+    th.join(timeout_s)
+    if th.is_alive():
+        return None, f"sg_comm_init did not return within {timeout_s:.0f} s (SG_COMM_INIT_TIMEOUT)", True
+    if box["rc"] != 0:
+        return None, f"sg_comm_init failed ({box['rc']}): {box['msg']}", False
+    return box["h"], None, False
 
 
 class SgTransport:
@@ -102,25 +157,41 @@ class SgTransport:
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
         self.device = torch.device("cuda", device) if isinstance(device, int) else device
-        # EVERY rank probes its own RCCL first (sg_comm_unique_id: dlopen + a local ncclGetUniqueId, no communication; the one
-        # failure DataParallel's "sg_or_torch" fallback exists for is "no usable librccl for dlopen"), then all ranks exchange
-        # (ok, message) AND rank 0's id in ONE collective.  Only when every rank is ready does anybody enter sg_comm_init
-        # (ncclCommInitRank, itself a collective): a rank whose library is missing can therefore never leave the others
-        # waiting inside ncclCommInitRank, and all ranks raise the same error after the same collective.  (A failure INSIDE
-        # ncclCommInitRank - a fabric fault - is RCCL's to report on every rank; it is not the fallback's case.)
+        # Step 1 - readiness.  EVERY rank probes its own RCCL first, locally (rank 0 by drawing the id: sg_comm_unique_id;
+        # the others with sg_comm_probe = dlopen + ncclGetVersion, no bootstrap root; the one failure DataParallel's
+        # "sg_or_torch" fallback exists for is "no usable librccl for dlopen"), then all ranks exchange (ok, message) AND
+        # rank 0's id in ONE host-side collective.  Only when every rank is ready does anybody enter sg_comm_init
+        # (ncclCommInitRank, itself a collective): a rank whose library is missing can never leave the others waiting inside
+        # it, and all ranks raise the same error after the same collective.
         mine = [None, None]
         try:
-            mine[0] = _unique_id(self.lib, _lib)
+            mine[0] = _unique_id(self.lib, _lib) if self.rank == 0 else (_probe(self.lib, _lib) >= 0)
         except Exception as e:
             mine[1] = f"{type(e).__name__}: {e}"
         everyone = [None] * self.world
         dist.all_gather_object(everyone, (mine[0] if self.rank == 0 else (mine[0] is not None), mine[1]), group=group)
         bad = [(r, m) for r, (ok, m) in enumerate(everyone) if not ok]
         if bad:
-            raise _lib.SgError("sg_comm_unique_id failed on rank(s) " + ", ".join(f"{r}: {m}" for r, m in bad))
+            raise _lib.SgError("RCCL is not usable (sg_comm_unique_id / sg_comm_probe) on rank(s) " + ", ".join(f"{r}: {m}" for r, m in bad))
         uid = everyone[0][0]
-        h = C.c_void_p()
-        _lib.check(self.lib.sg_comm_init(uid, self.rank, self.world, self.device.index, C.byref(h)), "sg_comm_init")
+        # Step 2 - the communicator, with a deadline.  A failure INSIDE ncclCommInitRank on one rank used
+        # to leave the others in that collective for ever.  Now every rank's call is bounded (_comm_init), the outcomes are
+        # exchanged on the host, and if ANY rank failed or timed out, ALL raise CommInitError - a rank that failed at once
+        # reaches the exchange first and waits there (the host group's own timeout bounds that) until the stuck ranks'
+        # deadlines bring them along.  Nobody is left hanging; callers exit non-zero (bench.py) and the job restarts as
+        # fresh processes.
+        h, err, stuck = _comm_init(self.lib, _lib, uid, self.rank, self.world, self.device.index, _init_timeout_s())
+        outcomes = [None] * self.world
+        dist.all_gather_object(outcomes, err, group=group)
+        failed = [(r, m) for r, m in enumerate(outcomes) if m is not None]
+        if failed:
+            if h is not None:
+                try:
+                    self.lib.sg_comm_destroy(h)
+                except Exception:
+                    pass
+            raise CommInitError("RCCL communicator not established; every rank gives up together - " +
+                                "; ".join(f"rank {r}: {m}" for r, m in failed), stuck=stuck)
         self.h = h
         self.stream = torch.cuda.Stream(self.device)
         self._pending = False
@@ -179,8 +250,9 @@ def make_transport(comm: str, device, group=None, fallback_backend: str = "nccl"
     torch.distributed when libsegengine cannot bring RCCL up on ANY rank.  The decision is a collective: in
     SgTransport.__init__ every rank probes its own librccl and all ranks exchange the outcome before anybody calls
     ncclCommInitRank, so either all ranks construct the transport or all raise the same error; the summed flag below then
-    only confirms that they take the same branch.  What this does NOT cover: a failure inside ncclCommInitRank itself (all
-    ranks are in that collective together; RCCL reports or times out on every rank).  `fallback_backend` is "nccl" in
+    only confirms that they take the same branch.  A failure or hang INSIDE ncclCommInitRank is not a fallback case: the call
+    is bounded by SG_COMM_INIT_TIMEOUT on every rank, the outcomes are exchanged, and all ranks raise CommInitError together
+    (the caller exits non-zero; a rank whose call never returned has `stuck` set and must end its process).  `fallback_backend` is "nccl" in
     production; the CPU tests pass "gloo"."""
     import torch
     import torch.distributed as dist
@@ -193,6 +265,8 @@ def make_transport(comm: str, device, group=None, fallback_backend: str = "nccl"
     tp, err = None, None
     try:
         tp = SgTransport(device, group)
+    except CommInitError:   # ncclCommInitRank failed / timed out somewhere: the fabric is in doubt and threads may be stuck
+        raise               # inside RCCL - not a case for a fallback onto the same RCCL; every rank raises this together
     except Exception as e:  # e.g. no usable librccl for dlopen
         err = e
     if comm == "sg":

@@ -230,9 +230,13 @@ class _SepConvNode(Node):
             src = self.bnsum_src
             sv = rt._saved.get(id(src)) if src is not None else None
             # (through a residual add - src.defer_add - the gradient must be complete here: nothing left in the sweep's table)
+            bn_x = rt.values.get(id(src.inputs[0])) if src is not None else None
+            # (the kernel reads the BatchNormalization's raw input as a dense tensor of dt's storage type, pixel stride = C:
+            # another dtype or a strided view takes the unfused pair dwconv_dgrad + bn_train_bwd instead of wrong sums)
             if (sv is not None and "mean" in sv and e.dwconv_dgrad_acc_ok(ddw) and dt.dtype == x.dtype
+                    and bn_x is not None and bn_x.dtype == dt.dtype and bn_x.is_contiguous() and tuple(bn_x.shape) == tuple(x.shape)
                     and (rt._pending is None or id(root) not in rt._pending)):
-                dx = e.dwconv_dgrad_bnsums(dt, rt.param(self.dw), ddw, rt.values[id(src.inputs[0])], sv["mean"], sv["invstd"],
+                dx = e.dwconv_dgrad_bnsums(dt, rt.param(self.dw), ddw, bn_x, sv["mean"], sv["invstd"],
                                            rt.param(src.gamma), rt.param(src.beta), src.relu, rt.grad(src.gamma),
                                            rt.grad(src.beta), x=x, pre_relu=self.pre_relu, res=res)
                 sv["sums_done"] = True

@@ -143,8 +143,10 @@ class Model:
         # to the raw tensor (sg_dwconv2d_fwd_bn / _wgrad_bn), so the normalised tensor is never written or read - two of the
         # layer's seven tensor passes.  Needs the statistics from the producing convolution's epilogue (decided at run
         # time: _BNNode.forward falls back to the materialising form) and the stride-1 run kernels' geometry.
-        # Default OFF: measured on the DeepLabv3+ step the 39 dropped bn_apply launches save 1.05 ms and the
-        # depthwise kernels, which are instruction- not bandwidth-bound, give 0.8 ms of it back (fp32 -0.3 ms, bf16 0.0).
+        # Default ON since round 4 (SG_BN_DEFER=0 restores the materialising form; tests/test_models_gpu.py keeps one leg on it).
+        # Round 2 measured "no net gain" (the 39 dropped bn_apply launches saved 1.05 ms and the depthwise kernels of that
+        # round gave 0.8 ms of it back); re-measured on the round-3 run kernels: 76.59 -> 75.71 and 76.96 -> 75.93 ms per fp32
+        # step, bit-identical, peak memory -2.7 GiB (LAB_NOTEBOOK.md 11.2).
         # BatchNormalization (no ReLU) -> two-operand Add: the residual adds of the Xception blocks sum a normalised branch and
         # the shortcut (itself a normalised 1x1 convolution in the entry / exit flow).  The Add applies the normalisation while
         # it sums (sg_add2_bn), the normalised tensor is never written or read: one of the layer's two forward passes
@@ -640,7 +642,12 @@ class GraphedTrainStep:
         cuts = _SegmentCuts(dist.reducer.buckets) if dist is not None else None
         lane = _Lane() if lanes else None
         state = {"ctx": None, "graph": None}
-        mode = "thread_local" if segmented else "global"
+        # every capture is "thread_local" (ADVICE r4): a HIP call from ANOTHER thread during the capture - a DataLoader's
+        # pin-memory thread, a Flask predict thread waiting on the Engine lock - must not invalidate it.  The side graphs W_k
+        # replay one after the other on the side stream, so they share ONE private pool of their own (never the main graphs':
+        # W_k runs beside M_(k+1)) instead of one pool each.
+        side_pool = torch.cuda.graph_pool_handle() if lanes else None
+        mode = "thread_local"
 
         def begin():
             if len(self.segments) >= 2:   # the replay makes this segment wait for W_(k-2): its operands may be reused from here on
@@ -662,7 +669,7 @@ class GraphedTrainStep:
                 eng.lane = None          # (the calls below ARE the deferred ones)
                 eng._in_side = True      # their scratch is the side buffer
                 try:
-                    with torch.cuda.graph(side_graph, capture_error_mode=mode):
+                    with torch.cuda.graph(side_graph, pool=side_pool, capture_error_mode=mode):
                         for fn in thunks:
                             fn()
                 finally:

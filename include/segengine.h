@@ -449,6 +449,9 @@ int sg_scale_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float a);
  * this is the new exchange step of SURVEY.md 8e — one process per GPU, identical replicas, rank r trains on its
  * own tiles, the flat gradient arena is summed over the ranks once per step (RCCL over xGMI), 1/nranks folded
  * into sg_adam_step's grad_scale.  RCCL is resolved with dlopen at the first call (SG_EUNSUPPORTED if absent).
+ *   sg_comm_probe       any rank, local: can this process load a usable RCCL (dlopen + ncclGetVersion; *version_out may
+ *                       be null)?  No bootstrap root, thread or socket is created - what every rank other than 0 calls
+ *                       before the ranks agree to enter sg_comm_init.
  *   sg_comm_unique_id   rank 0 only: writes SG_COMM_ID_BYTES opaque bytes the caller hands to every rank.
  *   sg_comm_init        collective over the nranks processes; binds to `device`.
  *   sg_comm_allreduce_sum  in-place sum of buf[count] (SG_F32 / SG_BF16 / SG_I64) over the ranks, queued on
@@ -457,6 +460,7 @@ int sg_scale_f32(sg_ctx* ctx, void* stream, void* p, int64_t n, float a);
  *   sg_comm_destroy     frees the communicator. */
 #define SG_COMM_ID_BYTES 128
 typedef struct sg_comm sg_comm;
+int sg_comm_probe(int* version_out);
 int sg_comm_unique_id(void* id_out);
 int sg_comm_init(const void* id, int rank, int nranks, int device, sg_comm** out);
 int sg_comm_allreduce_sum(sg_comm* comm, void* stream, int dtype, void* buf, int64_t count);

@@ -2,6 +2,7 @@
 builders, the C-ABI library (loads, exports every symbol include/segengine.h declares), LR schedule,
 callbacks, metrics arithmetic, synthetic data, fusion pass, gradient bucketing and a world_size-2 gloo run of
 the data-parallel reducer."""
+import json
 import os
 import re
 import sys
@@ -362,7 +363,8 @@ def _fallback_worker(rank, world, port, q, fail_rank):
 
     def fake_id(lib, _l):   # a rank whose RCCL is fine (never used: the readiness exchange fails first)
         return bytes(_l.SG_COMM_ID_BYTES)
-    D._unique_id = no_rccl if rank == fail_rank else fake_id   # every rank probes its own library
+    D._unique_id = no_rccl if rank == fail_rank else fake_id   # every rank probes its own library: rank 0 by drawing the id,
+    D._probe = no_rccl if rank == fail_rank else (lambda lib, _l: 21800)   # the others with sg_comm_probe (no bootstrap root)
     # comm="sg": every rank raises the SAME error, after the same collective, and nobody has entered sg_comm_init ...
     try:
         D.make_transport("sg", 0)
@@ -406,6 +408,132 @@ def test_sg_comm_failure_on_one_rank_keeps_the_ranks_in_step_gloo_world2(fail_ra
         assert same_error, f"rank {rank} did not see rank {fail_rank}'s sg_comm_unique_id failure"
         assert s == 3.0
         assert name == "torch" and g == [3.0] * 5
+
+
+def _comm_init_worker(rank, world, port, q, mode):
+    """rank 1's sg_comm_init fails at once (an RCCL error inside ncclCommInitRank); rank 0's never returns (it waits for a peer
+    that has gone).  mode 'raise': report what was raised; mode 'exit': do what bench.py does - os._exit(13)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), SG_COMM_INIT_TIMEOUT="2")
+    import datetime
+    import time
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from building_detection_amd import _lib, dist as D
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+
+    class FakeLib:   # the four entry points SgTransport.__init__ reaches before it owns a communicator
+        def sg_comm_init(self, uid, r, w, dev, out):
+            if r == 1:
+                return _lib.SG_ECOMM if hasattr(_lib, "SG_ECOMM") else -4
+            time.sleep(600)   # rank 0: inside ncclCommInitRank for ever
+            return 0
+
+        def sg_last_error(self):
+            return b"ncclCommInitRank: RCCL error 2 (unhandled system error) [test]"
+
+        def sg_comm_destroy(self, h):
+            return 0
+    D._unique_id = lambda lib, _l: bytes(_l.SG_COMM_ID_BYTES)
+    D._probe = lambda lib, _l: 21800
+    _lib.load = lambda: FakeLib()
+    t0 = time.time()
+    try:
+        D.make_transport("sg_or_torch", 0, fallback_backend="gloo")   # the fallback must NOT swallow this
+        out = ("no error", False, "")
+    except D.CommInitError as e:
+        out = ("CommInitError", e.stuck, str(e))
+    dt = time.time() - t0
+    if mode == "exit":
+        os._exit(13 if out[0] == "CommInitError" else 0)
+    q.put((rank, out, dt))
+    q.close()
+    q.join_thread()   # the queue's feeder thread has flushed; os._exit would cut it off
+    os._exit(0)   # rank 0's worker thread is still "inside RCCL": the process ends without joining it, as bench.py does
+
+
+def test_a_failure_inside_comm_init_on_one_rank_ends_every_rank_gloo_world2():
+    """a rank that fails INSIDE ncclCommInitRank used to leave the others in that collective for
+    ever.  sg_comm_init now runs against a deadline on every rank (SG_COMM_INIT_TIMEOUT), the outcomes are exchanged on the
+    host, and all ranks raise CommInitError together - the rank that failed at once waits in the exchange until the stuck
+    rank's deadline brings it along.  The stuck rank knows it is stuck (its process must end, never be re-used)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_comm_init_worker, args=(r, 2, port, q, "raise")) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=120) for _ in procs)
+    finally:
+        for p in procs:
+            p.join(timeout=30)
+            if p.is_alive():
+                p.terminate()
+    for rank, (kind, stuck, msg), dt in res:
+        assert kind == "CommInitError", (rank, kind)
+        assert "rank 0: sg_comm_init did not return within 2 s" in msg and "rank 1: sg_comm_init failed (-4)" in msg and "[test]" in msg, msg
+        assert stuck == (rank == 0)
+        assert dt < 30, f"rank {rank} took {dt:.1f} s to give up"
+    # ... and as processes (what bench.py does with the error): both END, both non-zero, nobody has to be killed
+    procs = [ctx.Process(target=_comm_init_worker, args=(r, 2, port + 1, q, "exit")) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=60)
+    codes = [p.exitcode for p in procs]
+    for p in procs:
+        if p.is_alive():
+            p.terminate()
+    assert codes == [13, 13], codes
+
+
+_RANK_BODY = """
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0 and os.environ["LOCAL_RANK"] == str(rank)
+mode = sys.argv[1]
+print(f"chatter from rank {rank}")          # every rank's own stdout: only rank 0's reaches the job's stdout
+if mode == "ok":
+    if rank == 0:
+        print(json.dumps({"metric": "host-only", "n_gpus": world, "args": sys.argv[1:]}))
+    sys.exit(0)
+if mode == "one_dies":                       # rank 1 fails; rank 2 would wait in a collective for ever; rank 0 finishes
+    if rank == 1:
+        sys.exit(3)
+    if rank == 2:
+        time.sleep(600)
+    print(json.dumps({"metric": "host-only", "n_gpus": world}))
+    sys.exit(0)
+"""
+
+
+def test_spawn_ranks_relays_rank0_propagates_the_worst_code_and_ends_survivors(tmp_path):
+    """bench.spawn_ranks (`python bench.py --gpus N` without a launcher) with a host-only rank body:
+    the environment of one job on 127.0.0.1, rank 0's stdout relayed as the job's stdout and the other ranks' kept off it,
+    the worst exit code propagated, and a rank left waiting for one that died terminated after the grace period."""
+    import subprocess
+    import time
+    body = tmp_path / "rank_body.py"
+    body.write_text(_RANK_BODY)
+    drv = tmp_path / "drv.py"
+    drv.write_text(f"import sys\nsys.path.insert(0, {ROOT!r})\nimport bench\n"
+                   f"raise SystemExit(bench.spawn_ranks(int(sys.argv[1]), script={str(body)!r}, argv=sys.argv[2:], grace_s=2.0))\n")
+    r = subprocess.run([sys.executable, str(drv), "3", "ok", "--steps", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    js = [json.loads(l) for l in lines if l.startswith("{")]
+    assert js == [{"metric": "host-only", "n_gpus": 3, "args": ["ok", "--steps", "2"]}]
+    assert lines.count("chatter from rank 0") == 1 and not any("rank 1" in l or "rank 2" in l for l in lines)
+    assert "chatter from rank 1" in r.stderr.decode() and "chatter from rank 2" in r.stderr.decode()
+    t0 = time.time()
+    r = subprocess.run([sys.executable, str(drv), "3", "one_dies"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+    dt = time.time() - t0
+    assert r.returncode == 3, (r.returncode, r.stderr.decode()[-400:])
+    assert dt < 30, f"the job took {dt:.1f} s to end"
+    err = r.stderr.decode()
+    assert "rank 1 exited with code 3" in err and "terminated 1 rank(s)" in err
+    assert [json.loads(l) for l in r.stdout.decode().splitlines() if l.startswith("{")] == [{"metric": "host-only", "n_gpus": 3}]
 
 
 def _segments_worker(rank, world, port, q):

@@ -660,10 +660,13 @@ def test_side_stream_operands_are_released_during_the_backward_pass(engine):
 @pytest.mark.parametrize("policy", ["float32", "mixed_bfloat16"])
 def test_batchnorm_applied_in_the_depthwise_gather(engine, policy, monkeypatch):
     """Fusion BatchNormalization(+ReLU) -> SeparableConv2D (training): the depthwise gather normalises the raw tensor with
-    bn_apply's own expression, the normalised tensor is never materialised (SG_BN_DEFER=1; off by default: no net gain).  In fp32 that is the
-    same arithmetic: loss, gradients and the weights after two Adam steps must equal the materialising graph's to the bit.
+    bn_apply's own expression, the normalised tensor is never materialised (SG_BN_DEFER=1, the default since round 4; model `ma`
+    below is the leg that keeps the materialising fallback SG_BN_DEFER=0 covered - ADVICE r4).  In fp32 that is the same arithmetic: loss, gradients and the weights after two Adam steps must equal the materialising graph's to the bit.
     With bf16 storage the fused form skips one rounding (the stored normalised tensor), so it is compared within the mode's
-    tolerance instead.  The fused graph must actually contain deferred layers."""
+    tolerance instead.  The fused graph must actually contain deferred layers.  A third model runs with BOTH round-4 fusions
+    off (SG_BN_DEFER=0 SG_BN_SUMS=0: every BatchNormalization reduces its own backward sums - the round-3 graph): its sums
+    differ from the depthwise dgrad's in the order of addition only, so in fp32 the first step's loss is the same number and
+    the gradients agree to rounding."""
     from building_detection_amd import mixed_precision as MP, zoo
     from building_detection_amd.data import synthetic_batch
     from building_detection_amd.losses import edge_focal_loss
@@ -674,21 +677,36 @@ def test_batchnorm_applied_in_the_depthwise_gather(engine, policy, monkeypatch):
         ma = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
         monkeypatch.setenv("SG_BN_DEFER", "1")
         mb = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+        monkeypatch.setenv("SG_BN_DEFER", "0")
+        monkeypatch.setenv("SG_BN_SUMS", "0")
+        mc = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+        monkeypatch.delenv("SG_BN_SUMS")
+        monkeypatch.setenv("SG_BN_DEFER", "1")
     finally:
         MP.set_global_policy("float32")
     n_def = sum(1 for n in mb.nodes if isinstance(n, L._BNNode) and n.defer_to is not None)
     assert n_def >= 30 and not any(isinstance(n, L._BNNode) and n.defer_to is not None for n in ma.nodes), n_def
+    assert any(isinstance(n, L._BNNode) and n.sums_from is not None for n in mb.nodes)
+    assert not any(isinstance(n, L._BNNode) and (n.sums_from is not None or n.defer_to is not None) for n in mc.nodes)
     mb.set_weights(ma.get_weights())
+    mc.set_weights(ma.get_weights())
     x, y = synthetic_batch(2, 64, 64, seed=77)
-    for m in (ma, mb):
+    for m in (ma, mb, mc):
         m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
     exact = policy == "float32"
+    lc = mc.train_on_batch(x, y)
     for step in range(2):
         la, lb = ma.train_on_batch(x, y), mb.train_on_batch(x, y)
         if exact:
             assert la["loss"] == lb["loss"], (step, la, lb)
             for ga, gb in zip(ma.get_gradients(), mb.get_gradients()):
                 assert np.array_equal(ga, gb)
+            if step == 0:   # the unfused round-3 graph: same forward (same loss bits), backward sums in another order
+                assert lc["loss"] == la["loss"], (lc, la)
+                num = sum(float(np.square(ga.astype(np.float64) - gc).sum()) for ga, gc in zip(ma.get_gradients(), mc.get_gradients()))
+                den = sum(float(np.square(ga.astype(np.float64)).sum()) for ga in ma.get_gradients())
+                print(f"SG_BN_SUMS=0 SG_BN_DEFER=0 against the default backward: relative L2 of all gradients {(num / den) ** 0.5:.2e}")
+                assert (num / den) ** 0.5 <= 1e-4
         else:
             assert abs(la["loss"] - lb["loss"]) <= 2e-2 * abs(la["loss"]), (step, la, lb)
     if exact:

@@ -920,8 +920,10 @@ np.savez(sys.argv[2], **out)
 def test_fused_second_stage_of_the_reductions_is_bit_identical(engine):
     """sg_reduce.h: the second stage (fp64 sums of the partial rows + the Op's finalize) runs inside the reduce kernel when one
     workgroup covers a column block (default), as a separate launch (SG_SEG_FUSED=0) or in the last-arriving workgroup
-    (SG_SEG_FUSED=2, arrival counters).  Same lanes, same order of additions: the three forms must agree to the bit on
-    BatchNorm backward, the depthwise filter gradient (both kernels), pooling and a bias gradient."""
+    (SG_SEG_FUSED=2, arrival counters behind an agent-scope release; SG_SEG_FUSED=3, the same with write-through partial rows
+    and no release - the sc1 hand-off of MI355X_MICROARCH.md).  Same lanes, same order of additions: the four forms
+    must agree to the bit on BatchNorm backward, the depthwise filter gradient (both kernels), pooling and a bias gradient -
+    all of them reductions over several row slabs per column block at the first shape."""
     import os
     import subprocess
     import sys
@@ -957,7 +959,7 @@ np.savez(sys.argv[2], **out)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     with tempfile.TemporaryDirectory() as td:
-        for mode in ("0", "1", "2"):
+        for mode in ("0", "1", "2", "3"):
             env = dict(os.environ)
             env["SG_SEG_FUSED"] = mode
             path = os.path.join(td, mode + ".npz")
@@ -968,3 +970,4 @@ np.savez(sys.argv[2], **out)
         assert np.isfinite(v).all(), k
         assert np.array_equal(v, res["1"][k]), ("separate launch vs fused (S == 1)", k)
         assert np.array_equal(v, res["2"][k]), ("separate launch vs arrival counters", k)
+        assert np.array_equal(v, res["3"][k]), ("separate launch vs arrival counters with write-through partial rows", k)
