@@ -16,6 +16,8 @@ SG_F32, SG_BF16, SG_I64 = 0, 1, 2
 SG_HEAD_F32 = 0x100  # OR-ed into the dtype of a thin 1x1 conv on bf16 storage: its few-channel side is fp32 (softmax head)
 SG_COMM_ID_BYTES = 128
 SG_EPI_BIAS, SG_EPI_RELU = 1, 2
+SG_PRO_UP2, SG_EPI_DOWN2 = 16, 32   # UpSampling2D(2) -> Conv2D 3x3 fused: forward prologue / dgrad epilogue (segengine.h)
+SG_X_UP2 = 0x200                   # ... and the dtype flag of its filter gradient
 SG_ACT_RELU, SG_ACT_SIGMOID = 0, 1
 SG_LOSS_CE2, SG_LOSS_FOCAL, SG_LOSS_EDGE_FOCAL = 0, 1, 2
 
@@ -57,6 +59,7 @@ _SIGNATURES = {
     "sg_conv2d_fwd": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i]),
     "sg_conv2d_fwd_ws_bytes": (_sz, [_dp]),
     "sg_conv2d_fwd_ws": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "sg_conv2d_up2_supported": (_i, [_i, _dp]),
     "sg_conv2d_fwd_stats_bytes": (_sz, [_dp]),
     "sg_conv2d_fwd_stats": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, C.POINTER(C.c_int)]),
     "sg_get_conv_x6": (_i, []),

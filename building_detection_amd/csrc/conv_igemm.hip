@@ -533,6 +533,8 @@ struct WgradParams {
   int skip_slabs;              // drop 32-pixel slabs that are pure padding for every tap of the tile (dilated convs)
   int KH_KW;
   int tap_inner;               // tile order (channel block, tap, column tile) instead of (tap, channel block, column tile)
+  int up;                      // 1: x is the source of a nearest 2x up-sampling (SG_X_UP2; wgrad_x6wp_kernel only): pixel (h, w)
+                               //    of the H x W tensor is x[n, h >> 1, w >> 1, :] of the (H / 2) x (W / 2) source
   FastDiv fd_ohow, fd_ow, fd_c, fd_kw, fd_oh;
 };
 
@@ -1768,7 +1770,7 @@ WgradPlan plan_wgrad(int num_cus, const sg_conv_desc* d, bool b16 = false) {
 inline int dt_storage(int dtype) { return dtype & 0xff; }
 inline bool dt_ok(int dtype) {
   const int st = dt_storage(dtype);
-  return (st == SG_F32 || st == SG_BF16) && (dtype & ~(0xff | SG_HEAD_F32)) == 0;
+  return (st == SG_F32 || st == SG_BF16) && (dtype & ~(0xff | SG_HEAD_F32 | SG_X_UP2)) == 0;
 }
 inline int dt_bytes(int dtype) { return dt_storage(dtype) == SG_BF16 ? 2 : 4; }
 
@@ -1939,9 +1941,17 @@ static size_t b16w_ws_extra(const sg_conv_desc* d, bool dgrad) {
   return extra;
 }
 
+int sg_conv2d_up2_supported(int dtype, const sg_conv_desc* d) {
+  if (!d || (dtype & 0xff) != SG_F32 || (dtype & SG_HEAD_F32)) return 0;
+  if (x6_mode() != 1) return 0;   // the six-pass arithmetic of the patch kernels
+  return (x6p_up2_geom(d) && x6wp_geom(d)) ? 1 : 0;
+}
+
 size_t sg_conv2d_fwd_ws_bytes(const sg_conv_desc* d) {
   if (!d) return 0;
-  return x6_ws_bytes(d->KH * d->KW, d->Cin, d->Cout) + 256 + b16w_ws_extra(d, false);
+  size_t n = x6_ws_bytes(d->KH * d->KW, d->Cin, d->Cout) + 256 + b16w_ws_extra(d, false);
+  if (n < x6p_up2_ws_bytes()) n = x6p_up2_ws_bytes();
+  return n;
 }
 
 int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
@@ -1971,7 +1981,35 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
   const bool b16 = dt_storage(dtype) == SG_BF16, head32 = (dtype & SG_HEAD_F32) != 0;
   const int eb = dt_bytes(dtype);
   SG_CHECK_ARG(!head32 || (b16 && d->Cout <= 4), "sg_conv2d_fwd: SG_HEAD_F32 needs Cout <= 4 (a softmax head) on bf16 storage");
+  SG_CHECK_ARG(!(dtype & SG_X_UP2), "sg_conv2d_fwd: SG_X_UP2 is the filter gradient's flag (forward: SG_PRO_UP2)");
   hipStream_t st = (hipStream_t)stream;
+  if (flags & SG_PRO_UP2) {
+    // UpSampling2D(2) -> Conv2D 3x3, sub-pixel form (conv_x6p.h): x is the SOURCE [N, H/2, W/2, Cin]; the kernel sees a
+    // convolution on the source grid with 4 phases x Cout columns.  (The patch kernel addresses with 64-bit pointers: no
+    // 2 GiB sub-batches.)
+    const int xl = d->x_ld ? d->x_ld : d->Cin;
+    if (!sg_conv2d_up2_supported(dtype, d) || !aligned16(x) || (xl % 4)) {
+      sg_set_error("sg_conv2d_fwd: SG_PRO_UP2 on a launch the fused up-sampling kernel does not cover (3x3 s1 SAME, 64 -> 32, "
+                   "H %% 16 = 0, W %% 32 = 0, fp32 storage, x6 arithmetic)");
+      return SG_EUNSUPPORTED;
+    }
+    if (!ws || !aligned16(ws) || ws_bytes == SG_WS_PREPARED || ws_bytes < x6p_up2_ws_bytes()) {
+      sg_set_error("sg_conv2d_fwd: SG_PRO_UP2 needs a plain workspace of %zu bytes (its summed-tap planes are made per launch)", x6p_up2_ws_bytes());
+      return SG_EWORKSPACE;
+    }
+    sg_conv_desc sd = *d;
+    sd.H = d->H / 2; sd.W = d->W / 2; sd.Ho = sd.H; sd.Wo = sd.W; sd.Cout = 4 * d->Cout;
+    sd.x_ld = xl; sd.y_ld = d->y_ld ? d->y_ld : d->Cout;
+    IgemmParams p;
+    fill_fwd_params(p, &sd, x, w, bias, y, flags & (SG_EPI_BIAS | SG_EPI_RELU), eb);
+    p.K = 4 * d->Cin;
+    p.y_ld = d->y_ld ? d->y_ld : d->Cout;
+    if (stats && tiles_out && !(flags & SG_EPI_RELU)) {
+      p.stats = (float*)stats;
+      *tiles_out = (int)sg_cdiv((int64_t)d->N * d->Ho * d->Wo, BM);   // one statistics tile per phase and source tile
+    }
+    return run_x6p_up2(p, (const float*)w, ws, ctx->num_cus, st);
+  }
   if (head32 && !(thin_ok(d) && aligned16(x))) {  // a head that is not a 1x1 convolution: the any-shape kernel, fp32 out
     // sub-batches of whole images when the bf16 input or the fp32 output passes 2 GiB (1024 x 1024 ensemble tiles)
     const int nb = images_per_2gib_mixed(d, 2, 4);
@@ -2238,6 +2276,16 @@ static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv
     sg_set_error("sg_conv2d_dgrad_acc: softmax-head launches do not add a collected gradient");
     return SG_EUNSUPPORTED;
   }
+  SG_CHECK_ARG(!(dtype & SG_X_UP2) && !(flags & SG_PRO_UP2), "sg_conv2d_dgrad: the up-sampling flag of the input gradient is SG_EPI_DOWN2");
+  const bool down2 = (flags & SG_EPI_DOWN2) != 0;
+  if (down2) {  // dx = the SOURCE's gradient [N, H/2, W/2, Cin]: the patch kernel's epilogue adds the 2 x 2 cells (conv_x6p.h)
+    const int yl_ = d->y_ld ? d->y_ld : d->Cout;
+    if (!sg_conv2d_up2_supported(dtype, d) || res || (flags & (SG_EPI_BIAS | SG_EPI_RELU)) || !aligned16(dy) || (yl_ % 4)) {
+      sg_set_error("sg_conv2d_dgrad: SG_EPI_DOWN2 on a launch the fused up-sampling kernel does not cover (3x3 s1 SAME, 64 -> 32, "
+                   "H %% 16 = 0, W %% 32 = 0, fp32 storage, x6 arithmetic, no bias / ReLU / collected gradient)");
+      return SG_EUNSUPPORTED;
+    }
+  }
   if (head32 && !thin) {  // fp32 dy in, bf16 dx out, any shape
     const int nb = images_per_2gib_mixed(d, 2, 4);  // dx bf16 (the forward's x), dy fp32
     SG_CHECK_ARG(nb >= 1, "sg_conv2d_dgrad: one image of the softmax head beyond 2 GiB");
@@ -2267,7 +2315,7 @@ static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv
         sg_conv_desc sub = *d;
         sub.N = (d->N - n0 < nb) ? d->N - n0 : nb;
         const char* dys = (const char*)dy + (int64_t)n0 * d->Ho * d->Wo * yl * eb;
-        char* dxs = (char*)dx + (int64_t)n0 * d->H * d->W * xl * eb;
+        char* dxs = (char*)dx + (int64_t)n0 * (down2 ? (d->H / 2) * (d->W / 2) : d->H * d->W) * xl * eb;
         const char* ress = res ? (const char*)res + (int64_t)n0 * d->H * d->W * xl * eb : nullptr;
         g_sub_batch = true;
         int rcs = conv2d_dgrad_impl(ctx, stream, dtype, &sub, dys, w, bias, dxs, flags, ws, ws_bytes, ress);
@@ -2299,6 +2347,10 @@ static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv
   const int ch = b16 ? 8 : 4;
   const bool vec = (d->Cout % ch == 0) && (p.x_ld % ch == 0) && (d->Cin % 4 == 0) && aligned16(dy);
   const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);
+  if (down2 && !(vpad_safe && x6_ok(p, vec, b16) && x6p_ok(p, d->KH, d->KW))) {  // only the patch kernel knows the flag
+    sg_set_error("sg_conv2d_dgrad: SG_EPI_DOWN2, but this launch does not take the patch kernel");
+    return SG_EUNSUPPORTED;
+  }
   if (vpad_safe && x6_ok(p, vec, b16)) {
     static const int perm_on = getenv("SG_DGRAD_PERM2") ? atoi(getenv("SG_DGRAD_PERM2")) : 1;
     if (perm_on && d->stride == 2 && d->dilation == 1 && d->H % 2 == 0 && d->W % 2 == 0 && d->KH * d->KW <= 64) {
@@ -2347,9 +2399,14 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   int rc = check_desc(d, "sg_conv2d_wgrad");
   if (rc) return rc;
   SG_CHECK_ARG(x && dy && dw, "sg_conv2d_wgrad: null tensor");
-  const bool b16 = dt_storage(dtype) == SG_BF16, head32 = (dtype & SG_HEAD_F32) != 0;
+  const bool b16 = dt_storage(dtype) == SG_BF16, head32 = (dtype & SG_HEAD_F32) != 0, up2 = (dtype & SG_X_UP2) != 0;
   const int eb = dt_bytes(dtype);
   const WgradPlan pl = plan_wgrad(ctx->num_cus, d, b16);
+  if (up2 && !(pl.patch && !head32 && x6p_up2_geom(d) && aligned16(x) && aligned16(dy))) {
+    // x = the source of a 2x nearest up-sampling: only the patch kernel gathers that way (conv_x6wp.h)
+    sg_set_error("sg_conv2d_wgrad: SG_X_UP2 on a launch the patch filter-gradient kernel does not cover");
+    return SG_EUNSUPPORTED;
+  }
   const size_t need = pl.dw_part_bytes + pl.bias_part_bytes + 512;
   if (!ws || ws_bytes < need) {
     sg_set_error("sg_conv2d_wgrad: workspace %zu < %zu", ws_bytes, need);
@@ -2402,13 +2459,14 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     p.K = K_all;
     p.P = dd.N * dd.Ho * dd.Wo;
     p.slabs_per_split = sps;
+    p.up = up2 ? 1 : 0;
     p.fd_ohow = make_fastdiv((uint32_t)(dd.Ho * dd.Wo));
     p.fd_ow = make_fastdiv((uint32_t)dd.Wo);
     p.fd_c = make_fastdiv((uint32_t)dd.Cin);
     p.fd_kw = make_fastdiv((uint32_t)dd.KW);
     p.fd_oh = make_fastdiv((uint32_t)dd.Ho);
     {
-      const int64_t xb = (((int64_t)dd.N * dd.H * dd.W - 1) * p.x_ld + dd.Cin) * eb;
+      const int64_t xb = (((int64_t)dd.N * (dd.H >> p.up) * (dd.W >> p.up) - 1) * p.x_ld + dd.Cin) * eb;
       const int64_t yb = (((int64_t)p.P - 1) * p.y_ld + dd.Cout) * eb;
       p.x_bytes = xb < (1ll << 31) ? (uint32_t)xb : 0;
       p.dy_bytes = yb < (1ll << 31) ? (uint32_t)yb : 0;
@@ -2430,6 +2488,10 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     }
     if (pl.patch) {
       const bool al = aligned16(xs) && aligned16(dys) && p.x_bytes != 0 && p.dy_bytes != 0 && !head32;
+      if (up2 && !al) {
+        sg_set_error("sg_conv2d_wgrad: SG_X_UP2 needs 16-byte aligned operands below 2 GiB");
+        return SG_EUNSUPPORTED;
+      }
       if (al) {
         const int grid = x6wp_grid(ctx->num_cus, &dd);  // a last, smaller sub-batch may have fewer tiles than slots
         parts = grid;
@@ -2479,7 +2541,8 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
       const int n0 = c * pl.nb;
       sub.N = (d->N - n0 < pl.nb) ? d->N - n0 : pl.nb;
       int parts = pl.S;
-      rc = launch_part(sub, (const char*)x + (int64_t)n0 * d->H * d->W * xl * eb, (const char*)dy + (int64_t)n0 * d->Ho * d->Wo * yl * eb,
+      rc = launch_part(sub, (const char*)x + (int64_t)n0 * (up2 ? (d->H / 2) * (d->W / 2) : d->H * d->W) * xl * eb,
+                       (const char*)dy + (int64_t)n0 * d->Ho * d->Wo * yl * eb,
                        (float*)ws + (int64_t)total_parts * slab, parts, pl.slabs_per_split);
       if (rc) return rc;
       total_parts += parts;

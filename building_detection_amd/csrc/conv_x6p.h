@@ -19,6 +19,20 @@
 //   * per k-step a wave issues 12 ds_read_b128 + 3 global loads for 24 MFMAs, the reads of the next half k-step
 //     in flight under the MFMAs of the current one.
 // Serves forward and dgrad alike (IgemmParams: off = -1, k_mul = +1 / off = +1, k_mul = -1).
+//
+// UpSampling2D(2, nearest) -> Conv2D 3x3 (train_model/DeepLabv3plus.py:476-477: 256 x 256 x 64 -> 512 x 512 x 64 -> 32; round 5):
+//   * forward, UP2 = true ("sub-pixel" form): output pixel (2i + a, 2j + b) of the up-sampled grid sees, through its nine
+//     taps, only the 2 x 2 source pixels (i + a - 1 .. i + a, j + b - 1 .. j + b): rows {i - 1: w[0], i: w[1] + w[2]} for
+//     a = 0, {i: w[0] + w[1], i + 1: w[2]} for a = 1, columns alike.  So the layer IS a convolution on the SOURCE grid with
+//     4 x Cout output columns (phase-major) in which phase (a, b) uses four of the nine source taps, with the kernel's taps
+//     summed beforehand (split3_weights_up2_frag_kernel): 4 / 9 of the MFMA work, the 10 x 18 patch staged once per
+//     8 x 16 SOURCE pixels = 512 output pixels instead of once per 128, and no up-sampled tensor at all.  Wave w of the
+//     workgroup is phase w (C = 64, BN = 128: four column blocks, no K split); the epilogue stores pixel-shuffled.  The
+//     summed taps change the rounding (w1 x + w2 x vs (w1 + w2) x): within fp32 rounding of the unfused layer, not
+//     bit-identical to it - the parity tests compare with the oracle, not with the unfused graph.
+//   * dgrad, SG_EPI_DOWN2: the ordinary dgrad on the up-sampled grid whose epilogue adds each 2 x 2 cell - all four values sit
+//     in ONE lane's accumulators - in up-sampling's backward order ((g00 + g01) + g10) + g11 and stores the SOURCE-sized
+//     gradient: bit-identical to dgrad + sg_upsample_nearest_bwd, without the 4x tensor in between.
 #pragma once
 
 template <int C>
@@ -58,6 +72,43 @@ __global__ __launch_bounds__(256) void split3_weights_frag_kernel(const float* _
   u32x4_t* o = reinterpret_cast<u32x4_t*>(out + (f * 3) * 512 + lane * 8);
   o[0] = (u32x4_t){h[0], h[1], h[2], h[3]};
   o[64] = (u32x4_t){m[0], m[1], m[2], m[3]};   // + 512 ushorts = 64 u32x4
+  o[128] = (u32x4_t){l[0], l[1], l[2], l[3]};
+}
+
+// The sub-pixel form's weights (see the header): w[3][3][Ck][Cout] -> effective kernel B[tap4 * Ck + kk][phase * Cout + co],
+// tap4 = 2 r + c the source tap (row a + r - 1, column b + c - 1) of phase (a, b) = the sum of the kernel's taps that read it
+// (rows: a = 0: r = 0 <- {0}, r = 1 <- {1, 2}; a = 1: r = 0 <- {0, 1}, r = 1 <- {2}; columns alike; added kh-major in
+// ascending order), split into the fragment-major planes of the patch kernel (NB32 = 4 phases, Cout = 32).
+__global__ __launch_bounds__(256) void split3_weights_up2_frag_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Ck,
+                                                                      int Cout) {
+  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int lane = (int)(gid & 63);
+  const int64_t f = gid >> 6;
+  if (f >= (int64_t)(4 * Ck / 16) * 4) return;
+  const int ks = (int)(f >> 2), ph = (int)(f & 3);
+  const int a = ph >> 1, b = ph & 1;
+  const int n = lane & 31, k0 = ks * 16 + (lane >> 5) * 8;
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float v[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int k = k0 + 2 * e + u;
+      const int tap4 = k / Ck, kk = k - tap4 * Ck;
+      const int r = tap4 >> 1, c = tap4 & 1;
+      const int kh0 = (a == 0) ? (r == 0 ? 0 : 1) : (r == 0 ? 0 : 2), kh1 = (a == 0) ? (r == 0 ? 0 : 2) : (r == 0 ? 1 : 2);
+      const int kw0 = (b == 0) ? (c == 0 ? 0 : 1) : (c == 0 ? 0 : 2), kw1 = (b == 0) ? (c == 0 ? 0 : 2) : (c == 0 ? 1 : 2);
+      float sum = 0.f;
+      for (int kh = kh0; kh <= kh1; ++kh)
+        for (int kw = kw0; kw <= kw1; ++kw) sum += w[((int64_t)(kh * 3 + kw) * Ck + kk) * Cout + n];
+      v[u] = sum;
+    }
+    split3_pair(v[0], v[1], h[e], m[e], l[e]);
+  }
+  u32x4_t* o = reinterpret_cast<u32x4_t*>(out + (f * 3) * 512 + lane * 8);
+  o[0] = (u32x4_t){h[0], h[1], h[2], h[3]};
+  o[64] = (u32x4_t){m[0], m[1], m[2], m[3]};
   o[128] = (u32x4_t){l[0], l[1], l[2], l[3]};
 }
 
@@ -147,14 +198,15 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(const float* __rest
 // of the pipe and overlapped ones barely slower.
 __device__ unsigned g_x6p_arrivals[2048];  // per CU: workgroups that have started there (never reset; used modulo)
 
-template <int C, int BN>
+template <int C, int BN, bool UP2 = false>
 __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, int tiles_x, int tiles_y, int ntiles, int delay,
                                                           int wg_per_cu) {
   using L = X6P<C>;
+  static_assert(!UP2 || (C == 64 && BN == 128), "the sub-pixel form: 64 source channels, 4 phases x 32 output channels");
   constexpr int NBLK = BN / 32;     // 32-column blocks of the tile: 1, 2, 4
   constexpr int KS = 4 / NBLK;      // K classes: 4, 2, 1
   constexpr int CS = C / 16;        // k-steps per tap
-  constexpr int NKS = 9 * CS;
+  constexpr int NKS = (UP2 ? 4 : 9) * CS;   // UP2: a phase reads four source taps
   constexpr int RED = (KS > 1) ? 4 * NBLK * (KS - 1) * 4096 : 0;          // bytes of the K-class exchange
   constexpr int STAT_OFF = (L::PATCH > RED) ? L::PATCH : RED;             // [2][4 waves][32] floats behind it
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -264,8 +316,15 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
     // byte offset (inside plane 0, row block 0) of this lane's A operand of k-step ks
     auto a_offset = [&](int ks) -> int {
       const int tap = ks / CS, cs = ks - tap * CS;
-      const int kh = tap / 3, kw = tap - kh * 3;
-      const int dyr = 1 + p.off_h + kh * p.k_mul, dxr = 1 + p.off_w + kw * p.k_mul;
+      int dyr, dxr;
+      if constexpr (UP2) {  // wave = column block = phase (a, b): source taps (a + r - 1, b + c - 1), patch row 0 = source row - 1
+        dyr = (nblk >> 1) + (tap >> 1);
+        dxr = (nblk & 1) + (tap & 1);
+      } else {
+        const int kh = tap / 3, kw = tap - kh * 3;
+        dyr = 1 + p.off_h + kh * p.k_mul;
+        dxr = 1 + p.off_w + kw * p.k_mul;
+      }
       const int q = px + dxr;
       return (pyl + dyr) * L::ROWP + q * L::PB + L::chunk_slot(cs * 2 + lh, q);
     };
@@ -379,21 +438,51 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
     }
 
     // ---- epilogue: each wave stores the blocks it finalised (all four when KS == 1) --------------------------------
-    const int col = (int)tile_n * BN + nblk * 32 + lr;
+    const int col = UP2 ? lr : (int)tile_n * BN + nblk * 32 + lr;   // UP2: the wave's 32 columns are the layer's 32 channels
     const float bv = (p.flags & SG_EPI_BIAS) ? p.bias[col] : 0.f;
-    float* yo = p.y + ((int64_t)img * p.OH * p.OW + (int64_t)by * 8 * p.OW + bx * 16) * p.y_ld + col;
     float s = 0.f;
+    if (!UP2 && (p.flags & SG_EPI_DOWN2)) {
+      // dgrad behind a 2x nearest up-sampling: block i holds tile rows 2i, 2i + 1 = ONE source row; the lane's register
+      // r -> pixel (rb >> 4, rb & 15), rb = (r & 3) + 8 (r >> 2) + 4 lh, so the 2 x 2 cell of source column
+      // (r >> 1 & 1) + 2 lh + 4 (r >> 2 & 1) is registers r0, r0 | 1 (next column), r0 | 8, r0 | 9 (next row)
+      const int OWs = p.OW >> 1;
+      float* yo = p.y + (((int64_t)img * (p.OH >> 1) + (int64_t)by * 4) * OWs + bx * 8) * p.y_ld + col;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      if (KS == 1 || kc == i % KS) {
+      for (int i = 0; i < 4; ++i) {
+        if (KS == 1 || kc == i % KS) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int rb = (r & 3) + 8 * (r >> 2) + 4 * lh;  // row of the 32-row block = pixel (2i + rb/16, rb%16)
-          float v = acc[i][r] + bv;
-          acc[i][r] = v;
-          s += v;
-          if (do_relu) v = fmaxf(v, 0.f);
-          if (!dbg && !(p.ablate & 8)) yo[((int64_t)(2 * i + (rb >> 4)) * p.OW + (rb & 15)) * p.y_ld] = v;
+          for (int q = 0; q < 4; ++q) {
+            const int r0 = 2 * (q & 1) + 4 * (q >> 1);
+            const float v = ((acc[i][r0] + acc[i][r0 | 1]) + acc[i][r0 | 8]) + acc[i][r0 | 9];   // sg_upsample_nearest_bwd's order
+            if (!dbg && !(p.ablate & 8)) yo[((int64_t)i * OWs + (q & 1) + 2 * lh + 4 * (q >> 1)) * p.y_ld] = v;
+          }
+        }
+      }
+    } else {
+      float* yo;
+      int64_t rowp, colp;   // element strides of one tile row / tile column in y
+      if constexpr (UP2) {  // source pixel (Y, X) of phase (a, b) -> pixel (2 Y + a, 2 X + b) of the 2 OH x 2 OW output
+        const int64_t OW2 = 2 * (int64_t)p.OW;
+        yo = p.y + ((((int64_t)img * 2 * p.OH + (int64_t)by * 16 + (nblk >> 1)) * OW2) + bx * 32 + (nblk & 1)) * p.y_ld + col;
+        rowp = 2 * OW2 * p.y_ld;
+        colp = 2 * (int64_t)p.y_ld;
+      } else {
+        yo = p.y + ((int64_t)img * p.OH * p.OW + (int64_t)by * 8 * p.OW + bx * 16) * p.y_ld + col;
+        rowp = (int64_t)p.OW * p.y_ld;
+        colp = p.y_ld;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if (KS == 1 || kc == i % KS) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rb = (r & 3) + 8 * (r >> 2) + 4 * lh;  // row of the 32-row block = pixel (2i + rb/16, rb%16)
+            float v = acc[i][r] + bv;
+            acc[i][r] = v;
+            s += v;
+            if (do_relu) v = fmaxf(v, 0.f);
+            if (!dbg && !(p.ablate & 8)) yo[(int64_t)(2 * i + (rb >> 4)) * rowp + (rb & 15) * colp] = v;
+          }
         }
       }
     }
@@ -443,8 +532,13 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
         for (int k = 0; k < KS; ++k) q += sl[128 + (k * NBLK + nblk) * 32 + lr];
       }
       if (lh == 0 && kc == 0) {
-        p.stats[((int64_t)tile_m * 2) * p.Nout + col] = s;
-        p.stats[((int64_t)tile_m * 2 + 1) * p.Nout + col] = q;
+        if constexpr (UP2) {  // a phase's 128 output pixels are one statistics tile: row 4 tile_m + phase of [tiles][2][32]
+          p.stats[((int64_t)(tile_m * 4 + nblk) * 2) * 32 + col] = s;
+          p.stats[((int64_t)(tile_m * 4 + nblk) * 2 + 1) * 32 + col] = q;
+        } else {
+          p.stats[((int64_t)tile_m * 2) * p.Nout + col] = s;
+          p.stats[((int64_t)tile_m * 2 + 1) * p.Nout + col] = q;
+        }
       }
     }
   }
@@ -468,17 +562,17 @@ inline bool x6p_ok(const IgemmParams& p, int KH, int KW) {
   return true;
 }
 
-template <int C, int BN>
+template <int C, int BN, bool UP2 = false>
 int launch_x6p(const IgemmParams& p, int num_cus, hipStream_t st) {
   constexpr int KS = 4 / (BN / 32), NBLK = BN / 32;
   constexpr size_t red = (KS > 1) ? (size_t)4 * NBLK * (KS - 1) * 4096 : 0;
   constexpr size_t lds = (X6P<C>::PATCH > red ? (size_t)X6P<C>::PATCH : red) + 2 * 4 * 32 * sizeof(float);
   static int wg_per_cu = 0;
   if (!wg_per_cu) {
-    int rc = set_dyn_lds(conv_x6p_kernel<C, BN>, lds);
+    int rc = set_dyn_lds(conv_x6p_kernel<C, BN, UP2>, lds);
     if (rc) return rc;
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_x6p_kernel<C, BN>, 256, lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_x6p_kernel<C, BN, UP2>, 256, lds);
     if (e != hipSuccess || nb < 1) nb = 1;
     wg_per_cu = nb > 4 ? 4 : nb;
   }
@@ -498,7 +592,7 @@ int launch_x6p(const IgemmParams& p, int num_cus, hipStream_t st) {
   int delay = 0;
   if (dly_env != 0 && grid == slots && wg_per_cu > 1 && tiles >= 2 * slots)
     delay = dly_env > 0 ? dly_env : (int)(2.0 * 128 * BN * 9 * C / 1.1e6 * 100.0 + 0.5);
-  hipLaunchKernelGGL((conv_x6p_kernel<C, BN>), dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, (int)tiles, delay, wg_per_cu);
+  hipLaunchKernelGGL((conv_x6p_kernel<C, BN, UP2>), dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, (int)tiles, delay, wg_per_cu);
   SG_LAUNCH_CHECK("conv_x6p_kernel");
   return 0;
 }
@@ -532,3 +626,23 @@ int run_x6p(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void*
   if (bn == 64) return launch_x6p<64, 64>(p, num_cus, st);
   return launch_x6p<64, 128>(p, num_cus, st);
 }
+
+// ---- UpSampling2D(2) -> Conv2D 3x3: which launches take the fused kernels (sg_conv2d_fwd* with SG_PRO_UP2, sg_conv2d_dgrad with
+// SG_EPI_DOWN2).  `d` describes the convolution on the UP-SAMPLED grid (H x W = twice the source's).
+inline bool x6p_up2_geom(const sg_conv_desc* d) {
+  if (!x6p_enabled() || d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dilation != 1) return false;
+  if (d->pad_t != 1 || d->pad_l != 1 || d->Ho != d->H || d->Wo != d->W) return false;
+  if (d->Cin != 64 || d->Cout != 32) return false;
+  if ((d->H % 16) || (d->W % 32)) return false;   // 8 x 16 SOURCE tiles (forward), 8 x 16 output tiles (dgrad)
+  return true;
+}
+
+// the sub-pixel forward: p describes the convolution on the SOURCE grid (H, W, OH, OW, M = source; Nout = 128 = 4 phases x 32)
+inline int run_x6p_up2(IgemmParams& p, const float* w, void* ws, int num_cus, hipStream_t st) {
+  p.ablate = 0;
+  p.wq = (const unsigned short*)ws;
+  hipLaunchKernelGGL(split3_weights_up2_frag_kernel, dim3(16), dim3(256), 0, st, w, (unsigned short*)ws, 64, 32);
+  SG_LAUNCH_CHECK("split3_weights_up2_frag_kernel");
+  return launch_x6p<64, 128, true>(p, num_cus, st);
+}
+inline size_t x6p_up2_ws_bytes() { return (size_t)16 * 4 * 3 * 512 * 2; }   // 16 k-steps x 4 phases x 3 planes x 1 KB

@@ -62,6 +62,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6wp_kernel(const WgradParams p,
     const uint32_t by = tq % (uint32_t)tiles_y, img = tq / (uint32_t)tiles_y;
     const int y0 = (int)by * L::TH - 1, x0 = (int)bx * L::TW - 1;
     const int ibase = (int)img * p.H;
+    const int up = p.up, ibase_s = (int)img * (p.H >> up), Ws = p.W >> up;   // SG_X_UP2: the patch is gathered from the source
     // the thread index is laundered per call: what derives from it (pixel, chunk, validity, LDS place of up to 11 chunks)
     // would otherwise be hoisted out of the tile loop and live - and spill - through the MFMA section
     int tl = t;
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6wp_kernel(const WgradParams p,
       const int pr = pp / L::PW, pc = pp - pr * L::PW;
       const int gy = y0 + pr, gx = x0 + pc;
       const bool ok = (NXC % 256 == 0 || idx < NXC) && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
-      const unsigned off = (unsigned)(((ibase + gy) * p.W + gx) * p.x_ld + c * CH) * (unsigned)EB;
+      const unsigned off = (unsigned)(((ibase_s + (gy >> up)) * Ws + (gx >> up)) * p.x_ld + c * CH) * (unsigned)EB;
       rx[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(ok ? off : OOB), 0, 0);
     }
 #pragma unroll

@@ -75,6 +75,18 @@ class _ConvNode(Node):
     def desc(self, rt, x):
         return rt.eng.conv_desc(tuple(x.shape), self.filters, self.k, self.k, self.stride, self.dilation, self.padding)
 
+    # UpSampling2D(2) -> this 3x3 convolution, fused (Model._fuse sets up_src; runtime._Runtime.up2_on decides per runtime):
+    # the up-sampling node hands its SOURCE through, this node's kernels read / write it directly (csrc/conv_x6p.h:
+    # sub-pixel forward, dgrad with the 2 x 2 sum in its epilogue, filter gradient gathering h >> 1, w >> 1)
+    up_src = None
+
+    def _up2(self, rt):
+        return self.up_src is not None and rt.up2_on(self.up_src)
+
+    def _up_desc(self, rt, x_src):
+        n, h, w, c = x_src.shape
+        return rt.eng.conv_desc((n, 2 * h, 2 * w, c), self.filters, self.k, self.k, self.stride, self.dilation, self.padding)
+
     def plane_sites(self, rt, batch):
         """(tag, weight, forward-conv descriptor, dgrad?, phase) of every launch of this layer that reads its kernel through
         the matrix-pipe weight planes: runtime._Runtime.ensure_planes prepares them once per optimiser step."""
@@ -82,6 +94,8 @@ class _ConvNode(Node):
                              self.dilation, self.padding)
         head = self.activation == "softmax"
         sites = [("f", self.w, d, 0, "fwd", head)]
+        if self._up2(rt):   # the sub-pixel forward makes its own (summed-tap) planes per launch
+            sites = []
         if rt.needs_grad(self.inputs[0]):
             sites.append(("d", self.w, d, 1, "bwd", head))
         return sites
@@ -93,17 +107,19 @@ class _ConvNode(Node):
     def forward(self, rt, xs, training):
         (x,) = xs
         b = rt.param(self.b) if self.b else None
+        up2 = self._up2(rt)   # x is then the up-sampling's source
+        d = self._up_desc(rt, x) if up2 else self.desc(rt, x)
         with rt.eng.timed(self._tag):
             if training and getattr(self, "emit_bn_stats", False):
                 # the following BatchNormalization takes its statistics from this conv's epilogue
-                y, st = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=self.desc(rt, x), want_stats=True,
-                                          planes=rt.planes(self, "f"))
+                y, st = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=d, want_stats=True,
+                                          planes=None if up2 else rt.planes(self, "f"), up2=up2)
                 if st is not None:
                     rt.bn_stats[id(y)] = st
                 return y
             # the softmax head stays fp32 under bf16 storage (logits, probabilities, loss: SG_HEAD_F32)
-            y = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=self.desc(rt, x), relu=self.activation == "relu",
-                                  head_f32=self.activation == "softmax", planes=rt.planes(self, "f"))
+            y = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=d, relu=self.activation == "relu",
+                                  head_f32=self.activation == "softmax", planes=None if up2 else rt.planes(self, "f"), up2=up2)
         if self.activation == "sigmoid":
             y = rt.eng.act_fwd(y, _lib.SG_ACT_SIGMOID, out=y)
         elif self.activation == "softmax":
@@ -121,7 +137,8 @@ class _ConvNode(Node):
             dz = e.softmax2_bwd(y, dy)
         else:
             dz = dy
-        d = self.desc(rt, x)
+        up2 = self._up2(rt)
+        d = self._up_desc(rt, x) if up2 else self.desc(rt, x)
         with e.timed(self._tag):
             want_b = self.b is not None and not getattr(self, "bias_grad_zero", False)
             # the input gradient first: the chain goes on with it, the filter gradient follows on the side stream beside the
@@ -135,15 +152,15 @@ class _ConvNode(Node):
                 # or the thin 1x1 kernel (scSE's spatial squeeze, Cout = 1)
                 thin = (self.k == 1 and self.stride == 1 and self.filters <= 4 and x.shape[-1] % 4 == 0 and x.shape[-1] >= 16
                         and "SG_CONV_NOTHIN" not in os.environ)
-                if (self._tag is None and dz.dtype == x.dtype
+                if (self._tag is None and dz.dtype == x.dtype and not up2
                         and (thin or (rt.plane_kind(self, "d") == 1 and rt.planes(self, "d") is not None))):
                     root = self.inputs[0]
                     while isinstance(root.node, _ActNode) and root.node.fused_away and len(root.consumers) == 1:
                         root = root.node.inputs[0]
                     res = rt.take_pending(root)
-                dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype, planes=rt.planes(self, "d"), res=res)
+                dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype, planes=rt.planes(self, "d"), res=res, down2=up2)
             gw, gb = rt.grad(self.w), (rt.grad(self.b) if want_b else None)
-            e.side_run(self._tag, (x, dz), lambda: e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=gw, db=gb))
+            e.side_run(self._tag, (x, dz), lambda: e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=gw, db=gb, x_up2=up2))
         return [dx]
 
     def flops(self, batch):
@@ -637,10 +654,16 @@ class _UpNode(Node):
         _, h, w, c = x.shape
         return self.connect([x], (None, h * self.size, w * self.size, c))
 
+    fused_into = None   # the 3x3 convolution that reads this node's SOURCE directly (Model._fuse; _ConvNode.up_src)
+
     def forward(self, rt, xs, training):
+        if self.fused_into is not None and rt.up2_on(self):
+            return xs[0]   # never materialised: the consumer's kernels address the source (h >> 1, w >> 1)
         return rt.eng.upsample_fwd(xs[0], self.size)
 
     def backward(self, rt, xs, y, dy):
+        if self.fused_into is not None and rt.up2_on(self):
+            return [rt.shared(dy)]   # the consumer's dgrad already summed the 2 x 2 cells: dy has the source's shape
         return [rt.eng.upsample_bwd(dy, tuple(xs[0].shape), self.size)]
 
 

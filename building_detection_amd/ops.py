@@ -353,19 +353,29 @@ class Engine:
         ho, wo, pt, pl = conv_out_geometry(h, w, kh, kw, stride, dilation, padding)
         return ConvDesc(n, h, w, cin, cout, kh, kw, stride, dilation, pt, pl, ho, wo, x_ld, y_ld)
 
+    def conv2d_up2_ok(self, d: ConvDesc, dtype=torch.float32) -> bool:
+        """Does the convolution `d` (on the up-sampled grid) take the fused UpSampling2D(2) -> Conv2D 3x3 kernels
+        (SG_PRO_UP2 / SG_EPI_DOWN2 / SG_X_UP2, csrc/conv_x6p.h)?"""
+        return dtype == torch.float32 and bool(self.lib.sg_conv2d_up2_supported(SG_F32, C.byref(d)))
+
     def conv2d_fwd(self, x, w, b=None, stride=1, dilation=1, padding="same", relu=False, out=None, desc=None,
-                   want_stats=False, head_f32=False, planes=None):
+                   want_stats=False, head_f32=False, planes=None, up2=False):
         """want_stats: also return the BatchNormalization statistics of y as (stats tensor [tiles,2,Cout], tiles), or
         None when this launch could not produce them (then BN computes its own).
-        head_f32 (bf16 storage only): the output is fp32 - the softmax head, a thin 1x1 convolution (SG_HEAD_F32)."""
+        head_f32 (bf16 storage only): the output is fp32 - the softmax head, a thin 1x1 convolution (SG_HEAD_F32).
+        up2: x is the SOURCE [N, H/2, W/2, Cin] of a nearest 2x up-sampling and `desc` (required) names the convolution on
+        the up-sampled grid (SG_PRO_UP2: the sub-pixel kernel; the up-sampled tensor is never built)."""
         _chk(x, "x"); _chk32(w, "w")
         kh, kw, cin, cout = w.shape
         d = desc or self.conv_desc(x.shape, cout, kh, kw, stride, dilation, padding)
         assert d.Cin == cin, (d.Cin, cin)
+        if up2:
+            assert desc is not None and tuple(x.shape) == (d.N, d.H // 2, d.W // 2, d.Cin), (tuple(x.shape), d.H, d.W)
+            planes = None   # the summed-tap planes of the sub-pixel form are made per launch in the plain workspace
         head_f32 = bool(head_f32) and x.dtype == torch.bfloat16
         y = out if out is not None else self.empty(d.N, d.Ho, d.Wo, cout, dtype=torch.float32 if head_f32 else x.dtype)
         dt = _dt(x) | (SG_HEAD_F32 if head_f32 else 0)
-        flags = (_lib.SG_EPI_BIAS if b is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
+        flags = (_lib.SG_EPI_BIAS if b is not None else 0) | (_lib.SG_EPI_RELU if relu else 0) | (_lib.SG_PRO_UP2 if up2 else 0)
         if planes is not None:  # this layer's weight planes, prepared once per step (runtime._Runtime.ensure_planes)
             wsp, wsn = C.c_void_p(planes), C.c_size_t(_lib.SG_WS_PREPARED)
         else:
@@ -382,20 +392,27 @@ class Engine:
                                             wsp, wsn), "sg_conv2d_fwd_ws")
         return y
 
-    def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None, out_dtype=None, planes=None, res=None):
+    def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None, out_dtype=None, planes=None, res=None,
+                     down2=False):
         """dx of the forward conv described by `d`; also Conv2DTranspose forward (then bias/relu apply).
         out_dtype = torch.bfloat16 with an fp32 dy: the backward of the fp32 softmax head of a bf16 model (SG_HEAD_F32).
         res: a gradient already collected for the same tensor, added in the kernel's epilogue (sg_conv2d_dgrad_acc: only for
-        launches whose prepared planes are of kind 1, the slab kernels)."""
+        launches whose prepared planes are of kind 1, the slab kernels).
+        down2: the conv's input was a nearest 2x up-sampling; dx is the gradient of its SOURCE, [N, H/2, W/2, Cin] (the 2 x 2
+        cells added in the epilogue in up-sampling's backward order: SG_EPI_DOWN2)."""
         _chk(dy, "dy"); _chk32(w, "w")
         odt = out.dtype if out is not None else (out_dtype or dy.dtype)
-        dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin, dtype=odt)
+        if down2:
+            assert res is None and bias is None and not relu
+            dx = out if out is not None else self.empty(d.N, d.H // 2, d.W // 2, d.Cin, dtype=odt)
+        else:
+            dx = out if out is not None else self.empty(d.N, d.H, d.W, d.Cin, dtype=odt)
         dt = (SG_BF16 | SG_HEAD_F32) if (odt == torch.bfloat16 and dy.dtype == torch.float32) else _dt(dy)
         if planes is not None:
             wsp, wsn = C.c_void_p(planes), C.c_size_t(_lib.SG_WS_PREPARED)
         else:
             wsp, wsn = self.ws(self.lib.sg_conv2d_dgrad_ws_bytes(C.byref(d)))
-        flags = (_lib.SG_EPI_BIAS if bias is not None else 0) | (_lib.SG_EPI_RELU if relu else 0)
+        flags = (_lib.SG_EPI_BIAS if bias is not None else 0) | (_lib.SG_EPI_RELU if relu else 0) | (_lib.SG_EPI_DOWN2 if down2 else 0)
         with self.timed(self._gemm_tag()):
             if res is not None:
                 check(self.lib.sg_conv2d_dgrad_acc(self.h, self.stream, dt, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
@@ -405,9 +422,14 @@ class Engine:
                                                flags, wsp, wsn), "sg_conv2d_dgrad")
         return dx
 
-    def conv2d_wgrad(self, x, dy, d: ConvDesc, want_bias=True, dw=None, db=None):
+    def conv2d_wgrad(self, x, dy, d: ConvDesc, want_bias=True, dw=None, db=None, x_up2=False):
+        """x_up2: x is the SOURCE [N, H/2, W/2, Cin] of the nearest 2x up-sampling the conv `d` read (SG_X_UP2: the patch
+        kernel gathers x[n, h >> 1, w >> 1]; the bits of the filter gradient on the materialised tensor)."""
         _chk(x, "x"); _chk(dy, "dy")
         dt = (SG_BF16 | SG_HEAD_F32) if (x.dtype == torch.bfloat16 and dy.dtype == torch.float32) else _dt(x)
+        if x_up2:
+            assert tuple(x.shape) == (d.N, d.H // 2, d.W // 2, d.Cin), (tuple(x.shape), d.H, d.W)
+            dt |= _lib.SG_X_UP2
         if dw is None:
             dw = self.empty(d.KH, d.KW, d.Cin, d.Cout)
         if want_bias and db is None:

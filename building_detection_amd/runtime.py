@@ -124,6 +124,16 @@ class Model:
                 if len(cons) == 1 and isinstance(cons[0], L._BNNode) and len(n.output.shape) == 4:
                     n.bias_grad_zero = True
                     n.emit_bn_stats = True  # the conv epilogue hands BN its statistics (sg_conv2d_fwd_stats)
+        # UpSampling2D(2) -> Conv2D 3x3 'same' (the decoder's last stage, train_model/DeepLabv3plus.py:476-477): the convolution's
+        # kernels read the up-sampling's source directly (sub-pixel forward with 4/9 of the products; csrc/conv_x6p.h) and the
+        # 4x tensor and its gradient are never built.  Marked here for every such pair; whether a runtime takes the fused
+        # kernels (fp32 storage, geometry, SG_UP2_FUSE != 0) is _Runtime.up2_on.
+        for n in self.nodes:
+            if isinstance(n, L._UpNode) and n.size == 2 and id(n.output) not in outs and len(n.output.consumers) == 1:
+                c = n.output.consumers[0]
+                if (isinstance(c, L._ConvNode) and c.k == 3 and c.stride == 1 and c.dilation == 1 and c.padding == "same"
+                        and c.activation in (None, "linear", "relu")):
+                    n.fused_into, c.up_src = c, n
         for n in self.nodes:
             if not isinstance(n, L._ActNode) or n.act != "relu" or n.fused_away:
                 continue
@@ -886,6 +896,7 @@ class _Runtime:
         dev = int(os.environ.get("LOCAL_RANK", "0")) if torch.cuda.is_available() and torch.cuda.device_count() > 1 else 0
         self.eng = get_engine(dev)  # makes `dev` torch's current device (Engine.__init__)
         e = self.eng
+        self._up2: Dict[tuple, bool] = {}   # up_sampling2d node -> fused with its convolution on this runtime (up2_on)
         self.w_train = e.zeros(max(model._n_train, ALIGN))
         self.g_train = e.zeros(max(model._n_train, ALIGN))
         self.adam_m = e.zeros(max(model._n_train, ALIGN))
@@ -955,6 +966,22 @@ class _Runtime:
             _lib.check(self.eng.lib.sg_prepare_planes(self.eng.h, self.eng.stream, C.c_void_p(self.w_train.data_ptr()),
                                                       C.c_void_p(arena.data_ptr()), C.c_void_p(jobs.data_ptr()), launch[0],
                                                       launch[1]), "sg_prepare_planes")
+
+    def up2_on(self, up_node) -> bool:
+        """Does THIS runtime run the pair `up_node` -> 3x3 convolution (Model._fuse: fused_into / up_src) on the fused kernels?
+        fp32 storage, the geometry csrc/conv_x6p.h covers (asked of the library), SG_UP2_FUSE != 0.  Decided once per pair:
+        the up-sampling node (identity then) and the convolution must agree."""
+        key = (id(up_node), int(self.eng.lib.sg_get_conv_x6()))   # (the arithmetic switch may change between steps: tests do)
+        got = self._up2.get(key)
+        if got is None:
+            c = up_node.fused_into
+            got = False
+            if c is not None and os.environ.get("SG_UP2_FUSE", "1") != "0" and self.model.compute_dtype == "float32":
+                _, h, w, cin = c.inputs[0].shape
+                d = self.eng.conv_desc((1, h, w, cin), c.filters, c.k, c.k, c.stride, c.dilation, c.padding)
+                got = bool(self.eng.conv2d_up2_ok(d))
+            self._up2[key] = got
+        return got
 
     def plane_kind(self, node, tag) -> int:
         """Which kernel family `node`'s launch `tag` takes (sg_conv2d_planes_job's kind; 0: none of the prepared-plane kernels)."""

@@ -53,10 +53,26 @@ extern "C" {
  * Conv2D(num_classes, 1, activation='softmax') (v3plus.py:345): logits, probabilities, loss and their gradients
  * stay in fp32 while every other activation is bf16. */
 #define SG_HEAD_F32 0x100
+/* OR-ed into the dtype of sg_conv2d_wgrad: x is the SOURCE of a nearest 2x up-sampling - x[N, H/2, W/2, Cin] stands for the
+ * up-sampled [N, H, W, Cin] tensor the descriptor names, the kernel reads x[n, h >> 1, w >> 1, :] (same bits as the filter
+ * gradient on the materialised tensor).  See SG_PRO_UP2. */
+#define SG_X_UP2 0x200
 
 /* epilogue flags for conv-like ops */
 #define SG_EPI_BIAS 1
 #define SG_EPI_RELU 2
+/* UpSampling2D(size=2) -> Conv2D(3x3, 'same') fused (train_model/DeepLabv3plus.py:476-477, the decoder's last stage; round 5).
+ * The descriptor always names the convolution on the UP-SAMPLED grid (H x W); the up-sampled tensor itself never exists.
+ *   SG_PRO_UP2   (flags of sg_conv2d_fwd / _ws / _stats) x is the source x[N, H/2, W/2, Cin].  The "sub-pixel" kernel computes
+ *                the four output phases from the 2 x 2 source pixels each of them sees, with the kernel's taps summed
+ *                beforehand: 4/9 of the multiplications, within fp32 rounding of the unfused pair (not bit-identical to it).
+ *   SG_EPI_DOWN2 (flags of sg_conv2d_dgrad) dx is the gradient of the SOURCE, dx[N, H/2, W/2, Cin]: each 2 x 2 cell of the
+ *                up-sampled tensor's gradient is added in the epilogue, in sg_upsample_nearest_bwd's order (bit-identical to
+ *                the unfused pair).  No bias / ReLU / collected gradient with it.
+ * Geometry: 3x3, stride 1, dilation 1, SAME, Cin = 64, Cout = 32, H % 16 = 0, W % 32 = 0, SG_F32 storage, x6 arithmetic on;
+ * anything else returns SG_EUNSUPPORTED (sg_conv2d_up2_supported tells beforehand). */
+#define SG_PRO_UP2   16
+#define SG_EPI_DOWN2 32
 
 typedef struct sg_ctx sg_ctx;
 
@@ -101,6 +117,9 @@ int sg_conv2d_fwd(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, c
 size_t sg_conv2d_fwd_ws_bytes(const sg_conv_desc* d);
 int sg_conv2d_fwd_ws(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
                      const void* w, const void* bias, void* y, int flags, void* ws, size_t ws_bytes);
+/* 1 when the convolution `d` (on the up-sampled grid) takes the fused up-sampling kernels (SG_PRO_UP2 / SG_EPI_DOWN2 /
+ * SG_X_UP2) with this storage type and the current arithmetic switch, else 0. */
+int sg_conv2d_up2_supported(int dtype, const sg_conv_desc* d);
 
 /* The forward that also hands the following BatchNormalization its statistics (epilogue flag
  * bn_stats): per 128-pixel tile and output channel the sum and the centred sum of squares of y, written to

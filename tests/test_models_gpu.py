@@ -715,6 +715,44 @@ def test_batchnorm_applied_in_the_depthwise_gather(engine, policy, monkeypatch):
     assert np.array_equal(ma.predict(x), mb.predict(x)) or not exact   # inference never defers: same graph, same weights
 
 
+def test_upsampling_fused_into_the_decoder_convolution(engine, monkeypatch):
+    """Model level of tests/test_ops_gpu.py::test_upsampling_fused_into_the_3x3_convolution: DeepLabv3+'s last decoder stage
+    `UpSampling2D(2) -> conv_bn_relu(32)` (train_model/DeepLabv3plus.py:476-477) runs on the fused kernels by default
+    (Model._fuse: fused_into / up_src; _Runtime.up2_on); SG_UP2_FUSE=0 keeps the materialising pair.  The two graphs agree within
+    rounding on predict(), the training loss and every gradient (the forward's summed taps round differently, so not to the bit),
+    and the fused model never launches an up-sampling kernel for that node."""
+    from building_detection_amd import zoo
+    from building_detection_amd import layers as L
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss
+    ma = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+    mb = zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)
+    pairs = [n for n in mb.nodes if isinstance(n, L._UpNode) and n.fused_into is not None]
+    assert len(pairs) == 1 and pairs[0].fused_into.filters == 32 and pairs[0].fused_into.up_src is pairs[0]
+    mb.set_weights(ma.get_weights())
+    x, y = synthetic_batch(2, 64, 64, seed=78)
+    for m in (ma, mb):
+        m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
+    monkeypatch.setenv("SG_UP2_FUSE", "0")
+    pa = ma.predict(x)
+    la = ma.train_on_batch(x, y)
+    assert not ma._runtime().up2_on(next(n for n in ma.nodes if isinstance(n, L._UpNode) and n.fused_into is not None))
+    monkeypatch.setenv("SG_UP2_FUSE", "1")
+    calls = []
+    orig = engine.upsample_fwd
+    monkeypatch.setattr(engine, "upsample_fwd", lambda t, s_, *a, **k: (calls.append((tuple(t.shape), s_)), orig(t, s_, *a, **k))[1])
+    pb = mb.predict(x)
+    lb = mb.train_on_batch(x, y)
+    assert mb._runtime().up2_on(pairs[0])
+    assert not any(sh[1:3] == (32, 32) and sh[3] == 64 and s_ == 2 for sh, s_ in calls), calls   # the 32 x 32 x 64 source is never up-sampled
+    assert float(np.abs(pa - pb).max()) <= 2e-6
+    assert abs(la["loss"] - lb["loss"]) <= 1e-6 * abs(la["loss"]), (la, lb)
+    num = sum(float(np.square(ga.astype(np.float64) - gb).sum()) for ga, gb in zip(ma.get_gradients(), mb.get_gradients()))
+    den = sum(float(np.square(ga.astype(np.float64)).sum()) for ga in ma.get_gradients())
+    print(f"fused up-sampling convolution against the materialising pair: relative L2 of all gradients {(num / den) ** 0.5:.2e}")
+    assert (num / den) ** 0.5 <= 1e-4
+
+
 def test_jit_capture_after_a_validation_batch_of_another_size(engine):
     """ADVICE r2 (runtime.py:494): fit_generator with steps_per_epoch=2 and a validation batch of another size under
     compile(jit_compile=True).  The two eager warm-up steps are epoch 1; its validation pass re-keys the runtime's weight

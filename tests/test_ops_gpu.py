@@ -856,6 +856,74 @@ def test_conv_epilogue_bn_statistics(engine, shape):
     close(z2, torch.relu(zr), rtol=2e-5, what="conv -> BN -> ReLU vs fp64 oracle")
 
 
+@pytest.mark.parametrize("shape", [(2, 16, 32), (3, 8, 16), (1, 24, 48)], ids=["two_tiles_per_image", "one_tile", "ragged_grid_3x3"])
+def test_upsampling_fused_into_the_3x3_convolution(engine, shape):
+    """UpSampling2D(2) -> Conv2D(32, 3, 'same') on 64 channels (train_model/DeepLabv3plus.py:476-477) on the fused kernels
+    (csrc/conv_x6p.h, round 5): the sub-pixel forward (SG_PRO_UP2: four phases from the 2 x 2 source pixels each sees, the
+    kernel's taps summed beforehand, statistics for the following BatchNormalization), the dgrad that adds the 2 x 2 cells in its
+    epilogue (SG_EPI_DOWN2) and the filter gradient that gathers the source at (h >> 1, w >> 1) (SG_X_UP2).  Against the fp64
+    oracle AND against the unfused pair of engine launches: forward within rounding (the summed taps round differently), both
+    gradients BIT-identical (same products, same order of additions)."""
+    n, hs, ws_ = shape   # source map; the convolution runs on (2 hs) x (2 ws)
+    cin, cout = 64, 32
+    g = torch.Generator().manual_seed(hs * 131 + ws_)
+    x = rnd(g, n, hs, ws_, cin)
+    wt = rnd(g, 3, 3, cin, cout) * (1.0 / np.sqrt(9 * cin))
+    b = rnd(g, cout) * 3
+    dy = rnd(g, n, 2 * hs, 2 * ws_, cout)
+    xd, wd, bd, dyd = x.cuda(), wt.cuda(), b.cuda(), dy.cuda()
+    d = engine.conv_desc((n, 2 * hs, 2 * ws_, cin), cout, 3, 3, 1, 1, "same")
+    assert engine.conv2d_up2_ok(d), "this geometry is the fused kernels' own"
+    # fp64 oracle through the materialised up-sampling
+    xr, wr, br = x.double().requires_grad_(), wt.double().requires_grad_(), b.double().requires_grad_()
+    yr = T.conv2d(T.upsample_nearest(xr, 2), wr, br, 1, 1, "same")
+    yr.backward(dy.double())
+    # the unfused engine pair
+    up = engine.upsample_fwd(xd, 2)
+    y_un = engine.conv2d_fwd(up, wd, bd, desc=d)
+    dx_un = engine.upsample_bwd(engine.conv2d_dgrad(dyd, wd, d), tuple(x.shape), 2)
+    dw_un, db_un = engine.conv2d_wgrad(up, dyd, d)
+    # fused
+    y, st = engine.conv2d_fwd(xd, wd, bd, desc=d, want_stats=True, up2=True)
+    assert st is not None and st[1] == n * 4 * hs * ws_ // 128
+    close(y, yr, what="sub-pixel forward vs fp64")
+    close(y, y_un, rtol=1e-5, what="sub-pixel forward vs the unfused pair")
+    e64 = (y.double().cpu() - yr.detach()).abs().max().item(), (y_un.double().cpu() - yr.detach()).abs().max().item()
+    # (the summed taps are rounded to fp32 once before the three-way split: one more 2^-24 on the kernel, measured 8e-7 against
+    # the unfused pair's 4.5e-7 of |y|_max ~ 4 on the first shape - both far inside the 2e-5 bar above)
+    assert e64[0] <= 3 * e64[1] + 5e-7, f"sub-pixel form {e64[0]:.2e} from fp64, unfused {e64[1]:.2e}"
+    dx = engine.conv2d_dgrad(dyd, wd, d, down2=True)
+    assert tuple(dx.shape) == tuple(x.shape)
+    close(dx, xr.grad, what="dgrad with the 2x2 sum vs fp64")
+    assert torch.equal(dx, dx_un), "dgrad + up-sampling backward fused: not the bits of the unfused pair"
+    dw, db = engine.conv2d_wgrad(xd, dyd, d, x_up2=True)
+    close(dw, wr.grad, what="filter gradient from the source vs fp64")
+    assert torch.equal(dw, dw_un) and torch.equal(db, db_un), "filter gradient gathered from the source: not the unfused bits"
+    # the statistics the epilogue leaves (one tile per phase and source tile) = BatchNormalization's own pass over y
+    gam, bet = (rnd(g, cout) + 1.5).cuda(), rnd(g, cout).cuda()
+    mm1, mv1 = torch.zeros(cout).cuda(), torch.ones(cout).cuda()
+    mm2, mv2 = torch.zeros(cout).cuda(), torch.ones(cout).cuda()
+    z1, mean1, inv1 = engine.bn_train_fwd(y, gam, bet, mm1, mv1, relu=True)
+    z2, mean2, inv2 = engine.bn_train_fwd_from_tiles(y, st[0], st[1], gam, bet, mm2, mv2, relu=True)
+    close(mean2, mean1, rtol=2e-6, what="mean")
+    close(inv2, inv1, rtol=2e-6, what="inv-std")
+    close(mv2, mv1, rtol=2e-6, what="moving variance")
+    close(z2, z1, rtol=5e-6, what="normalised output")
+    # ReLU in the epilogue (a Conv2D(activation='relu') behind an up-sampling), no bias
+    close(engine.conv2d_fwd(xd, wd, None, desc=d, relu=True, up2=True), torch.relu(T.conv2d(T.upsample_nearest(x.double(), 2), wt.double(), None, 1, 1, "same")),
+          what="sub-pixel forward with ReLU")
+    # batch-slice invariance, bit for bit: an image's result does not depend on the batch it travels in
+    if n > 1:
+        d1 = engine.conv_desc((1, 2 * hs, 2 * ws_, cin), cout, 3, 3, 1, 1, "same")
+        assert torch.equal(engine.conv2d_fwd(xd[1:2].contiguous(), wd, bd, desc=d1, up2=True)[0], y[1])
+    # a geometry the fused kernels do not cover is refused loudly, never computed some other way
+    from building_detection_amd._lib import SgError
+    d_bad = engine.conv_desc((n, 2 * hs, 2 * ws_, cin), cout, 3, 3, 1, 2, "same")
+    assert not engine.conv2d_up2_ok(d_bad)
+    with pytest.raises(SgError):
+        engine.conv2d_fwd(xd, wd, bd, desc=d_bad, up2=True)
+
+
 def test_sub_batch_paths_of_oversized_tensors(engine):
     """activations beyond 2 GiB run as sub-batches of whole images (forward, dgrad) / as chunks with one reduce
     (wgrad).  SG_CONV_MAX_BYTES (read once per process) lowers that limit, so a child process runs a 5-image convolution
