@@ -73,6 +73,12 @@ _SIGNATURES = {
     "sg_conv2d_dgrad_acc": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "sg_conv2d_wgrad_ws_bytes": (_sz, [_vp, _dp]),
     "sg_conv2d_wgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "sg_split_planes": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
+    "sg_conv2d_planes_in": (_i, [_dp, _i]),
+    "sg_conv2d_fwd_stats_ap": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, C.POINTER(C.c_int), _vp]),
+    "sg_conv2d_dgrad_ap": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
+    "sg_conv2d_wgrad_planes_supported": (_i, [_vp, _dp]),
+    "sg_conv2d_wgrad_planes": (_i, [_vp, _vp, _dp, _vp, _vp, _vp, _vp, _sz]),
     "sg_bias_grad_ws_bytes": (_sz, [_vp, _i64, _i]),
     "sg_bias_grad": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz]),
     "sg_dwconv2d_fwd": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _i]),

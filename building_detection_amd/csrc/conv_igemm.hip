@@ -73,6 +73,9 @@ struct IgemmParams {
   // dgrad: a gradient already collected for the same tensor (y's layout, may be y itself), added in the epilogue
   // (sg_conv2d_dgrad_acc; conv_x6_kernel / conv_b16_kernel only)
   const float* res;
+  // the A operand already split into three bf16 planes [3][pixels][C] (sg_split_planes; sg_conv2d_fwd_stats_ap / _dgrad_ap): the
+  // planes-in kernel (conv_x6w.h) reads them instead of splitting x itself; ignored by every other kernel; null: none
+  const unsigned short* a_planes;
   // host side only: bytes of workspace that start at the weight planes (the planes, then scratch of a split-K launch:
   // conv_b16w.h); SIZE_MAX = prepared planes, whose arena slot sg_conv2d_planes_job sized for both
   size_t ws_room;
@@ -533,6 +536,8 @@ struct WgradParams {
   int skip_slabs;              // drop 32-pixel slabs that are pure padding for every tap of the tile (dilated convs)
   int KH_KW;
   int tap_inner;               // tile order (channel block, tap, column tile) instead of (tap, channel block, column tile)
+  uint32_t x_plane_bytes, dy_plane_bytes;   // planes-in filter gradient (wgrad_x6_kernel<.., PIN>): bytes from one bf16 plane of
+                               //    x / dy to the next; x_bytes / dy_bytes then cover all three
   int up;                      // 1: x is the source of a nearest 2x up-sampling (SG_X_UP2; wgrad_x6wp_kernel only): pixel (h, w)
                                //    of the H x W tensor is x[n, h >> 1, w >> 1, :] of the (H / 2) x (W / 2) source
   FastDiv fd_ohow, fd_ow, fd_c, fd_kw, fd_oh;
@@ -1797,6 +1802,7 @@ void fill_fwd_params(IgemmParams& p, const sg_conv_desc* d, const void* x, const
   p.stats = nullptr;
   p.perm2 = 0;
   p.res = nullptr;
+  p.a_planes = nullptr;
   p.ws_room = 0;
 }
 
@@ -1823,6 +1829,7 @@ void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, co
   p.stats = nullptr;
   p.perm2 = 0;
   p.res = nullptr;
+  p.a_planes = nullptr;
   p.ws_room = 0;
 }
 
@@ -1969,8 +1976,41 @@ size_t sg_conv2d_fwd_stats_bytes(const sg_conv_desc* d) {
   return (size_t)sg_cdiv((int64_t)d->N * d->Ho * d->Wo, BM) * 2 * d->Cout * sizeof(float);
 }
 
+static int conv2d_fwd_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
+                           const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out,
+                           const void* x_planes);
+
 int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
                         const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out) {
+  return conv2d_fwd_impl(ctx, stream, dtype, d, x, w, bias, y, flags, ws, ws_bytes, stats, tiles_out, nullptr);
+}
+
+int sg_conv2d_fwd_stats_ap(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
+                           const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out,
+                           const void* x_planes) {
+  SG_CHECK_ARG(!x_planes || aligned16(x_planes), "sg_conv2d_fwd_stats_ap: planes must be 16-byte aligned");
+  return conv2d_fwd_impl(ctx, stream, dtype, d, x, w, bias, y, flags, ws, ws_bytes, stats, tiles_out, x_planes);
+}
+
+// does the fp32 launch of this geometry read its A operand as bf16 planes (conv_x6w.h)?  Then handing it planes that exist
+// already (sg_split_planes: shared by several consumers of one tensor, or kept for the filter gradient) saves its own split.
+int sg_conv2d_planes_in(const sg_conv_desc* d, int dgrad) {
+  if (!d || check_desc(d, "sg_conv2d_planes_in") || x6_mode() != 1) return 0;
+  if (dgrad && d->stride != 1) return 0;
+  if ((d->x_ld && d->x_ld != d->Cin) || (d->y_ld && d->y_ld != d->Cout)) return 0;   // planes are dense
+  static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+  IgemmParams q;
+  if (!dgrad) fill_fwd_params(q, d, dummy, dummy, nullptr, nullptr, 0, 4);
+  else fill_dgrad_params(q, d, dummy, dummy, nullptr, nullptr, 0, 4);
+  q.x = (const float*)(uintptr_t)16;
+  if (q.C % BK != 0 && q.K != q.C) return 0;   // (virtually padded channels: the planes would need the padded depth)
+  if (x6p_ok(q, d->KH, d->KW)) return 0;
+  return x6w_plan(q) > 0 ? 1 : 0;
+}
+
+static int conv2d_fwd_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
+                           const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out,
+                           const void* x_planes) {
   if (tiles_out) *tiles_out = 0;
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_fwd: null ctx");
   SG_CHECK_ARG(dt_ok(dtype), "sg_conv2d_fwd: dtype %d", dtype);
@@ -2065,6 +2105,7 @@ int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
   }
   IgemmParams p;
   fill_fwd_params(p, d, x, w, bias, y, flags, eb);
+  if (!b16 && p.x_ld == d->Cin) p.a_planes = (const unsigned short*)x_planes;
   const int ch = b16 ? 8 : 4;
   const bool vec = (d->Cin % ch == 0) && (p.x_ld % ch == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
   const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);  // padded reads must stay inside this tensor
@@ -2235,11 +2276,18 @@ size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d) {
 }
 
 static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
-                            const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* res);
+                            const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* res,
+                            const void* dy_planes = nullptr);
 
 int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
                     const void* bias, void* dx, int flags, void* ws, size_t ws_bytes) {
   return conv2d_dgrad_impl(ctx, stream, dtype, d, dy, w, bias, dx, flags, ws, ws_bytes, nullptr);
+}
+
+int sg_conv2d_dgrad_ap(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                       const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* dy_planes) {
+  SG_CHECK_ARG(!dy_planes || aligned16(dy_planes), "sg_conv2d_dgrad_ap: planes must be 16-byte aligned");
+  return conv2d_dgrad_impl(ctx, stream, dtype, d, dy, w, bias, dx, flags, ws, ws_bytes, nullptr, dy_planes);
 }
 
 int sg_conv2d_dgrad_acc(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
@@ -2249,7 +2297,7 @@ int sg_conv2d_dgrad_acc(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
 }
 
 static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
-                            const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* res) {
+                            const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* res, const void* dy_planes) {
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_dgrad: null ctx");
   SG_CHECK_ARG(dt_ok(dtype), "sg_conv2d_dgrad: dtype %d", dtype);
   int rc = check_desc(d, "sg_conv2d_dgrad");
@@ -2344,6 +2392,7 @@ static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv
   IgemmParams p;
   fill_dgrad_params(p, d, dy, wt, bias, dx, flags, eb);
   p.res = (const float*)res;
+  if (!b16 && p.x_ld == d->Cout) p.a_planes = (const unsigned short*)dy_planes;
   const int ch = b16 ? 8 : 4;
   const bool vec = (d->Cout % ch == 0) && (p.x_ld % ch == 0) && (d->Cin % 4 == 0) && aligned16(dy);
   const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);
@@ -2573,6 +2622,114 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     SG_LAUNCH_CHECK("reduce_splits_kernel");
   }
   return bias_grad();
+}
+
+// ---- planes-in filter gradient (round 5; conv_x6.h: wgrad_x6_kernel<.., PIN>) -------------------------------------------
+int sg_split_planes(sg_ctx* ctx, void* stream, const void* x, int64_t rows, int C, int ld, void* planes) {
+  SG_CHECK_ARG(ctx && x && planes && rows > 0 && C > 0, "sg_split_planes: bad argument");
+  const int xl = ld ? ld : C;
+  SG_CHECK_ARG((C % 4 == 0) && (xl % 4 == 0) && xl >= C && aligned16(x) && aligned16(planes), "sg_split_planes: C and ld must be multiples of 4, pointers 16-byte aligned");
+  int64_t blocks = sg_cdiv(rows * (C / 4), 256);
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(x6w_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x, (unsigned short*)planes, rows, C, xl);
+  SG_LAUNCH_CHECK("x6w_split_kernel");
+  return 0;
+}
+
+static bool wgrad_planes_geom(const sg_ctx* ctx, const sg_conv_desc* d, WgradPlan* out) {
+  if (x6_mode() != 1) return false;
+  if (d->stride != 1 || d->Ho != d->H || d->Wo != d->W || (d->Wo % 32) || (d->Cin % 8) || (d->Cout % 8) || d->Cout < 16) return false;
+  if ((d->x_ld && d->x_ld != d->Cin) || (d->y_ld && d->y_ld != d->Cout)) return false;   // planes are dense
+  const int64_t xp = (int64_t)d->N * d->H * d->W * d->Cin * 2, yp = (int64_t)d->N * d->Ho * d->Wo * d->Cout * 2;
+  const int64_t sh = ((int64_t)d->pad_t * d->W + d->pad_l + 64) * d->Cin * 4;
+  if (3 * xp + 2 * sh >= (1ll << 31) || 3 * yp >= (1ll << 31)) return false;
+  const WgradPlan pl = plan_wgrad(ctx->num_cus, d, false);
+  if (pl.wide || pl.patch || pl.chunks > 1 || thin_ok(d)) return false;
+  if (out) *out = pl;
+  return true;
+}
+
+int sg_conv2d_wgrad_planes_supported(const sg_ctx* ctx, const sg_conv_desc* d) {
+  return (ctx && d && check_desc(d, "sg_conv2d_wgrad_planes_supported") == 0 && wgrad_planes_geom(ctx, d, nullptr)) ? 1 : 0;
+}
+
+int sg_conv2d_wgrad_planes(sg_ctx* ctx, void* stream, const sg_conv_desc* d, const void* x_planes, const void* dy_planes, void* dw,
+                           void* ws, size_t ws_bytes) {
+  SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_wgrad_planes: null ctx");
+  int rc = check_desc(d, "sg_conv2d_wgrad_planes");
+  if (rc) return rc;
+  SG_CHECK_ARG(x_planes && dy_planes && dw && aligned16(x_planes) && aligned16(dy_planes), "sg_conv2d_wgrad_planes: null / unaligned tensor");
+  WgradPlan pl;
+  if (!wgrad_planes_geom(ctx, d, &pl)) {
+    sg_set_error("sg_conv2d_wgrad_planes: geometry outside the planes-in kernel (stride 1 SAME, W %% 32 = 0, channels %% 8 = 0, dense "
+                 "planes below 2 GiB, not a wide pointwise / patch-form layer, x6 arithmetic)");
+    return SG_EUNSUPPORTED;
+  }
+  const size_t need = pl.dw_part_bytes + 512;
+  if (!ws || ws_bytes < need || !aligned16(ws)) {
+    sg_set_error("sg_conv2d_wgrad_planes: workspace %zu < %zu", ws_bytes, need);
+    return SG_EWORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  const int K_all = d->KH * d->KW * d->Cin;
+  WgradParams p;
+  memset(&p, 0, sizeof(p));
+  p.x = (const float*)x_planes;
+  p.dy = (const float*)dy_planes;
+  p.out = pl.S > 1 ? (float*)ws : (float*)dw;
+  p.H = d->H; p.W = d->W; p.Cin = d->Cin; p.x_ld = d->Cin;
+  p.OH = d->Ho; p.OW = d->Wo; p.Cout = d->Cout; p.y_ld = d->Cout;
+  p.stride = 1; p.dil = d->dilation; p.pad_t = d->pad_t; p.pad_l = d->pad_l;
+  p.K = K_all;
+  p.P = d->N * d->Ho * d->Wo;
+  p.slabs_per_split = pl.slabs_per_split;
+  p.fd_ohow = make_fastdiv((uint32_t)(d->Ho * d->Wo));
+  p.fd_ow = make_fastdiv((uint32_t)d->Wo);
+  p.fd_c = make_fastdiv((uint32_t)d->Cin);
+  p.fd_kw = make_fastdiv((uint32_t)d->KW);
+  p.fd_oh = make_fastdiv((uint32_t)d->Ho);
+  p.x_plane_bytes = (uint32_t)((int64_t)d->N * d->H * d->W * d->Cin * 2);
+  p.dy_plane_bytes = (uint32_t)((int64_t)p.P * d->Cout * 2);
+  p.x_bytes = 3 * p.x_plane_bytes;
+  p.dy_bytes = 3 * p.dy_plane_bytes;
+  {
+    static int noskip = -1;
+    if (noskip < 0) noskip = getenv("SG_CONV_NOSKIP") ? 1 : 0;
+    p.KH_KW = p.K / p.Cin;
+    p.skip_slabs = (!noskip && p.dil > 1 && p.KH_KW > 1) ? 1 : 0;
+    p.tap_inner = ((conv_l2(true) & 4) && p.KH_KW > 1 && p.Cin % BM == 0) ? 1 : 0;   // as dispatch_wgrad: the same tile order
+  }
+  {
+    static const int abl = getenv("SG_X6_ABLATE") ? atoi(getenv("SG_X6_ABLATE")) & 7 : 0;   // timing-only diagnostics of the PF = 1 form
+    p.stagger = abl;
+  }
+  const int bn = wgrad_bn(p.Cout);
+  // SG_WGRAD_PIN_PF: 1 = single LDS buffer, two workgroups per CU (the fp32-operand kernel's default structure); 2 = one workgroup
+  // per CU, two buffers, the stores of slab s + 1 and the loads of slab s + 3 woven between the MFMAs of slab s
+  static const int pf = getenv("SG_WGRAD_PIN_PF") ? atoi(getenv("SG_WGRAD_PIN_PF")) : 2;
+  static const int w22 = getenv("SG_WGRAD_PIN_W22") ? atoi(getenv("SG_WGRAD_PIN_W22")) : 0;   // experiment: 4 waves of 64 x 64 per 128 x 128 tile
+  if (w22 && bn == 128) {
+    rc = (pf == 2) ? launch_wgrad_x6<128, 2, 2, 2, 3, bf16_t, true>(p, pl.S, st) : launch_wgrad_x6<128, 2, 2, 1, 3, bf16_t, true>(p, pl.S, st);
+  } else if (pf == 2) {
+    if (bn == 128) rc = launch_wgrad_x6<128, 2, 4, 2, 3, bf16_t, true>(p, pl.S, st);
+    else if (bn == 64) rc = launch_wgrad_x6<64, 4, 2, 2, 3, bf16_t, true>(p, pl.S, st);
+    else rc = launch_wgrad_x6<32, 4, 1, 2, 3, bf16_t, true>(p, pl.S, st);
+  } else {
+    if (bn == 128) rc = launch_wgrad_x6<128, 2, 4, 1, 3, bf16_t, true>(p, pl.S, st);
+    else if (bn == 64) rc = launch_wgrad_x6<64, 4, 2, 1, 3, bf16_t, true>(p, pl.S, st);
+    else rc = launch_wgrad_x6<32, 4, 1, 1, 3, bf16_t, true>(p, pl.S, st);
+  }
+  if (rc) return rc;
+  if (pl.S > 1) {
+    const int64_t n = (int64_t)K_all * d->Cout;
+    const bool v4 = (n % 4 == 0) && aligned16(dw);
+    int64_t blocks = sg_cdiv(n, v4 ? 1024 : 256);
+    if (blocks > 2048) blocks = 2048;
+    if (v4) hipLaunchKernelGGL(reduce_splits_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, (float*)dw, n, pl.S);
+    else hipLaunchKernelGGL(reduce_splits_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, st, (const float*)ws, (float*)dw, n, pl.S);
+    SG_LAUNCH_CHECK("reduce_splits_kernel");
+  }
+  return 0;
 }
 
 size_t sg_bias_grad_ws_bytes(const sg_ctx* ctx, int64_t rows, int C) {

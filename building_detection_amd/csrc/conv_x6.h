@@ -870,11 +870,19 @@ struct X6WPitch {
 // both operands are bf16 in HBM and a thread's 16-byte chunk (8 channels) goes to LDS unchanged.
 constexpr int WG_NS = 1;  // register sets of the bf16 wgrad: 2 measured no faster (728 -> 728: 55 us either way,
                           // profiles/r02_b16_prefetch_ab.txt), 4 spills at BN = 128
-template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float>
+// PIN ("planes in", round 5): the fp32 (six-pass) filter gradient whose operands are ALREADY split - x and dy arrive as three
+// bf16 planes [3][pixels][channels] each (x6w_split_kernel's layout: the forward's activation planes, kept; dy's made once per
+// layer) and a thread's 16-byte chunk of every plane goes from the buffer load to LDS untouched, as in the bf16-storage form.
+// The fp32 form splits 16 chunks per thread and slab on the VALU (two split3_pair each, ~200 instructions) for 24 MFMAs per
+// wave, between two barriers: as long as the MFMA phase itself.  Same LDS image, same fragments, same products in the same order
+// as the fp32 form: bit-identical results.
+template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float, bool PIN = false>
 __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM * WGN / 2) void wgrad_x6_kernel(const WgradParams p) {
   static_assert(NPL == 3 || NPL == 1, "planes");
-  static_assert(NPL == 1 || std::is_same<TA, float>::value, "the three-plane split is the fp32 path");
+  static_assert(NPL == 1 || std::is_same<TA, float>::value || PIN, "the three-plane split is the fp32 path");
+  static_assert(!PIN || (NPL == 3 && !std::is_same<TA, float>::value), "planes in: three bf16 planes per operand");
   constexpr bool A16 = !std::is_same<TA, float>::value;
+  constexpr int NLD = PIN ? 3 : 1;        // 16-byte loads per chunk position (one per plane)
   constexpr int EB = EL<TA>::BYTES, CH = EL<TA>::CH;
   constexpr int CPA = BM / CH;            // 16-byte chunks per A' pixel row: 32 (fp32) or 16 (bf16)
   constexpr int CPB = BN / CH;
@@ -958,7 +966,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   // several slab times: it keeps WG_NS slabs of loads in flight (a set is two 16-byte registers there); the six-pass form
   // (24 MFMAs per slab, 24 registers per set) keeps one, or two with the double-buffered structure.
   constexpr int NS = (PF == 1 && NPL == 1 && A16) ? WG_NS : PF;
-  u32x4_t ra[NS][NA], rb[NS][NB];
+  u32x4_t ra[NS][NA * NLD], rb[NS][NB * NLD];
   auto load_AB = [&](int p0, auto SET) {
     constexpr int S = decltype(SET)::value;
     uint32_t q, ow0, n_, oh;
@@ -973,11 +981,16 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
       const bool v = row_ok && ((unsigned)(col0 + PS * j * p.stride) < (unsigned)p.W);
-      ra[S][j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a, 0);
+#pragma unroll
+      for (int pl = 0; pl < NLD; ++pl)   // PIN: the same chunk of every plane, the plane in the scalar offset
+        ra[S][j * NLD + pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a + pl * (int)p.x_plane_bytes, 0);
     }
     const int soff_b = p0 * p.y_ld * EB;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) rb[S][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b, 0);
+    for (int i = 0; i < NB; ++i)
+#pragma unroll
+      for (int pl = 0; pl < NLD; ++pl)
+        rb[S][i * NLD + pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b + pl * (int)p.dy_plane_bytes, 0);
   };
 
   // one 16-byte chunk (4 fp32 or 8 bf16 channels of one pixel) to its place in the [pixel][channel] LDS image
@@ -1001,6 +1014,23 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   };
   auto store_AB = [&](auto SET, int buf) {
     constexpr int S = decltype(SET)::value;
+    if constexpr (PIN) {   // plane pl of a chunk -> plane pl of the LDS image, unchanged
+#pragma unroll
+      for (int j = 0; j < NA; ++j)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          *reinterpret_cast<u32x4_t*>(Ap + buf * BUFSZ + pl * BK * PA + (pr0 + PS * j) * PA + rc * 16) = ra[S][j * 3 + pl];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int idx = t + NT * i;
+        if (idx < NBC) {
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl)
+            *reinterpret_cast<u32x4_t*>(Bp + buf * BUFSZ + pl * BK * PB + (idx / CPB) * PB + (idx % CPB) * 16) = rb[S][i * 3 + pl];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < NA; ++j) store_chunk(ra[S][j], Ap + buf * BUFSZ, pr0 + PS * j, rc, PA);
 #pragma unroll
@@ -1027,40 +1057,58 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   const char* a_lane = Ap + tr_row * PA + (wm + tr_col) * 2;
   const char* b_lane = Bp + tr_row * PB + (wn + tr_col) * 2;
 
+  // Round 5: a rolling fragment pipeline.  The slab's MFMAs go in 2 TM blocks (k-step, row sub-tile i: 6 TN MFMAs); while block q
+  // multiplies, the A fragments of block q + 1 (and, at the k-step change, its B fragments) are already on their way from LDS.
+  // Before, every k-step opened with ALL of its reads and a full wait: the read + MFMA loop alone took 646 of the 830 us of the
+  // ASPP filter gradient (gpurun_out/r5g).  One A set and one B set more in registers (requesting the whole slab up front
+  // needs 36 more and spills at this kernel's 128-register budget).  Same products in the same order: bit-identical.
   auto compute = [&](int buf) {
+    bf16x8_t afr[2][NPL], bfr[2][TN][NPL];
+    auto rd_a = [&](int ks, int i, bf16x8_t (&d)[NPL]) {
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t af[TM][NPL], bf[TN][NPL];
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int pl = 0; pl < NPL; ++pl) {
-          const char* a = a_lane + buf * BUFSZ + (pl * BK + 16 * ks) * PA + 64 * i;
-          af[i][pl] = tr_frag(a, a + 4 * PA);
-        }
+      for (int pl = 0; pl < NPL; ++pl) {
+        const char* a = a_lane + buf * BUFSZ + (pl * BK + 16 * ks) * PA + 64 * i;
+        d[pl] = tr_frag(a, a + 4 * PA);
+      }
+    };
+    auto rd_b = [&](int ks, bf16x8_t (&d)[TN][NPL]) {
 #pragma unroll
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int pl = 0; pl < NPL; ++pl) {
           const char* b = b_lane + buf * BUFSZ + (pl * BK + 16 * ks) * PB + 64 * j;
-          bf[j][pl] = tr_frag(b, b + 4 * PB);
+          d[j][pl] = tr_frag(b, b + 4 * PB);
         }
+    };
+    rd_b(0, bfr[0]);
+    rd_a(0, 0, afr[0]);
+    constexpr int NQ = 2 * TM;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+    for (int q = 0; q < NQ; ++q) {
+      const int ks = q / TM, i = q % TM;
+      if (q + 1 < NQ) {
+        const int ks1 = (q + 1) / TM, i1 = (q + 1) % TM;
+        rd_a(ks1, i1, afr[(q + 1) & 1]);
+        if (ks1 != ks) rd_b(ks1, bfr[ks1 & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // (left alone, the scheduler sinks the reads back to their first use)
+      const bf16x8_t(&af)[NPL] = afr[q & 1];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          if constexpr (NPL == 1) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-            continue;
-          }
-          constexpr int P2 = NPL == 3 ? 2 : 0, P1 = NPL == 3 ? 1 : 0;
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][P2], bf[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][P2], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][P1], bf[j][P1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][P1], bf[j][0], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][P1], acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+      for (int j = 0; j < TN; ++j) {
+        const bf16x8_t(&bf)[NPL] = bfr[ks & 1][j];
+        if constexpr (NPL == 1) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[i][j], 0, 0, 0);
+          continue;
         }
+        constexpr int P2 = NPL == 3 ? 2 : 0, P1 = NPL == 3 ? 1 : 0;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[P2], bf[0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[P2], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[P1], bf[P1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[P1], bf[0], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[P1], acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc[i][j], 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   };
 
@@ -1170,11 +1218,32 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
         fd_divmod((uint32_t)p0, p.fd_ow, q_, ow0);
         fd_divmod(q_, p.fd_oh, n_, oh);
         const bool row_ok = (unsigned)((int)oh + s_dh) < (unsigned)p.H;
-        const int soff_a = p0 * p.x_ld * 4, soff_b = p0 * p.y_ld * 4;
+        const int soff_a = p0 * p.x_ld * EB, soff_b = p0 * p.y_ld * EB;
         const int col0 = (int)ow0 + s_dw + pr0;
         unsigned ha[NA][2], ma[NA][2], la[NA][2], hb[NB][2], mb[NB][2], lb[NB][2];
-        constexpr int P_SA = 2 * NA, P_WA = P_SA + NA, P_SB = P_WA + 2 * NB, P_WB = P_SB + NB, P_LA = P_WB + NA, P_LB = P_LA + NB;
+        constexpr int P_SA = PIN ? 0 : 2 * NA, P_WA = P_SA + NA * NLD, P_SB = P_WA + (PIN ? 0 : 2 * NB), P_WB = P_SB + NB * NLD,
+                      P_LA = P_WB + NA * NLD, P_LB = P_LA + NB * NLD;
         auto piece = [&](int w) {
+          if constexpr (PIN) {
+            // planes in: nothing to compute - 12 LDS stores of register set S (slab s + 1) into buffer sbuf, then the 12 loads of
+            // slab p0 into the same set, one piece behind each of the slab's 24 MFMAs
+            if (w < P_WA) {
+              const int j = w / 3, pl = w % 3;
+              *reinterpret_cast<u32x4_t*>(Ap + sbuf * BUFSZ + pl * BK * PA + (pr0 + PS * j) * PA + rc * 16) = ra[S][j * 3 + pl];
+            } else if (w < P_WB) {
+              const int i = (w - P_WA) / 3, pl = (w - P_WA) % 3, idx = t + NT * i;
+              if ((NBC % NT == 0) || idx < NBC)
+                *reinterpret_cast<u32x4_t*>(Bp + sbuf * BUFSZ + pl * BK * PB + (idx / CPB) * PB + (idx % CPB) * 16) = rb[S][i * 3 + pl];
+            } else if (w < P_LA) {
+              const int j = (w - P_WB) / 3, pl = (w - P_WB) % 3;
+              const bool v = row_ok && ((unsigned)(col0 + PS * j) < (unsigned)p.W);
+              ra[S][j * 3 + pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? a_voffc[j] : OOB), soff_a + pl * (int)p.x_plane_bytes, 0);
+            } else if (w < P_LB) {
+              const int i = (w - P_LA) / 3, pl = (w - P_LA) % 3;
+              rb[S][i * 3 + pl] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_dy, (int)b_voff[i], soff_b + pl * (int)p.dy_plane_bytes, 0);
+            }
+            return;
+          }
           if (w < P_SA) {
             const int j = w >> 1, hf = w & 1;
             const f32x4 f = __builtin_bit_cast(f32x4, ra[S][j]);
@@ -1250,17 +1319,17 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
   }
 }
 
-template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float>
+template <int BN, int WGM, int WGN, int PF, int NPL = 3, typename TA = float, bool PIN = false>
 int launch_wgrad_x6(const WgradParams& p, int S, hipStream_t st) {
   constexpr size_t lds = (size_t)PF * NPL * BK * (X6WPitch<BN>::A + X6WPitch<BN>::B) + (2 * 1024 + 4) * sizeof(int);
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(wgrad_x6_kernel<BN, WGM, WGN, PF, NPL, TA>, lds);
+    int rc = set_dyn_lds(wgrad_x6_kernel<BN, WGM, WGN, PF, NPL, TA, PIN>, lds);
     if (rc) return rc;
     attr_done = true;
   }
   const int64_t tiles = sg_cdiv(p.K, BM) * sg_cdiv(p.Cout, BN);
-  hipLaunchKernelGGL((wgrad_x6_kernel<BN, WGM, WGN, PF, NPL, TA>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
+  hipLaunchKernelGGL((wgrad_x6_kernel<BN, WGM, WGN, PF, NPL, TA, PIN>), dim3((unsigned)tiles, 1, (unsigned)S), dim3(64 * WGM * WGN), lds, st, p);
   SG_LAUNCH_CHECK("wgrad_x6_kernel");
   return 0;
 }

@@ -436,19 +436,23 @@ inline int launch_x6w(const IgemmParams& p, int S, char* scratch, hipStream_t st
     sg_set_error("conv_x6w: bad launch (%lld tiles, %d shares) or an operand beyond one 2 GiB buffer descriptor", (long long)tiles, S);
     return SG_EINVAL;
   }
-  {
+  // the activation planes: the caller's (sg_conv2d_fwd_stats_ap / _dgrad_ap: made once by sg_split_planes for every consumer of
+  // the tensor and for its filter gradient) or, without them, split here into the scratch
+  const unsigned short* aq = p.a_planes;
+  if (!aq) {
     int64_t blocks = sg_cdiv(rows * (p.C / 4), 256);
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(x6w_split_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p.x, (unsigned short*)scratch, rows, p.C, p.x_ld);
     SG_LAUNCH_CHECK("x6w_split_kernel");
+    aq = (const unsigned short*)scratch;
   }
   float* part = S > 1 ? reinterpret_cast<float*>(scratch + a_bytes) : nullptr;
   static const int var = getenv("SG_X6W_VAR") ? atoi(getenv("SG_X6W_VAR")) : 1;
   if (var == 1)
-    hipLaunchKernelGGL(conv_x6w_kernel<1>, dim3((unsigned)(tiles * S)), dim3(512), (size_t)XW_LDS, st, p, (const unsigned short*)scratch,
+    hipLaunchKernelGGL(conv_x6w_kernel<1>, dim3((unsigned)(tiles * S)), dim3(512), (size_t)XW_LDS, st, p, aq,
                        (uint32_t)(3 * plane), (uint32_t)plane, S, part);
   else
-    hipLaunchKernelGGL(conv_x6w_kernel<0>, dim3((unsigned)(tiles * S)), dim3(512), (size_t)XW_LDS, st, p, (const unsigned short*)scratch,
+    hipLaunchKernelGGL(conv_x6w_kernel<0>, dim3((unsigned)(tiles * S)), dim3(512), (size_t)XW_LDS, st, p, aq,
                        (uint32_t)(3 * plane), (uint32_t)plane, S, part);
   SG_LAUNCH_CHECK("conv_x6w_kernel");
   if (S > 1) {

@@ -110,16 +110,21 @@ class _ConvNode(Node):
         up2 = self._up2(rt)   # x is then the up-sampling's source
         d = self._up_desc(rt, x) if up2 else self.desc(rt, x)
         with rt.eng.timed(self._tag):
+            # training, fp32, a long-K multi-tap layer whose kernels read bf16 planes (csrc/conv_x6w.h, the planes-in filter
+            # gradient): the activation is split ONCE per step - for every consumer of the tensor (the ASPP input feeds five
+            # convolutions) and kept for this layer's filter gradient - instead of once per launch
+            xp = rt.act_planes(self, x, d) if (training and not up2) else None
             if training and getattr(self, "emit_bn_stats", False):
                 # the following BatchNormalization takes its statistics from this conv's epilogue
                 y, st = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=d, want_stats=True,
-                                          planes=None if up2 else rt.planes(self, "f"), up2=up2)
+                                          planes=None if up2 else rt.planes(self, "f"), up2=up2, x_planes=xp)
                 if st is not None:
                     rt.bn_stats[id(y)] = st
                 return y
             # the softmax head stays fp32 under bf16 storage (logits, probabilities, loss: SG_HEAD_F32)
             y = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=d, relu=self.activation == "relu",
-                                  head_f32=self.activation == "softmax", planes=None if up2 else rt.planes(self, "f"), up2=up2)
+                                  head_f32=self.activation == "softmax", planes=None if up2 else rt.planes(self, "f"), up2=up2,
+                                  x_planes=xp)
         if self.activation == "sigmoid":
             y = rt.eng.act_fwd(y, _lib.SG_ACT_SIGMOID, out=y)
         elif self.activation == "softmax":
@@ -141,6 +146,13 @@ class _ConvNode(Node):
         d = self._up_desc(rt, x) if up2 else self.desc(rt, x)
         with e.timed(self._tag):
             want_b = self.b is not None and not getattr(self, "bias_grad_zero", False)
+            # planes of the forward's activation (kept by rt.act_planes) and of dz: the planes-in filter gradient takes both as
+            # they are, the planes-in dgrad shares dz's (one split of dz instead of one per launch)
+            xp = None if up2 else rt.act_planes(self, x, d, make=False)
+            wg_planes = xp is not None and dz.dtype == x.dtype and e.conv2d_wgrad_planes_ok(d)
+            dzp = None
+            if dz.dtype == x.dtype and not up2 and (wg_planes or (rt.needs_grad(self.inputs[0]) and rt.planes_in_on() and e.conv2d_planes_in(d, True))):
+                dzp = e.split_planes(dz)
             # the input gradient first: the chain goes on with it, the filter gradient follows on the side stream beside the
             # bandwidth-bound kernels of the next node (two MFMA kernels side by side only share the matrix pipe)
             dx = None
@@ -158,9 +170,17 @@ class _ConvNode(Node):
                     while isinstance(root.node, _ActNode) and root.node.fused_away and len(root.consumers) == 1:
                         root = root.node.inputs[0]
                     res = rt.take_pending(root)
-                dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype, planes=rt.planes(self, "d"), res=res, down2=up2)
+                dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype, planes=rt.planes(self, "d"), res=res, down2=up2,
+                                    dy_planes=dzp if res is None else None)
             gw, gb = rt.grad(self.w), (rt.grad(self.b) if want_b else None)
-            e.side_run(self._tag, (x, dz), lambda: e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=gw, db=gb, x_up2=up2))
+            if wg_planes:
+                def wgrad_from_planes():
+                    e.conv2d_wgrad_planes(xp, dzp, d, dw=gw)
+                    if want_b:
+                        e.bias_grad(dz, gb)
+                e.side_run(self._tag, (xp, dzp, dz), wgrad_from_planes)
+            else:
+                e.side_run(self._tag, (x, dz), lambda: e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=gw, db=gb, x_up2=up2))
         return [dx]
 
     def flops(self, batch):

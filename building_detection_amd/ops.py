@@ -359,12 +359,14 @@ class Engine:
         return dtype == torch.float32 and bool(self.lib.sg_conv2d_up2_supported(SG_F32, C.byref(d)))
 
     def conv2d_fwd(self, x, w, b=None, stride=1, dilation=1, padding="same", relu=False, out=None, desc=None,
-                   want_stats=False, head_f32=False, planes=None, up2=False):
+                   want_stats=False, head_f32=False, planes=None, up2=False, x_planes=None):
         """want_stats: also return the BatchNormalization statistics of y as (stats tensor [tiles,2,Cout], tiles), or
         None when this launch could not produce them (then BN computes its own).
         head_f32 (bf16 storage only): the output is fp32 - the softmax head, a thin 1x1 convolution (SG_HEAD_F32).
         up2: x is the SOURCE [N, H/2, W/2, Cin] of a nearest 2x up-sampling and `desc` (required) names the convolution on
-        the up-sampled grid (SG_PRO_UP2: the sub-pixel kernel; the up-sampled tensor is never built)."""
+        the up-sampled grid (SG_PRO_UP2: the sub-pixel kernel; the up-sampled tensor is never built).
+        x_planes: split_planes(x), when the caller has them (sg_conv2d_fwd_stats_ap: the planes-in kernel then skips its own
+        split; any other kernel ignores them)."""
         _chk(x, "x"); _chk32(w, "w")
         kh, kw, cin, cout = w.shape
         d = desc or self.conv_desc(x.shape, cout, kh, kw, stride, dilation, padding)
@@ -384,16 +386,25 @@ class Engine:
             st = self.empty(self.lib.sg_conv2d_fwd_stats_bytes(C.byref(d)) // 4)
             tiles = C.c_int(0)
             with self.timed(self._gemm_tag()):
-                check(self.lib.sg_conv2d_fwd_stats(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y),
-                                                   flags, wsp, wsn, _ptr(st), C.byref(tiles)), "sg_conv2d_fwd_stats")
+                check(self.lib.sg_conv2d_fwd_stats_ap(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y),
+                                                      flags, wsp, wsn, _ptr(st), C.byref(tiles), _ptr(x_planes)), "sg_conv2d_fwd_stats")
             return y, ((st, tiles.value) if tiles.value > 0 else None)
         with self.timed(self._gemm_tag()):
-            check(self.lib.sg_conv2d_fwd_ws(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags,
-                                            wsp, wsn), "sg_conv2d_fwd_ws")
+            if x_planes is not None:
+                check(self.lib.sg_conv2d_fwd_stats_ap(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags,
+                                                      wsp, wsn, None, None, _ptr(x_planes)), "sg_conv2d_fwd_stats_ap")
+            else:
+                check(self.lib.sg_conv2d_fwd_ws(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags,
+                                                wsp, wsn), "sg_conv2d_fwd_ws")
         return y
 
+    def conv2d_planes_in(self, d: ConvDesc, dgrad: bool) -> bool:
+        """Does the fp32 forward (dgrad) launch of `d` read its activation as bf16 planes (csrc/conv_x6w.h)?  Then planes the
+        caller already has (split_planes) save the launch its own split."""
+        return bool(self.lib.sg_conv2d_planes_in(C.byref(d), 1 if dgrad else 0))
+
     def conv2d_dgrad(self, dy, w, d: ConvDesc, bias=None, relu=False, out=None, out_dtype=None, planes=None, res=None,
-                     down2=False):
+                     down2=False, dy_planes=None):
         """dx of the forward conv described by `d`; also Conv2DTranspose forward (then bias/relu apply).
         out_dtype = torch.bfloat16 with an fp32 dy: the backward of the fp32 softmax head of a bf16 model (SG_HEAD_F32).
         res: a gradient already collected for the same tensor, added in the kernel's epilogue (sg_conv2d_dgrad_acc: only for
@@ -417,6 +428,9 @@ class Engine:
             if res is not None:
                 check(self.lib.sg_conv2d_dgrad_acc(self.h, self.stream, dt, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
                                                    flags, wsp, wsn, _ptr(res)), "sg_conv2d_dgrad_acc")
+            elif dy_planes is not None:
+                check(self.lib.sg_conv2d_dgrad_ap(self.h, self.stream, dt, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
+                                                  flags, wsp, wsn, _ptr(dy_planes)), "sg_conv2d_dgrad_ap")
             else:
                 check(self.lib.sg_conv2d_dgrad(self.h, self.stream, dt, C.byref(d), _ptr(dy), _ptr(w), _ptr(bias), _ptr(dx),
                                                flags, wsp, wsn), "sg_conv2d_dgrad")
@@ -440,6 +454,29 @@ class Engine:
             check(self.lib.sg_conv2d_wgrad(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
                                            _ptr(db) if want_bias else None, wsp, wsn), "sg_conv2d_wgrad")
         return dw, (db if want_bias else None)
+
+    def split_planes(self, x, out=None):
+        """x [..., C] fp32 -> int16 tensor [3, rows, C]: the three bf16 planes of the exact split a1 + a2 + a3 = x (sg_split_planes)."""
+        _chk32(x, "x")
+        c = x.shape[-1]
+        rows = x.numel() // c
+        pl = out if out is not None else torch.empty((3, rows, c), dtype=torch.int16, device=x.device)
+        check(self.lib.sg_split_planes(self.h, self.stream, _ptr(x), rows, c, c, _ptr(pl)), "sg_split_planes")
+        return pl
+
+    def conv2d_wgrad_planes_ok(self, d: ConvDesc) -> bool:
+        return bool(self.lib.sg_conv2d_wgrad_planes_supported(self.h, C.byref(d)))
+
+    def conv2d_wgrad_planes(self, x_planes, dy_planes, d: ConvDesc, dw=None):
+        """The fp32 filter gradient from operands that are already split into bf16 planes (sg_conv2d_wgrad_planes): the bits of
+        conv2d_wgrad on the fp32 tensors, without the per-launch VALU split."""
+        if dw is None:
+            dw = self.empty(d.KH, d.KW, d.Cin, d.Cout)
+        wsp, wsn = self.ws(self.lib.sg_conv2d_wgrad_ws_bytes(self.h, C.byref(d)))
+        with self.timed(self._gemm_tag()):
+            check(self.lib.sg_conv2d_wgrad_planes(self.h, self.stream, C.byref(d), _ptr(x_planes), _ptr(dy_planes), _ptr(dw), wsp, wsn),
+                  "sg_conv2d_wgrad_planes")
+        return dw
 
     def bias_grad(self, dy, db):
         """db[C] = column sums of dy[..., C] (bias gradient of Conv2DTranspose / stand-alone use)."""

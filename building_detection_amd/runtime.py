@@ -897,6 +897,8 @@ class _Runtime:
         self.eng = get_engine(dev)  # makes `dev` torch's current device (Engine.__init__)
         e = self.eng
         self._up2: Dict[tuple, bool] = {}   # up_sampling2d node -> fused with its convolution on this runtime (up2_on)
+        self._act_planes: Dict[int, tuple] = {}      # id(symbolic tensor) -> (fp32 activation, its bf16 planes) of this step
+        self._act_planes_use: Dict[int, bool] = {}   # id(conv node) -> its forward reads planes (geometry)
         self.w_train = e.zeros(max(model._n_train, ALIGN))
         self.g_train = e.zeros(max(model._n_train, ALIGN))
         self.adam_m = e.zeros(max(model._n_train, ALIGN))
@@ -966,6 +968,33 @@ class _Runtime:
             _lib.check(self.eng.lib.sg_prepare_planes(self.eng.h, self.eng.stream, C.c_void_p(self.w_train.data_ptr()),
                                                       C.c_void_p(arena.data_ptr()), C.c_void_p(jobs.data_ptr()), launch[0],
                                                       launch[1]), "sg_prepare_planes")
+
+    def planes_in_on(self) -> bool:
+        """fp32 storage with the six-pass arithmetic, SG_ACT_PLANES != 0: activation planes are made once per tensor and step."""
+        return (self.model.compute_dtype == "float32" and os.environ.get("SG_ACT_PLANES", "1") != "0"
+                and int(self.eng.lib.sg_get_conv_x6()) == 1)
+
+    def act_planes(self, node, x, d, make=True):
+        """The three bf16 planes of activation `x` (Engine.split_planes), made at most once per tensor and training step - every
+        consumer whose forward reads planes (csrc/conv_x6w.h) shares them and its filter gradient takes them again (kept until
+        the step's backward sweep ends: release()).  None when `node`'s launches have no use for them."""
+        if not self.planes_in_on():
+            return None
+        key = id(node.inputs[0])
+        got = self._act_planes.get(key)
+        if got is not None and got[0] is x:
+            return got[1]
+        if not make:
+            return None
+        use = self._act_planes_use.get(id(node))
+        if use is None:   # decided once per node from its geometry
+            use = bool(self.eng.conv2d_planes_in(d, False))
+            self._act_planes_use[id(node)] = use
+        if not use:
+            return None
+        pl = self.eng.split_planes(x)
+        self._act_planes[key] = (x, pl)
+        return pl
 
     def up2_on(self, up_node) -> bool:
         """Does THIS runtime run the pair `up_node` -> 3x3 convolution (Model._fuse: fused_into / up_src) on the fused kernels?
@@ -1075,6 +1104,7 @@ class _Runtime:
         self.values.clear()
         self._saved.clear()
         self.bn_stats.clear()
+        self._act_planes.clear()
 
     def forward(self, x, training: bool):
         m = self.model
@@ -1086,6 +1116,7 @@ class _Runtime:
         if m.compute_dtype == "bfloat16":  # activations are bf16 from the first layer on (sg_cast, round to nearest even)
             x = self.eng.cast(x, self.torch.bfloat16)
         self.values = {id(m.inputs[0]): x}
+        self._act_planes.clear()   # (a step's activation planes: made in this sweep, read again by its filter gradients)
         if training:
             for n in m.nodes:
                 xs = [self.values[id(t)] for t in n.inputs]
@@ -1157,4 +1188,5 @@ class _Runtime:
                 if self.node_done_fires is None or self.node_done_fires(n.index):
                     e.join_side()  # a bucket's all-reduce reads filter gradients the side stream may still be writing
                 hook(n.index)  # data-parallel: launches the all-reduce of every gradient bucket now complete
+        self._act_planes.clear()   # (the side stream's launches hold their own references)
         e.join_side()  # Adam, get_gradients() and the loss-scaling checks read the gradients on the main stream

@@ -164,6 +164,32 @@ size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d);
 int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
                     const void* dy, void* dw, void* dbias, void* ws, size_t ws_bytes);
 
+/* Planes-in filter gradient (round 5).  The fp32 ("x6") filter gradient splits BOTH of its operands into three bf16 planes on
+ * the VALU in every launch; where the planes already exist - the forward's activation planes of a long-K convolution, kept - the
+ * kernel can take them as they are:
+ *   sg_split_planes          x[rows][ld] fp32 (C channels used) -> planes[3][rows][C] bf16, the exact 3-way split of conv_x6.h
+ *                            (a1 + a2 + a3 = x; the layout the planes-in forward kernel conv_x6w.h reads).
+ *   sg_conv2d_wgrad_planes   dw[KH,KW,Cin,Cout] of the convolution `d` from x_planes[3][N*H*W][Cin] and dy_planes[3][N*Ho*Wo][Cout];
+ *                            same products in the same order as sg_conv2d_wgrad on the fp32 tensors (bit-identical), no bias
+ *                            gradient (sg_bias_grad).  ws: sg_conv2d_wgrad_ws_bytes(ctx, d).  Stride 1, SAME, Wo % 32 = 0,
+ *                            channels % 8 = 0, not a layer of the wide-pointwise / patch families; _supported() tells.
+ * Replaces the filter gradient of the ASPP / SK / decoder 3x3 convolutions (train_model/DeepLabv3plus.py:219-229, 431-443). */
+int sg_split_planes(sg_ctx* ctx, void* stream, const void* x, int64_t rows, int C, int ld, void* planes);
+/* The forward / input gradient with the activation's planes handed in.  The long-K multi-tap launches (csrc/conv_x6w.h: the ASPP /
+ * SK / decoder 3x3 convolutions) read their A operand as sg_split_planes' planes and otherwise split it themselves in every
+ * launch; x_planes / dy_planes (may be null) = the planes of the very tensor passed as x / dy, dense [3][pixels][C].  The five
+ * consumers of the ASPP input share ONE split this way, and a layer's dy planes serve its dgrad and its filter gradient.
+ * Launches that take another kernel ignore the planes.  sg_conv2d_planes_in(d, dgrad): 1 if the launch reads planes. */
+int sg_conv2d_planes_in(const sg_conv_desc* d, int dgrad);
+int sg_conv2d_fwd_stats_ap(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
+                           const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out,
+                           const void* x_planes);
+int sg_conv2d_dgrad_ap(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
+                       const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* dy_planes);
+int sg_conv2d_wgrad_planes_supported(const sg_ctx* ctx, const sg_conv_desc* d);
+int sg_conv2d_wgrad_planes(sg_ctx* ctx, void* stream, const sg_conv_desc* d, const void* x_planes, const void* dy_planes, void* dw,
+                           void* ws, size_t ws_bytes);
+
 /* Bias gradient db[C] = column sums of dy[rows][C] (pixel stride ld, 0 = C); fixed-order two-stage reduce.
  * Used for the bias of Conv2DTranspose (v3plus.py:328,335; scse.py:71-89; res34.py:144), whose kernel
  * gradient comes from sg_conv2d_wgrad with the operand roles swapped. */

@@ -715,6 +715,42 @@ def test_batchnorm_applied_in_the_depthwise_gather(engine, policy, monkeypatch):
     assert np.array_equal(ma.predict(x), mb.predict(x)) or not exact   # inference never defers: same graph, same weights
 
 
+def test_activation_planes_once_per_step_give_the_same_bits(engine, monkeypatch):
+    """Round 5 (_Runtime.act_planes, layers._ConvNode): in training the activation planes of the long-K 3x3 layers are made once
+    per tensor and step - the five consumers of the ASPP input share one split, each layer's filter gradient takes the kept
+    planes and the planes of its dy (wgrad_x6_kernel<.., PIN>) - instead of once per launch inside the kernels (SG_ACT_PLANES=0).
+    Same split, same products, same order: loss, every gradient and the weights after two Adam steps are bit-identical, and the
+    planes-in launches really happen.  (At 128 x 128 the ASPP / SK maps are 8 x 8: the decoder's 64-row maps take the kernels.)"""
+    from building_detection_amd import zoo
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss
+    ma = zoo.Xception_DeepLabV3_Plus((512, 512, 3), 2)
+    mb = zoo.Xception_DeepLabV3_Plus((512, 512, 3), 2)
+    mb.set_weights(ma.get_weights())
+    x, y = synthetic_batch(1, 512, 512, seed=79)
+    for m in (ma, mb):
+        m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
+    calls = {"split": 0, "wgrad_planes": 0}
+    o_split, o_wg = engine.split_planes, engine.conv2d_wgrad_planes
+    monkeypatch.setattr(engine, "split_planes", lambda t, out=None: (calls.__setitem__("split", calls["split"] + 1), o_split(t, out))[1])
+    monkeypatch.setattr(engine, "conv2d_wgrad_planes", lambda *a, **k: (calls.__setitem__("wgrad_planes", calls["wgrad_planes"] + 1), o_wg(*a, **k))[1])
+    for step in range(2):
+        monkeypatch.setenv("SG_ACT_PLANES", "0")
+        la = ma.train_on_batch(x, y)
+        assert calls["split"] == 0 and calls["wgrad_planes"] == 0
+        monkeypatch.setenv("SG_ACT_PLANES", "1")
+        lb = mb.train_on_batch(x, y)
+        assert la["loss"] == lb["loss"], (step, la, lb)
+        for ga, gb in zip(ma.get_gradients(), mb.get_gradients()):
+            assert np.array_equal(ga, gb)
+        # ASPP input (shared by its three dilated branches and the SK block's 3x3 entry) + the decoder's two 64 x 64 layers: three
+        # activation splits, one split of dz per layer; six (seven with the SK entry) planes-in filter gradients
+        assert calls["wgrad_planes"] >= 6 and calls["split"] < 3 + 2 * calls["wgrad_planes"], calls
+        calls["split"] = calls["wgrad_planes"] = 0
+    for wa, wb in zip(ma.get_weights(), mb.get_weights()):
+        assert np.array_equal(wa, wb)
+
+
 def test_upsampling_fused_into_the_decoder_convolution(engine, monkeypatch):
     """Model level of tests/test_ops_gpu.py::test_upsampling_fused_into_the_3x3_convolution: DeepLabv3+'s last decoder stage
     `UpSampling2D(2) -> conv_bn_relu(32)` (train_model/DeepLabv3plus.py:476-477) runs on the fused kernels by default

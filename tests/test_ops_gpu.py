@@ -924,6 +924,46 @@ def test_upsampling_fused_into_the_3x3_convolution(engine, shape):
         engine.conv2d_fwd(xd, wd, bd, desc=d_bad, up2=True)
 
 
+@pytest.mark.parametrize("case", [(2, 32, 32, 2048, 256, 3, 6), (3, 32, 32, 1024, 256, 3, 18), (1, 64, 64, 512, 256, 3, 1), (2, 32, 64, 256, 136, 3, 2),
+                                  (2, 32, 32, 264, 40, 3, 1), (2, 32, 32, 1280, 256, 1, 1)],
+                         ids=["aspp_d6", "aspp_like_d18_b3", "decoder_512", "w64_cout136_d2", "ragged_c264_cout40", "pointwise_1280"])
+def test_activation_planes_handed_in(engine, case):
+    """Round 5: sg_split_planes + sg_conv2d_fwd_stats_ap / _dgrad_ap / sg_conv2d_wgrad_planes.  The long-K fp32 convolutions read
+    their activation as three bf16 planes (conv_x6w.h) and split it in every launch; with the planes handed in - made once per
+    tensor and step - forward and dgrad skip that split and the filter gradient (wgrad_x6_kernel<.., PIN>) takes BOTH operands as
+    planes instead of splitting them on the VALU.  The planes ARE the exact split the kernels make themselves, so every result
+    must have the bits of the launch without them; the planes themselves must add up to the tensor exactly."""
+    n, h, w, cin, cout, k, dil = case
+    g = torch.Generator().manual_seed(cin + dil)
+    x = rnd(g, n, h, w, cin).cuda()
+    wt = (rnd(g, k, k, cin, cout) * (1.0 / np.sqrt(k * k * cin))).cuda()
+    b = rnd(g, cout).cuda()
+    dy = rnd(g, n, h, w, cout).cuda()
+    d = engine.conv_desc(tuple(x.shape), cout, k, k, 1, dil, "same")
+    xp, dyp = engine.split_planes(x), engine.split_planes(dy)
+    assert tuple(xp.shape) == (3, n * h * w, cin) and xp.dtype == torch.int16
+    parts = (xp.view(torch.bfloat16).double().sum(0)).view(n, h, w, cin)   # a1 + a2 + a3, exact in fp64
+    assert torch.equal(parts, x.double()), "the three planes do not add up to the tensor"
+    y0, st0 = engine.conv2d_fwd(x, wt, b, desc=d, want_stats=True)
+    y1, st1 = engine.conv2d_fwd(x, wt, b, desc=d, want_stats=True, x_planes=xp)
+    assert torch.equal(y0, y1) and (st0 is None) == (st1 is None)
+    if st0 is not None:
+        assert st0[1] == st1[1] and torch.equal(st0[0], st1[0])
+    assert torch.equal(engine.conv2d_fwd(x, wt, None, desc=d, relu=True), engine.conv2d_fwd(x, wt, None, desc=d, relu=True, x_planes=xp))
+    assert torch.equal(engine.conv2d_dgrad(dy, wt, d), engine.conv2d_dgrad(dy, wt, d, dy_planes=dyp))
+    dw0, _ = engine.conv2d_wgrad(x, dy, d, want_bias=False)
+    if engine.conv2d_wgrad_planes_ok(d):
+        dw1 = engine.conv2d_wgrad_planes(xp, dyp, d)
+        assert torch.equal(dw0, dw1), "planes-in filter gradient: not the bits of the fp32-operand kernel"
+    else:
+        assert k == 1, "only the wide pointwise layer of these cases belongs to another kernel family"
+    xr, wr = x.cpu().double().requires_grad_(), wt.cpu().double().requires_grad_()
+    T.conv2d(xr, wr, b.cpu().double(), 1, dil, "same").backward(dy.cpu().double())
+    close(dw0, wr.grad, what="filter gradient vs fp64")
+    # which launches read planes: the long-K multi-tap ones (the query the runtime asks before it makes planes)
+    assert engine.conv2d_planes_in(d, False) == (k == 3 and k * k * cin >= 2048 and cout >= 192)
+
+
 def test_sub_batch_paths_of_oversized_tensors(engine):
     """activations beyond 2 GiB run as sub-batches of whole images (forward, dgrad) / as chunks with one reduce
     (wgrad).  SG_CONV_MAX_BYTES (read once per process) lowers that limit, so a child process runs a 5-image convolution
