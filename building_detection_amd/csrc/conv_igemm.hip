@@ -2706,7 +2706,9 @@ int sg_conv2d_wgrad_planes(sg_ctx* ctx, void* stream, const sg_conv_desc* d, con
   const int bn = wgrad_bn(p.Cout);
   // SG_WGRAD_PIN_PF: 1 = single LDS buffer, two workgroups per CU (the fp32-operand kernel's default structure); 2 = one workgroup
   // per CU, two buffers, the stores of slab s + 1 and the loads of slab s + 3 woven between the MFMAs of slab s
-  static const int pf = getenv("SG_WGRAD_PIN_PF") ? atoi(getenv("SG_WGRAD_PIN_PF")) : 2;
+  // Measured (scripts/wgrad_planes_bench.py, fourteen long-K shapes, gpurun_out/r5h): 7301 us with PF 1, 7577 with PF 2, 8485 for
+  // the fp32-operand kernel - the read + MFMA loop itself takes 640 of the 810 us of the ASPP launch either way.
+  static const int pf = getenv("SG_WGRAD_PIN_PF") ? atoi(getenv("SG_WGRAD_PIN_PF")) : 1;
   static const int w22 = getenv("SG_WGRAD_PIN_W22") ? atoi(getenv("SG_WGRAD_PIN_W22")) : 0;   // experiment: 4 waves of 64 x 64 per 128 x 128 tile
   if (w22 && bn == 128) {
     rc = (pf == 2) ? launch_wgrad_x6<128, 2, 2, 2, 3, bf16_t, true>(p, pl.S, st) : launch_wgrad_x6<128, 2, 2, 1, 3, bf16_t, true>(p, pl.S, st);

@@ -46,3 +46,16 @@ timed("up-sampling backward (2x2 sums)", lambda: e.upsample_bwd(dxu, tuple(x.sha
 timed("FUSED dgrad with the 2x2 sum in the epilogue", lambda: e.conv2d_dgrad(dy, w, d, out=dxs, down2=True))
 timed("filter gradient on the materialised tensor", lambda: e.conv2d_wgrad(up, dy, d))
 timed("FUSED filter gradient gathering the source", lambda: e.conv2d_wgrad(x, dy, d, x_up2=True))
+
+# the input gradient as ONE 4x4 stride-2 convolution of dy with summed taps (the 2x2 sum taken before the products: 4/9 of them)
+S = {-1: [2], 0: [1, 2], 1: [0, 1], 2: [0]}
+wd = torch.zeros(4, 4, 32, 64, device="cuda")
+for u in range(-1, 3):
+    for v in range(-1, 3):
+        for kh in S[u]:
+            for kw in S[v]:
+                wd[u + 1, v + 1] += w[kh, kw].t()
+ref = e.conv2d_dgrad(dy, w, d, down2=True)
+got = e.conv2d_fwd(dy, wd, None, stride=2, padding="same")
+print("4x4 stride-2 form vs fused dgrad: max |diff|", float((got - ref).abs().max()), "of", float(ref.abs().max()))
+timed("input gradient as a 4x4 stride-2 convolution of dy", lambda: e.conv2d_fwd(dy, wd, None, stride=2, padding="same", out=dxs))
