@@ -44,6 +44,13 @@ class ConvDesc(C.Structure):
         "x_ld", "y_ld")]
 
 
+class BnIn(C.Structure):
+    """Mirror of `sg_bn_in` (include/segengine.h): a BatchNormalization (+ReLU) applied to a convolution's input in its loader."""
+
+    _fields_ = [("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("relu", C.c_int32), ("infer", C.c_int32), ("eps", C.c_float)]
+
+
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _dp = C.POINTER(ConvDesc)
 _pp = C.POINTER(C.c_void_p)
@@ -73,6 +80,9 @@ _SIGNATURES = {
     "sg_conv2d_dgrad_acc": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "sg_conv2d_wgrad_ws_bytes": (_sz, [_vp, _dp]),
     "sg_conv2d_wgrad": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _vp, _sz]),
+    "sg_conv2d_bn_in_supported": (_i, [_vp, _i, _dp]),
+    "sg_conv2d_fwd_stats_bn": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, C.POINTER(C.c_int), C.POINTER(BnIn)]),
+    "sg_conv2d_wgrad_bn": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(BnIn)]),
     "sg_split_planes": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "sg_conv2d_planes_in": (_i, [_dp, _i]),
     "sg_conv2d_fwd_stats_ap": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, C.POINTER(C.c_int), _vp]),

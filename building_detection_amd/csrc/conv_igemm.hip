@@ -38,6 +38,30 @@ constexpr int LDA = BK + 4;  // floats; 144-byte rows
 template <int V>
 using IC = std::integral_constant<int, V>;
 
+// A BatchNormalization (+ReLU) applied to the convolution's INPUT while it is loaded (round 5: sg_conv2d_fwd_stats_bn /
+// sg_conv2d_wgrad_bn; the patch kernels and the thin 1x1 kernels): y = [relu](fmaf((x - mean) * invstd, gamma, beta)), bn_apply's own
+// expression, on every pixel inside the image (the zero padding stays zero).  mean == nullptr: none.
+struct BnIn {
+  const float* mean;
+  const float* invstd;   // infer: the moving variance, invstd = rsqrtf(var + eps)
+  const float* gamma;
+  const float* beta;
+  int relu, infer;
+  float eps;
+};
+__device__ __forceinline__ f32x4 bn_in_inv(const BnIn& b, int c) {
+  f32x4 is = *reinterpret_cast<const f32x4*>(b.invstd + c);
+  if (b.infer) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) is[k] = rsqrtf(is[k] + b.eps);
+  }
+  return is;
+}
+__device__ __forceinline__ float bn_in_one(float x, float m, float is, float g, float bt, int relu) {
+  const float t = fmaf((x - m) * is, g, bt);
+  return relu ? fmaxf(t, 0.f) : t;
+}
+
 struct IgemmParams {
   const float* __restrict__ x;
   const float* __restrict__ w;
@@ -76,6 +100,7 @@ struct IgemmParams {
   // the A operand already split into three bf16 planes [3][pixels][C] (sg_split_planes; sg_conv2d_fwd_stats_ap / _dgrad_ap): the
   // planes-in kernel (conv_x6w.h) reads them instead of splitting x itself; ignored by every other kernel; null: none
   const unsigned short* a_planes;
+  BnIn bn;   // conv_x6p_kernel only: the BatchNormalization applied in the patch loader (mean == nullptr: none)
   // host side only: bytes of workspace that start at the weight planes (the planes, then scratch of a split-K launch:
   // conv_b16w.h); SIZE_MAX = prepared planes, whose arena slot sg_conv2d_planes_job sized for both
   size_t ws_room;
@@ -538,6 +563,7 @@ struct WgradParams {
   int tap_inner;               // tile order (channel block, tap, column tile) instead of (tap, channel block, column tile)
   uint32_t x_plane_bytes, dy_plane_bytes;   // planes-in filter gradient (wgrad_x6_kernel<.., PIN>): bytes from one bf16 plane of
                                //    x / dy to the next; x_bytes / dy_bytes then cover all three
+  BnIn bn;                     // wgrad_x6wp_kernel only: the BatchNormalization applied to x in the patch loader (mean == nullptr: none)
   int up;                      // 1: x is the source of a nearest 2x up-sampling (SG_X_UP2; wgrad_x6wp_kernel only): pixel (h, w)
                                //    of the H x W tensor is x[n, h >> 1, w >> 1, :] of the (H / 2) x (W / 2) source
   FastDiv fd_ohow, fd_ow, fd_c, fd_kw, fd_oh;
@@ -1486,7 +1512,7 @@ int check_desc(const sg_conv_desc* d, const char* who) {
 template <int CO, typename TA, typename TY>
 __global__ __launch_bounds__(256) void thin_fwd_kernel(const TA* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ bias, TY* __restrict__ y, int64_t P,
-                                                       int chunks, int x_ld, int y_ld, int LP, int flags) {
+                                                       int chunks, int x_ld, int y_ld, int LP, int flags, const BnIn bn) {
   constexpr int PIX = 4;  // pixels per lane group: four independent 16-byte loads in flight
   const int t = threadIdx.x;
   const int gpb = 256 / LP;  // lane groups per block
@@ -1510,6 +1536,14 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(const TA* __restrict__ x,
     for (int i = 0; i < PIX; ++i) {
       const f32x4 z = {0.f, 0.f, 0.f, 0.f};
       xv[i] = pix[i] < P ? ld4<TA>(x + pix[i] * x_ld + 4 * c) : z;
+    }
+    if (bn.mean) {   // uniform: the BatchNormalization (+ReLU) in front of this layer, applied here
+      const f32x4 bm = *reinterpret_cast<const f32x4*>(bn.mean + 4 * c), bi = bn_in_inv(bn, 4 * c);
+      const f32x4 bg = *reinterpret_cast<const f32x4*>(bn.gamma + 4 * c), bb = *reinterpret_cast<const f32x4*>(bn.beta + 4 * c);
+#pragma unroll
+      for (int i = 0; i < PIX; ++i)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) xv[i][k] = pix[i] < P ? bn_in_one(xv[i][k], bm[k], bi[k], bg[k], bb[k], bn.relu) : 0.f;
     }
 #pragma unroll
     for (int i = 0; i < PIX; ++i)
@@ -1571,10 +1605,18 @@ struct ThinWgradOp {
   const TY* __restrict__ dy;
   float* dw;
   int x_ld, y_ld;
+  BnIn bn;   // the BatchNormalization (+ReLU) in front of the layer, applied to x here (mean == nullptr: none)
   template <int V>
   __device__ __forceinline__ void accum(int, int64_t r, int c, float (&acc)[CO][V]) const {
     float v[V];
     ldv<V>(x + r * x_ld + c, v);
+    if (bn.mean) {   // uniform
+#pragma unroll
+      for (int k = 0; k < V; ++k) {
+        const float is = bn.infer ? rsqrtf(bn.invstd[c + k] + bn.eps) : bn.invstd[c + k];
+        v[k] = bn_in_one(v[k], bn.mean[c + k], is, bn.gamma[c + k], bn.beta[c + k], bn.relu);
+      }
+    }
 #pragma unroll
     for (int o = 0; o < CO; ++o) {
       const float g = ld1<TY>(dy + r * y_ld + o);
@@ -1607,15 +1649,24 @@ size_t thin_part_bytes(int num_cus, const sg_conv_desc* d) {
   }
 }
 
+inline BnIn bn_in_none() {
+  BnIn b;
+  b.mean = b.invstd = b.gamma = b.beta = nullptr;
+  b.relu = b.infer = 0;
+  b.eps = 0.f;
+  return b;
+}
+
 template <int CO, typename TA, typename TY>
-int thin_fwd_t(const sg_conv_desc* d, const TA* x, const float* w, const float* bias, TY* y, int flags, hipStream_t st) {
+int thin_fwd_t(const sg_conv_desc* d, const TA* x, const float* w, const float* bias, TY* y, int flags, hipStream_t st,
+               const BnIn bn = bn_in_none()) {
   const int64_t P = (int64_t)d->N * d->H * d->W;
   const int chunks = d->Cin / 4;
   int LP = 1;
   while (LP * 2 <= chunks && LP < 64) LP <<= 1;
   const int64_t groups = sg_cdiv(P, (int64_t)4 * (256 / LP));
   hipLaunchKernelGGL((thin_fwd_kernel<CO, TA, TY>), dim3((unsigned)groups), dim3(256), 0, st, x, w, bias, y, P, chunks,
-                     d->x_ld ? d->x_ld : d->Cin, d->y_ld ? d->y_ld : d->Cout, LP, flags);
+                     d->x_ld ? d->x_ld : d->Cin, d->y_ld ? d->y_ld : d->Cout, LP, flags, bn);
   SG_LAUNCH_CHECK("thin_fwd_kernel");
   return 0;
 }
@@ -1632,11 +1683,13 @@ int thin_dgrad_t(const sg_conv_desc* d, const TY* dy, const float* w, TA* dx, hi
 }
 
 template <int CO, typename TA, typename TY>
-int thin_wgrad_t(int num_cus, const sg_conv_desc* d, const TA* x, const TY* dy, float* dw, float* part, hipStream_t st) {
+int thin_wgrad_t(int num_cus, const sg_conv_desc* d, const TA* x, const TY* dy, float* dw, float* part, hipStream_t st,
+                 const BnIn bn = bn_in_none()) {
   const int64_t P = (int64_t)d->N * d->H * d->W;
   const SegPlan pl = seg_plan<CO>(num_cus, 1, P, d->Cin, true);
   ThinWgradOp<CO, TA, TY> op;
   op.x = x; op.dy = dy; op.dw = dw;
+  op.bn = bn;
   op.x_ld = d->x_ld ? d->x_ld : d->Cin;
   op.y_ld = d->y_ld ? d->y_ld : d->Cout;
   return seg_reduce_launch(op, pl, 1, P, d->Cin, part, st, "thin_wgrad");
@@ -1803,6 +1856,7 @@ void fill_fwd_params(IgemmParams& p, const sg_conv_desc* d, const void* x, const
   p.perm2 = 0;
   p.res = nullptr;
   p.a_planes = nullptr;
+  p.bn.mean = nullptr;
   p.ws_room = 0;
 }
 
@@ -1830,6 +1884,7 @@ void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, co
   p.perm2 = 0;
   p.res = nullptr;
   p.a_planes = nullptr;
+  p.bn.mean = nullptr;
   p.ws_room = 0;
 }
 
@@ -1978,7 +2033,47 @@ size_t sg_conv2d_fwd_stats_bytes(const sg_conv_desc* d) {
 
 static int conv2d_fwd_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
                            const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out,
-                           const void* x_planes);
+                           const void* x_planes, const sg_bn_in* bn = nullptr);
+
+static BnIn bn_in_of(const sg_bn_in* b) {
+  BnIn o = bn_in_none();
+  if (b && b->mean) {
+    o.mean = (const float*)b->mean; o.invstd = (const float*)b->invstd; o.gamma = (const float*)b->gamma; o.beta = (const float*)b->beta;
+    o.relu = b->relu; o.infer = b->infer; o.eps = b->eps;
+  }
+  return o;
+}
+// geometry of the launches that can apply a BatchNormalization to their input: the thin 1x1 kernels (Cout <= 4) and the patch
+// kernels (3x3, stride 1, SAME, 32 / 64 input channels: conv_x6p.h forward, conv_x6wp.h filter gradient), fp32 storage
+static bool bn_in_geom(const sg_ctx* ctx, int dtype, const sg_conv_desc* d, bool* thin_out) {
+  if ((dtype & 0xff) != SG_F32 || (dtype & (SG_HEAD_F32 | SG_X_UP2))) return false;
+  if ((d->x_ld && d->x_ld != d->Cin)) return false;
+  const bool thin = thin_ok(d);
+  if (thin_out) *thin_out = thin;
+  if (thin) return true;
+  if (x6_mode() != 1 || !x6p_enabled()) return false;
+  if (d->KH != 3 || d->KW != 3 || d->stride != 1 || d->dilation != 1 || d->pad_t != 1 || d->pad_l != 1 || d->Ho != d->H || d->Wo != d->W) return false;
+  if (!(d->Cin == 32 || d->Cin == 64) || (d->H % 8) || (d->W % 16)) return false;
+  if (!(d->Cout == 32 || d->Cout == 64 || d->Cout % 128 == 0)) return false;
+  return plan_wgrad(ctx->num_cus, d, false).patch != 0;   // forward AND filter gradient must both take the patch kernels
+}
+
+int sg_conv2d_bn_in_supported(const sg_ctx* ctx, int dtype, const sg_conv_desc* d) {
+  return (ctx && d && check_desc(d, "sg_conv2d_bn_in_supported") == 0 && bn_in_geom(ctx, dtype, d, nullptr)) ? 1 : 0;
+}
+
+int sg_conv2d_fwd_stats_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
+                           const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out,
+                           const sg_bn_in* bn) {
+  SG_CHECK_ARG(bn && bn->mean && bn->invstd && bn->gamma && bn->beta, "sg_conv2d_fwd_stats_bn: null BatchNormalization parameters");
+  SG_CHECK_ARG(ctx && d, "sg_conv2d_fwd_stats_bn: null argument");
+  if (check_desc(d, "sg_conv2d_fwd_stats_bn") || !bn_in_geom(ctx, dtype, d, nullptr) || (flags & SG_PRO_UP2)) {
+    sg_set_error("sg_conv2d_fwd_stats_bn: this launch takes neither a thin 1x1 nor a patch kernel (3x3 s1 SAME, 32 / 64 input channels, "
+                 "fp32 storage): no kernel to apply the BatchNormalization in");
+    return SG_EUNSUPPORTED;
+  }
+  return conv2d_fwd_impl(ctx, stream, dtype, d, x, w, bias, y, flags, ws, ws_bytes, stats, tiles_out, nullptr, bn);
+}
 
 int sg_conv2d_fwd_stats(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
                         const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out) {
@@ -2010,7 +2105,7 @@ int sg_conv2d_planes_in(const sg_conv_desc* d, int dgrad) {
 
 static int conv2d_fwd_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
                            const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out,
-                           const void* x_planes) {
+                           const void* x_planes, const sg_bn_in* bn) {
   if (tiles_out) *tiles_out = 0;
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_fwd: null ctx");
   SG_CHECK_ARG(dt_ok(dtype), "sg_conv2d_fwd: dtype %d", dtype);
@@ -2081,7 +2176,7 @@ static int conv2d_fwd_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_d
         const char* xs = (const char*)x + (int64_t)n0 * d->H * d->W * xl * eb;
         char* ys = (char*)y + (int64_t)n0 * d->Ho * d->Wo * yl * eb;
         g_sub_batch = true;   // the weight planes were laid out for the whole batch: no batch-size dependent kernel choice
-        int rcs = sg_conv2d_fwd_ws(ctx, stream, dtype, &sub, xs, w, bias, ys, flags, ws, ws_bytes);  // (no statistics)
+        int rcs = conv2d_fwd_impl(ctx, stream, dtype, &sub, xs, w, bias, ys, flags, ws, ws_bytes, nullptr, nullptr, nullptr, bn);  // (no statistics)
         g_sub_batch = false;
         if (rcs) return rcs;
       }
@@ -2090,7 +2185,7 @@ static int conv2d_fwd_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_d
   }
   if (thin_ok(d) && aligned16(x)) {
     if (!b16) {
-#define CALL(CO) thin_fwd_t<CO, float, float>(d, (const float*)x, (const float*)w, (const float*)bias, (float*)y, flags, st)
+#define CALL(CO) thin_fwd_t<CO, float, float>(d, (const float*)x, (const float*)w, (const float*)bias, (float*)y, flags, st, bn_in_of(bn))
       THIN_SWITCH(d->Cout, CALL)
 #undef CALL
     } else if (head32) {
@@ -2106,8 +2201,13 @@ static int conv2d_fwd_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_d
   IgemmParams p;
   fill_fwd_params(p, d, x, w, bias, y, flags, eb);
   if (!b16 && p.x_ld == d->Cin) p.a_planes = (const unsigned short*)x_planes;
+  p.bn = bn_in_of(bn);
   const int ch = b16 ? 8 : 4;
   const bool vec = (d->Cin % ch == 0) && (p.x_ld % ch == 0) && (d->Cout % 4 == 0) && aligned16(x) && aligned16(w);
+  if (p.bn.mean && !(x6_ok(p, vec, b16) && x6p_ok(p, d->KH, d->KW) && ws && aligned16(ws))) {   // only the patch kernel applies it
+    sg_set_error("sg_conv2d_fwd_stats_bn: the launch does not take the patch kernel after all (alignment / workspace)");
+    return SG_EUNSUPPORTED;
+  }
   const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);  // padded reads must stay inside this tensor
   const bool prepared = ws_bytes == SG_WS_PREPARED;
   const bool have_ws = ws && aligned16(ws) && (prepared || ws_bytes >= x6_ws_bytes(d->KH * d->KW, d->Cin, d->Cout));
@@ -2441,8 +2541,27 @@ size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
   return (a > b ? a : b) + 512;
 }
 
+static int conv2d_wgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
+                             void* dw, void* dbias, void* ws, size_t ws_bytes, const sg_bn_in* bn);
+
 int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
                     void* dw, void* dbias, void* ws, size_t ws_bytes) {
+  return conv2d_wgrad_impl(ctx, stream, dtype, d, x, dy, dw, dbias, ws, ws_bytes, nullptr);
+}
+
+int sg_conv2d_wgrad_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
+                       void* dw, void* dbias, void* ws, size_t ws_bytes, const sg_bn_in* bn) {
+  SG_CHECK_ARG(bn && bn->mean && bn->invstd && bn->gamma && bn->beta, "sg_conv2d_wgrad_bn: null BatchNormalization parameters");
+  SG_CHECK_ARG(ctx && d, "sg_conv2d_wgrad_bn: null argument");
+  if (check_desc(d, "sg_conv2d_wgrad_bn") || !bn_in_geom(ctx, dtype, d, nullptr)) {
+    sg_set_error("sg_conv2d_wgrad_bn: this launch takes neither the thin 1x1 nor the patch filter-gradient kernel");
+    return SG_EUNSUPPORTED;
+  }
+  return conv2d_wgrad_impl(ctx, stream, dtype, d, x, dy, dw, dbias, ws, ws_bytes, bn);
+}
+
+static int conv2d_wgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
+                             void* dw, void* dbias, void* ws, size_t ws_bytes, const sg_bn_in* bn) {
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_wgrad: null ctx");
   SG_CHECK_ARG(dt_ok(dtype), "sg_conv2d_wgrad: dtype %d", dtype);
   int rc = check_desc(d, "sg_conv2d_wgrad");
@@ -2476,7 +2595,7 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
   if (thin) {
     auto run = [&]() -> int {
       if (!b16) {
-#define CALL(CO) thin_wgrad_t<CO, float, float>(ctx->num_cus, d, (const float*)x, (const float*)dy, (float*)dw, (float*)ws, st)
+#define CALL(CO) thin_wgrad_t<CO, float, float>(ctx->num_cus, d, (const float*)x, (const float*)dy, (float*)dw, (float*)ws, st, bn_in_of(bn))
         THIN_SWITCH(d->Cout, CALL)
 #undef CALL
       } else if (head32) {
@@ -2509,6 +2628,8 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     p.P = dd.N * dd.Ho * dd.Wo;
     p.slabs_per_split = sps;
     p.up = up2 ? 1 : 0;
+    p.bn = bn_in_of(bn);
+    p.x_plane_bytes = p.dy_plane_bytes = 0;
     p.fd_ohow = make_fastdiv((uint32_t)(dd.Ho * dd.Wo));
     p.fd_ow = make_fastdiv((uint32_t)dd.Wo);
     p.fd_c = make_fastdiv((uint32_t)dd.Cin);
@@ -2537,8 +2658,8 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
     }
     if (pl.patch) {
       const bool al = aligned16(xs) && aligned16(dys) && p.x_bytes != 0 && p.dy_bytes != 0 && !head32;
-      if (up2 && !al) {
-        sg_set_error("sg_conv2d_wgrad: SG_X_UP2 needs 16-byte aligned operands below 2 GiB");
+      if ((up2 || p.bn.mean) && !al) {
+        sg_set_error("sg_conv2d_wgrad: SG_X_UP2 / a BatchNormalization on x need 16-byte aligned operands below 2 GiB (the patch kernel)");
         return SG_EUNSUPPORTED;
       }
       if (al) {
@@ -2553,6 +2674,10 @@ int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d,
       p.slabs_per_split = sps;
       S = (int)sg_cdiv(nslab, sps);
       parts = S;
+    }
+    if (p.bn.mean) {   // (the patch branch above returned; nothing below applies a BatchNormalization to x)
+      sg_set_error("sg_conv2d_wgrad_bn: the launch does not take the patch kernel after all");
+      return SG_EUNSUPPORTED;
     }
     if (pl.wide) {  // unaligned operands: the slab kernels, with the plan's share count
       const int nslab = (int)sg_cdiv((int64_t)p.P, BK);

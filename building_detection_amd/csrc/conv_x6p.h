@@ -264,6 +264,16 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
       const float* xi = p.x + (int64_t)img * p.H * p.W * p.x_ld;
       const int c4 = lane & (LPP - 1), pxl = lane / LPP;
       f32x4 v[SPW];
+      unsigned okm = 0;   // bit k: slot k of this lane lies inside the image (the BatchNormalization below leaves the padding zero)
+      // round 5: the BatchNormalization(+ReLU) in front of this layer applied while the patch is split (IgemmParams::bn; uniform)
+      const bool bn_on = p.bn.mean != nullptr;
+      f32x4 bm = {0.f, 0.f, 0.f, 0.f}, bi = bm, bg = bm, bb = bm;
+      if (bn_on) {
+        bm = *reinterpret_cast<const f32x4*>(p.bn.mean + c4 * 4);
+        bi = bn_in_inv(p.bn, c4 * 4);
+        bg = *reinterpret_cast<const f32x4*>(p.bn.gamma + c4 * 4);
+        bb = *reinterpret_cast<const f32x4*>(p.bn.beta + c4 * 4);
+      }
 #pragma unroll
       for (int k = 0; k < SPW; ++k) {
         const int slot = wave + 4 * k;  // uniform
@@ -271,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
         const int pc = ps * PPW + pxl, gy = y0 + pr, gx = x0 + pc;
         const bool ok = (NSLOT % 4 == 0 || slot < NSLOT) && pc < 18 && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
         v[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok) okm |= 1u << k;
         if (ok && !(p.ablate & 2)) v[k] = *reinterpret_cast<const f32x4*>(xi + ((int64_t)gy * p.W + gx) * p.x_ld + c4 * 4);
       }
       __syncthreads();  // the previous tile's LDS reads (K loop, K-class exchange, statistics) are done
@@ -285,6 +296,11 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
         const int pr = slot / NPASS, ps = slot - pr * NPASS;
         const int pc = ps * PPW + pxl;
         if ((NSLOT % 4 == 0 || slot < NSLOT) && pc < 18) {
+          if (bn_on) {
+            const bool in = (okm >> k) & 1u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][e] = in ? bn_in_one(v[k][e], bm[e], bi[e], bg[e], bb[e], p.bn.relu) : 0.f;
+          }
           unsigned h0, m0, l0, h1, m1, l1;
           split3_pair(v[k][0], v[k][1], h0, m0, l0);
           split3_pair(v[k][2], v[k][3], h1, m1, l1);

@@ -57,6 +57,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6wp_kernel(const WgradParams p,
 
   // ---- staging: chunk idx = t + 256 j of the patch -> (patch pixel, 16-byte chunk); its LDS place is tile-invariant
   u32x4_t rx[NXL], ry[NYL];
+  unsigned okm = 0;   // bit j: patch chunk j of the tile in flight lies inside the image (WgradParams::bn keeps the padding zero)
+  // round 5: the BatchNormalization(+ReLU) in front of the layer applied to x while the patch is split (fp32 storage; uniform).
+  // A thread's chunks t + 256 j all hold the same four channels (256 is a multiple of the chunks per pixel).
+  // (the four parameter vectors are re-read from L2 in every store_tile: kept in registers through the MFMA section they spill
+  // the 64 x 64 instantiation, which sits at the 256-register cap)
+  const bool bn_on = !A16 && p.bn.mean != nullptr;
   auto load_tile = [&](uint32_t tile) {
     const uint32_t bx = tile % (uint32_t)tiles_x, tq = tile / (uint32_t)tiles_x;
     const uint32_t by = tq % (uint32_t)tiles_y, img = tq / (uint32_t)tiles_y;
@@ -67,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6wp_kernel(const WgradParams p,
     // would otherwise be hoisted out of the tile loop and live - and spill - through the MFMA section
     int tl = t;
     asm volatile("" : "+v"(tl));
+    okm = 0;
 #pragma unroll
     for (int j = 0; j < NXL; ++j) {
       const int idx = tl + 256 * j;
@@ -74,6 +81,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6wp_kernel(const WgradParams p,
       const int pr = pp / L::PW, pc = pp - pr * L::PW;
       const int gy = y0 + pr, gx = x0 + pc;
       const bool ok = (NXC % 256 == 0 || idx < NXC) && (unsigned)gy < (unsigned)p.H && (unsigned)gx < (unsigned)p.W;
+      if (ok) okm |= 1u << j;
       const unsigned off = (unsigned)(((ibase_s + (gy >> up)) * Ws + (gx >> up)) * p.x_ld + c * CH) * (unsigned)EB;
       rx[j] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(ok ? off : OOB), 0, 0);
     }
@@ -112,10 +120,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_x6wp_kernel(const WgradParams p,
   auto store_tile = [&]() {
     int tl = t;
     asm volatile("" : "+v"(tl));
+    f32x4 bm = {0.f, 0.f, 0.f, 0.f}, bi = bm, bg = bm, bb = bm;
+    if (bn_on) {
+      const int cb = (tl % CPX) * 4;
+      bm = *reinterpret_cast<const f32x4*>(p.bn.mean + cb);
+      bi = bn_in_inv(p.bn, cb);
+      bg = *reinterpret_cast<const f32x4*>(p.bn.gamma + cb);
+      bb = *reinterpret_cast<const f32x4*>(p.bn.beta + cb);
+    }
 #pragma unroll
     for (int j = 0; j < NXL; ++j) {
       const int idx = tl + 256 * j;
-      if (NXC % 256 == 0 || idx < NXC) store_chunk(rx[j], smem, L::XPLANE, idx / CPX, idx % CPX, L::XP);
+      if (NXC % 256 == 0 || idx < NXC) {
+        u32x4_t v = rx[j];
+        if (bn_on) {
+          f32x4 f = __builtin_bit_cast(f32x4, v);
+          const bool in = (okm >> j) & 1u;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) f[e] = in ? bn_in_one(f[e], bm[e], bi[e], bg[e], bb[e], p.bn.relu) : 0.f;
+          v = __builtin_bit_cast(u32x4_t, f);
+        }
+        store_chunk(v, smem, L::XPLANE, idx / CPX, idx % CPX, L::XP);
+      }
     }
 #pragma unroll
     for (int j = 0; j < NYL; ++j) {

@@ -79,6 +79,21 @@ class _ConvNode(Node):
     # the up-sampling node hands its SOURCE through, this node's kernels read / write it directly (csrc/conv_x6p.h:
     # sub-pixel forward, dgrad with the 2 x 2 sum in its epilogue, filter gradient gathering h >> 1, w >> 1)
     up_src = None
+    # BatchNormalization(+ReLU) -> this convolution, the normalisation applied in this layer's loaders (Model._fuse sets bn_src /
+    # _BNNode.defer_conv; the BatchNormalization node then hands its RAW input through - saved state "deferred")
+    bn_src = None
+
+    def _bn_in(self, rt, training):
+        """(gamma, beta, mean, invstd | moving variance, relu, infer, eps) when this call's input is the raw input of bn_src"""
+        src = self.bn_src
+        if src is None:
+            return None
+        sv = rt._saved.get(id(src))
+        if sv is None or not sv.get("deferred"):
+            return None
+        if training:
+            return (rt.param(src.gamma), rt.param(src.beta), sv["mean"], sv["invstd"], src.relu, False, src.epsilon)
+        return (rt.param(src.gamma), rt.param(src.beta), rt.param(src.mm), rt.param(src.mv), src.relu, True, src.epsilon)
 
     def _up2(self, rt):
         return self.up_src is not None and rt.up2_on(self.up_src)
@@ -114,17 +129,20 @@ class _ConvNode(Node):
             # gradient): the activation is split ONCE per step - for every consumer of the tensor (the ASPP input feeds five
             # convolutions) and kept for this layer's filter gradient - instead of once per launch
             xp = rt.act_planes(self, x, d) if (training and not up2) else None
+            bn_in = self._bn_in(rt, training)
+            if training:
+                rt.save(self, bn_in=bn_in)
             if training and getattr(self, "emit_bn_stats", False):
                 # the following BatchNormalization takes its statistics from this conv's epilogue
                 y, st = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=d, want_stats=True,
-                                          planes=None if up2 else rt.planes(self, "f"), up2=up2, x_planes=xp)
+                                          planes=None if up2 else rt.planes(self, "f"), up2=up2, x_planes=xp, bn_in=bn_in)
                 if st is not None:
                     rt.bn_stats[id(y)] = st
                 return y
             # the softmax head stays fp32 under bf16 storage (logits, probabilities, loss: SG_HEAD_F32)
             y = rt.eng.conv2d_fwd(x, rt.param(self.w), b, desc=d, relu=self.activation == "relu",
                                   head_f32=self.activation == "softmax", planes=None if up2 else rt.planes(self, "f"), up2=up2,
-                                  x_planes=xp)
+                                  x_planes=xp, bn_in=bn_in)
         if self.activation == "sigmoid":
             y = rt.eng.act_fwd(y, _lib.SG_ACT_SIGMOID, out=y)
         elif self.activation == "softmax":
@@ -173,7 +191,11 @@ class _ConvNode(Node):
                 dx = e.conv2d_dgrad(dz, rt.param(self.w), d, out_dtype=x.dtype, planes=rt.planes(self, "d"), res=res, down2=up2,
                                     dy_planes=dzp if res is None else None)
             gw, gb = rt.grad(self.w), (rt.grad(self.b) if want_b else None)
-            if wg_planes:
+            bn_in = rt.saved(self).get("bn_in") if id(self) in rt._saved else None
+            if bn_in is not None:   # x is the raw input of the BatchNormalization in front: the filter gradient normalises it as the forward did
+                e.side_run(self._tag, (x, dz) + tuple(bn_in[:4]),
+                           lambda: e.conv2d_wgrad(x, dz, d, want_bias=want_b, dw=gw, db=gb, bn_in=bn_in))
+            elif wg_planes:
                 def wgrad_from_planes():
                     e.conv2d_wgrad_planes(xp, dzp, d, dw=gw)
                     if want_b:
@@ -432,6 +454,7 @@ class _BNNode(Node):
         self.defer_to = None  # fused by the optimisation pass: the SeparableConv2D that applies this layer in its gather
         self.defer_add = None  # fused by the optimisation pass: the two-operand Add that applies this layer while it sums
         self.sums_from = None  # fused by the optimisation pass: the SeparableConv2D whose depthwise dgrad sums this layer's dgamma / dbeta
+        self.defer_conv = None  # fused by the optimisation pass: the Conv2D whose loaders apply this layer (thin 1x1 / patch kernels)
 
     def build(self, x):
         c = x.shape[-1]
@@ -447,7 +470,7 @@ class _BNNode(Node):
         if training:
             st = rt.bn_stats.pop(id(x), None)
             if st is not None:  # statistics already produced by the conv that wrote x
-                defer = self.defer_to is not None or self.defer_add is not None
+                defer = self.defer_to is not None or self.defer_add is not None or (self.defer_conv is not None and rt.bn_conv_on(self))
                 y, mean, invstd = e.bn_train_fwd_from_tiles(x, st[0], st[1], rt.param(self.gamma), rt.param(self.beta),
                                                             rt.param(self.mm), rt.param(self.mv), relu=self.relu,
                                                             momentum=self.momentum, eps=self.epsilon, apply=not defer)
@@ -460,6 +483,9 @@ class _BNNode(Node):
             rt.save(self, mean=mean, invstd=invstd, deferred=False)
             return y
         if self.defer_add is not None and x.shape[-1] % 4 == 0:   # inference: the Add applies the moving statistics
+            rt.save(self, deferred=True)
+            return x
+        if self.defer_conv is not None and rt.bn_conv_on(self):   # inference: the consuming convolution's loader applies them
             rt.save(self, deferred=True)
             return x
         rt.save(self, deferred=False)

@@ -353,20 +353,35 @@ class Engine:
         ho, wo, pt, pl = conv_out_geometry(h, w, kh, kw, stride, dilation, padding)
         return ConvDesc(n, h, w, cin, cout, kh, kw, stride, dilation, pt, pl, ho, wo, x_ld, y_ld)
 
+    def conv2d_bn_in_ok(self, d: ConvDesc, dtype=torch.float32) -> bool:
+        """Can the launches of convolution `d` apply a BatchNormalization(+ReLU) to their input themselves (sg_conv2d_fwd_stats_bn /
+        sg_conv2d_wgrad_bn: the thin 1x1 and the patch kernels, fp32 storage)?"""
+        return dtype == torch.float32 and bool(self.lib.sg_conv2d_bn_in_supported(self.h, SG_F32, C.byref(d)))
+
+    @staticmethod
+    def _bn_in(bn):
+        """bn = (gamma, beta, mean, invstd-or-moving-variance, relu, infer, eps) -> the sg_bn_in struct (tensors kept by the caller)"""
+        gamma, beta, mean, inv, relu, infer, eps = bn
+        for t in (gamma, beta, mean, inv):
+            _chk32(t, "bn_in")
+        return _lib.BnIn(mean.data_ptr(), inv.data_ptr(), gamma.data_ptr(), beta.data_ptr(), int(bool(relu)), int(bool(infer)), float(eps))
+
     def conv2d_up2_ok(self, d: ConvDesc, dtype=torch.float32) -> bool:
         """Does the convolution `d` (on the up-sampled grid) take the fused UpSampling2D(2) -> Conv2D 3x3 kernels
         (SG_PRO_UP2 / SG_EPI_DOWN2 / SG_X_UP2, csrc/conv_x6p.h)?"""
         return dtype == torch.float32 and bool(self.lib.sg_conv2d_up2_supported(SG_F32, C.byref(d)))
 
     def conv2d_fwd(self, x, w, b=None, stride=1, dilation=1, padding="same", relu=False, out=None, desc=None,
-                   want_stats=False, head_f32=False, planes=None, up2=False, x_planes=None):
+                   want_stats=False, head_f32=False, planes=None, up2=False, x_planes=None, bn_in=None):
         """want_stats: also return the BatchNormalization statistics of y as (stats tensor [tiles,2,Cout], tiles), or
         None when this launch could not produce them (then BN computes its own).
         head_f32 (bf16 storage only): the output is fp32 - the softmax head, a thin 1x1 convolution (SG_HEAD_F32).
         up2: x is the SOURCE [N, H/2, W/2, Cin] of a nearest 2x up-sampling and `desc` (required) names the convolution on
         the up-sampled grid (SG_PRO_UP2: the sub-pixel kernel; the up-sampled tensor is never built).
         x_planes: split_planes(x), when the caller has them (sg_conv2d_fwd_stats_ap: the planes-in kernel then skips its own
-        split; any other kernel ignores them)."""
+        split; any other kernel ignores them).
+        bn_in: (gamma, beta, mean, invstd | moving variance, relu, infer, eps) - x is the RAW input of that BatchNormalization(+ReLU)
+        and the kernel applies it while loading (sg_conv2d_fwd_stats_bn; conv2d_bn_in_ok tells which launches can)."""
         _chk(x, "x"); _chk32(w, "w")
         kh, kw, cin, cout = w.shape
         d = desc or self.conv_desc(x.shape, cout, kh, kw, stride, dilation, padding)
@@ -382,6 +397,18 @@ class Engine:
             wsp, wsn = C.c_void_p(planes), C.c_size_t(_lib.SG_WS_PREPARED)
         else:
             wsp, wsn = self.ws(self.lib.sg_conv2d_fwd_ws_bytes(C.byref(d)))
+        if bn_in is not None:
+            assert not up2 and x_planes is None
+            bq = self._bn_in(bn_in)
+            st = self.empty(self.lib.sg_conv2d_fwd_stats_bytes(C.byref(d)) // 4) if want_stats else None
+            tiles = C.c_int(0)
+            with self.timed(self._gemm_tag()):
+                check(self.lib.sg_conv2d_fwd_stats_bn(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(w), _ptr(b), _ptr(y), flags,
+                                                      wsp, wsn, _ptr(st), C.byref(tiles) if want_stats else None, C.byref(bq)),
+                      "sg_conv2d_fwd_stats_bn")
+            if want_stats:
+                return y, ((st, tiles.value) if tiles.value > 0 else None)
+            return y
         if want_stats:
             st = self.empty(self.lib.sg_conv2d_fwd_stats_bytes(C.byref(d)) // 4)
             tiles = C.c_int(0)
@@ -436,7 +463,7 @@ class Engine:
                                                flags, wsp, wsn), "sg_conv2d_dgrad")
         return dx
 
-    def conv2d_wgrad(self, x, dy, d: ConvDesc, want_bias=True, dw=None, db=None, x_up2=False):
+    def conv2d_wgrad(self, x, dy, d: ConvDesc, want_bias=True, dw=None, db=None, x_up2=False, bn_in=None):
         """x_up2: x is the SOURCE [N, H/2, W/2, Cin] of the nearest 2x up-sampling the conv `d` read (SG_X_UP2: the patch
         kernel gathers x[n, h >> 1, w >> 1]; the bits of the filter gradient on the materialised tensor)."""
         _chk(x, "x"); _chk(dy, "dy")
@@ -451,8 +478,13 @@ class Engine:
         need = self.lib.sg_conv2d_wgrad_ws_bytes(self.h, C.byref(d))
         wsp, wsn = self.ws(need)
         with self.timed(self._gemm_tag()):
-            check(self.lib.sg_conv2d_wgrad(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
-                                           _ptr(db) if want_bias else None, wsp, wsn), "sg_conv2d_wgrad")
+            if bn_in is not None:   # x is the raw input of the BatchNormalization(+ReLU) in front of the layer (see conv2d_fwd)
+                bq = self._bn_in(bn_in)
+                check(self.lib.sg_conv2d_wgrad_bn(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+                                                  _ptr(db) if want_bias else None, wsp, wsn, C.byref(bq)), "sg_conv2d_wgrad_bn")
+            else:
+                check(self.lib.sg_conv2d_wgrad(self.h, self.stream, dt, C.byref(d), _ptr(x), _ptr(dy), _ptr(dw),
+                                               _ptr(db) if want_bias else None, wsp, wsn), "sg_conv2d_wgrad")
         return dw, (db if want_bias else None)
 
     def split_planes(self, x, out=None):

