@@ -409,29 +409,35 @@ def main():
         # --pmc runs of scripts/dilated_bench.py at this very configuration; scripts/pmc_traffic.py)
         traffic, traffic_note = None, "PMC passes exist for the 512x512 bs16 fp32 configuration only"
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        tj = next((os.path.join(pdir, n) for n in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n))), None)
+        tj = next((os.path.join(pdir, n) for n in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json") if os.path.exists(os.path.join(pdir, n))), None)
         if args.batch == 16 and args.size == 512 and tj and not b16:
             with open(tj) as f:
                 tr = json.load(f)
             traffic = int(tr["set_bytes_per_step"])
             traffic_note = ("NOT measured in this run: a committed constant from the separate rocprofv3 --pmc passes of %s "
                             "(FETCH_SIZE pass x2 for gfx950's 64-B tally + WRITE_SIZE pass, L2-miss side, Infinity-Cache hits "
-                            "included) over the same kernel set at this configuration; algorithmic bytes of the set = %d"
-                            % (os.path.basename(tj), int(tr["algorithmic_bytes_per_step"])))
+                            "included) over the same kernel set at this configuration, launched as the step launches it (round 5: "
+                            "scripts/dilated_step.py - activation planes made once per tensor, planes-in filter gradients); "
+                            "algorithmic bytes of the set = %d (x %.2f)"
+                            % (os.path.basename(tj), int(tr["algorithmic_bytes_per_step"]), traffic / tr["algorithmic_bytes_per_step"]))
         # Executed share of the nominal FLOPs: the kernels skip whole padding taps (exact: the skipped products are x0), so
         # the matrix pipe executes fewer bf16 MFMA operations than 6 x nominal.  Counted by SQ_INSTS_VALU_MFMA_MOPS_BF16
         # (x512 FLOP) in a separate rocprofv3 --pmc pass over this kernel set (scripts/pmc_mfma.py); it depends on the
         # shapes only, not on the run.
         exec_ratio, exec_note = None, "no PMC pass for this configuration"
         pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        pj = next((q for q in (os.path.join(pdir, n) for n in ("r04_pmc_mfma.json", "r03_pmc_mfma.json", "r01_pmc_mfma.json")) if os.path.exists(q)),
+        pj = next((q for q in (os.path.join(pdir, n) for n in ("r05_pmc_mfma.json", "r04_pmc_mfma.json", "r03_pmc_mfma.json", "r01_pmc_mfma.json")) if os.path.exists(q)),
                   os.path.join(pdir, "r01_pmc_mfma.json"))
         if args.batch == 16 and args.size == 512 and x6 and os.path.exists(pj):
             with open(pj) as f:
-                k = json.load(f)["kernels"]
-            # the profiled script launches every forward 3x, dgrad / wgrad 2x (warm-up + ITERS=1): 30 and 12 launches
-            executed = (k["x6_fwd_dgrad"]["bf16_mfma_flops"] * 12 / k["x6_fwd_dgrad"]["launches"]
-                        + k["x6_wgrad"]["bf16_mfma_flops"] * 6 / k["x6_wgrad"]["launches"]) / 6.0  # fp32-equivalent
+                rec = json.load(f)
+            if "bf16_mfma_flops_per_step" in rec:   # round 5: scripts/pmc_set.py over scripts/dilated_step.py, already per step
+                executed = rec["bf16_mfma_flops_per_step"] / 6.0  # fp32-equivalent
+            else:
+                k = rec["kernels"]
+                # the profiled script launches every forward 3x, dgrad / wgrad 2x (warm-up + ITERS=1): 30 and 12 launches
+                executed = (k["x6_fwd_dgrad"]["bf16_mfma_flops"] * 12 / k["x6_fwd_dgrad"]["launches"]
+                            + k["x6_wgrad"]["bf16_mfma_flops"] * 6 / k["x6_wgrad"]["launches"]) / 6.0  # fp32-equivalent
             exec_ratio = executed / (dil_tflop * 1e12)
             exec_note = ("NOT measured in this run: a committed constant from a separate counter pass (SQ_INSTS_VALU_MFMA_MOPS_BF16 x "
                          "512, profiles/%s; it depends on the layer shapes only - rounds 1, 3 and 4 count the same operations) "
@@ -466,7 +472,8 @@ def main():
                          "frac_executed_note": exec_note,
                          "traffic": traffic, "traffic_note": traffic_note,
                          "kernel": (("conv_b16w_kernel / conv_b16_kernel / wgrad_x6_kernel<NPL=1,bf16>" if b16
-                                     else "conv_x6w_kernel (ASPP forward + dgrad, activation planes by x6w_split_kernel) / conv_x6_kernel / wgrad_x6_kernel") if x6
+                                     else "conv_x6w_kernel (ASPP forward + dgrad, activation planes once per tensor: x6w_split_kernel) / conv_x6_kernel (SK) / "
+                                          "wgrad_x6_kernel<.., PIN> (ASPP filter gradients from the planes) / wgrad_x6_kernel (SK)") if x6
                                     else "igemm_conv_kernel / igemm_wgrad_kernel") + " on the 6 dilated 3x3 convs (fwd+dgrad+wgrad)",
                          "ms_per_step": round(dil_ms, 3), "launches_per_step": prof.get("dilated_conv_launches", 0) // max(args.steps, 1)},
         }

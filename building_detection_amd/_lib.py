@@ -88,6 +88,7 @@ _SIGNATURES = {
     "sg_conv2d_fwd_stats_ap": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, C.POINTER(C.c_int), _vp]),
     "sg_conv2d_dgrad_ap": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp]),
     "sg_conv2d_wgrad_planes_supported": (_i, [_vp, _dp]),
+    "sg_conv2d_wgrad_planes_ws_bytes": (_sz, [_vp, _dp]),
     "sg_conv2d_wgrad_planes": (_i, [_vp, _vp, _dp, _vp, _vp, _vp, _vp, _sz]),
     "sg_bias_grad_ws_bytes": (_sz, [_vp, _i64, _i]),
     "sg_bias_grad": (_i, [_vp, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz]),

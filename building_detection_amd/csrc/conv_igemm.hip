@@ -2768,10 +2768,27 @@ static bool wgrad_planes_geom(const sg_ctx* ctx, const sg_conv_desc* d, WgradPla
   const int64_t xp = (int64_t)d->N * d->H * d->W * d->Cin * 2, yp = (int64_t)d->N * d->Ho * d->Wo * d->Cout * 2;
   const int64_t sh = ((int64_t)d->pad_t * d->W + d->pad_l + 64) * d->Cin * 4;
   if (3 * xp + 2 * sh >= (1ll << 31) || 3 * yp >= (1ll << 31)) return false;
-  const WgradPlan pl = plan_wgrad(ctx->num_cus, d, false);
+  WgradPlan pl = plan_wgrad(ctx->num_cus, d, false);
   if (pl.wide || pl.patch || pl.chunks > 1 || thin_ok(d)) return false;
+  // SG_WGRAD_PIN_SMUL: more, shorter pixel shares than the fp32-operand plan (the planes are 1.5 x the bytes per pixel: the share
+  // of x that the workgroups of an XCD walk together should still fit its L2)
+  static const int smul = getenv("SG_WGRAD_PIN_SMUL") ? atoi(getenv("SG_WGRAD_PIN_SMUL")) : 1;
+  if (smul > 1 && pl.S > 1) {
+    const int64_t nslab = sg_cdiv((int64_t)d->N * d->Ho * d->Wo, BK);
+    int64_t S = (int64_t)pl.S * smul;
+    if (S > nslab / 4) S = nslab / 4 > 0 ? nslab / 4 : 1;
+    pl.slabs_per_split = (int)sg_cdiv(nslab, S);
+    pl.S = (int)sg_cdiv(nslab, pl.slabs_per_split);
+    pl.dw_part_bytes = (size_t)pl.S * d->KH * d->KW * d->Cin * d->Cout * 4;
+  }
   if (out) *out = pl;
   return true;
+}
+
+size_t sg_conv2d_wgrad_planes_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d) {
+  WgradPlan pl;
+  if (!ctx || !d || check_desc(d, "sg_conv2d_wgrad_planes_ws_bytes") || !wgrad_planes_geom(ctx, d, &pl)) return 0;
+  return pl.dw_part_bytes + 512;
 }
 
 int sg_conv2d_wgrad_planes_supported(const sg_ctx* ctx, const sg_conv_desc* d) {
@@ -2825,7 +2842,7 @@ int sg_conv2d_wgrad_planes(sg_ctx* ctx, void* stream, const sg_conv_desc* d, con
     p.tap_inner = ((conv_l2(true) & 4) && p.KH_KW > 1 && p.Cin % BM == 0) ? 1 : 0;   // as dispatch_wgrad: the same tile order
   }
   {
-    static const int abl = getenv("SG_X6_ABLATE") ? atoi(getenv("SG_X6_ABLATE")) & 7 : 0;   // timing-only diagnostics of the PF = 1 form
+    static const int abl = getenv("SG_X6_ABLATE") ? atoi(getenv("SG_X6_ABLATE")) & 15 : 0;   // timing-only diagnostics of the PF = 1 form
     p.stagger = abl;
   }
   const int bn = wgrad_bn(p.Cout);

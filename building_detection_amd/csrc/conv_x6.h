@@ -1080,13 +1080,26 @@ __global__ __launch_bounds__(64 * WGM * WGN, PF == 2 ? (WGM * WGN + 3) / 4 : WGM
           d[j][pl] = tr_frag(b, b + 4 * PB);
         }
     };
-    rd_b(0, bfr[0]);
-    rd_a(0, 0, afr[0]);
+    const bool rd = !(PF == 1 && (p.stagger & 8));   // SG_X6_ABLATE bit 8 (timing only): no fragment reads, MFMAs on whatever the registers hold
+    if (rd) {
+      rd_b(0, bfr[0]);
+      rd_a(0, 0, afr[0]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+#pragma unroll
+        for (int pl = 0; pl < NPL; ++pl) {
+          asm volatile("" : "=v"(afr[u][pl]));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) asm volatile("" : "=v"(bfr[u][j][pl]));
+        }
+      }
+    }
     constexpr int NQ = 2 * TM;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int ks = q / TM, i = q % TM;
-      if (q + 1 < NQ) {
+      if (q + 1 < NQ && rd) {
         const int ks1 = (q + 1) / TM, i1 = (q + 1) % TM;
         rd_a(ks1, i1, afr[(q + 1) & 1]);
         if (ks1 != ks) rd_b(ks1, bfr[ks1 & 1]);

@@ -504,7 +504,7 @@ class Engine:
         conv2d_wgrad on the fp32 tensors, without the per-launch VALU split."""
         if dw is None:
             dw = self.empty(d.KH, d.KW, d.Cin, d.Cout)
-        wsp, wsn = self.ws(self.lib.sg_conv2d_wgrad_ws_bytes(self.h, C.byref(d)))
+        wsp, wsn = self.ws(self.lib.sg_conv2d_wgrad_planes_ws_bytes(self.h, C.byref(d)))
         with self.timed(self._gemm_tag()):
             check(self.lib.sg_conv2d_wgrad_planes(self.h, self.stream, C.byref(d), _ptr(x_planes), _ptr(dy_planes), _ptr(dw), wsp, wsn),
                   "sg_conv2d_wgrad_planes")

@@ -194,7 +194,7 @@ int sg_conv2d_wgrad_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc*
  *                            (a1 + a2 + a3 = x; the layout the planes-in forward kernel conv_x6w.h reads).
  *   sg_conv2d_wgrad_planes   dw[KH,KW,Cin,Cout] of the convolution `d` from x_planes[3][N*H*W][Cin] and dy_planes[3][N*Ho*Wo][Cout];
  *                            same products in the same order as sg_conv2d_wgrad on the fp32 tensors (bit-identical), no bias
- *                            gradient (sg_bias_grad).  ws: sg_conv2d_wgrad_ws_bytes(ctx, d).  Stride 1, SAME, Wo % 32 = 0,
+ *                            gradient (sg_bias_grad).  ws: sg_conv2d_wgrad_planes_ws_bytes(ctx, d).  Stride 1, SAME, Wo % 32 = 0,
  *                            channels % 8 = 0, not a layer of the wide-pointwise / patch families; _supported() tells.
  * Replaces the filter gradient of the ASPP / SK / decoder 3x3 convolutions (train_model/DeepLabv3plus.py:219-229, 431-443). */
 int sg_split_planes(sg_ctx* ctx, void* stream, const void* x, int64_t rows, int C, int ld, void* planes);
@@ -210,6 +210,7 @@ int sg_conv2d_fwd_stats_ap(sg_ctx* ctx, void* stream, int dtype, const sg_conv_d
 int sg_conv2d_dgrad_ap(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
                        const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* dy_planes);
 int sg_conv2d_wgrad_planes_supported(const sg_ctx* ctx, const sg_conv_desc* d);
+size_t sg_conv2d_wgrad_planes_ws_bytes(const sg_ctx* ctx, const sg_conv_desc* d);
 int sg_conv2d_wgrad_planes(sg_ctx* ctx, void* stream, const sg_conv_desc* d, const void* x_planes, const void* dy_planes, void* dw,
                            void* ws, size_t ws_bytes);
 

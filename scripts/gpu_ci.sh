@@ -1,7 +1,7 @@
 #!/bin/bash
 # One GPU-box session: parity tests, smoke, bench, rocprof summary.  Every stage runs under its own timeout; a
 # stage that times out or is killed aborts the session (no further GPU step after a hang).
-#   usage: scripts/gpu_ci.sh <tag> [stages...]      stages: tests smoke bench prof dp1 pmc pmc2 pmc3 full infer census nodes bw
+#   usage: scripts/gpu_ci.sh <tag> [stages...]      stages: tests smoke bench prof dp1 pmc pmc2 pmc3 pmc5 full infer census nodes bw
 set -u
 TAG=${1:-run}; shift || true
 STAGES=${*:-"tests smoke bench prof"}
@@ -48,6 +48,14 @@ for s in $STAGES; do
            export ITERS=1
            run_stage pmc_mfma 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- python3 scripts/patch_bench.py
            run_stage pmc_lds 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d "$OUT/pmc_lds" -- python3 scripts/patch_bench.py
+           unset ITERS ;;
+    pmc5)  # round 5: the roofline set as the step runs it (shared activation planes, planes-in filter gradients): four separate passes
+           export ITERS=1
+           run_stage pmc_fetch 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 scripts/dilated_step.py
+           run_stage pmc_write 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 scripts/dilated_step.py
+           run_stage pmc_mfma 600 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_mfma" -- python3 scripts/dilated_step.py
+           run_stage pmc_lds 600 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU_MFMA_MOPS_BF16 --output-format csv -d "$OUT/pmc_lds" -- python3 scripts/dilated_step.py
+           find "$OUT" -name '*kernel_trace*.csv' -size +20M -delete 2>/dev/null
            unset ITERS ;;
     full)  run_stage full 900 python -m pytest tests/test_fullsize_gpu.py -m gpu -q -s -p no:cacheprovider ;;
     infer) run_stage infer 600 python scripts/bench_infer.py ;;
