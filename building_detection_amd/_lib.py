@@ -51,6 +51,13 @@ class BnIn(C.Structure):
                 ("relu", C.c_int32), ("infer", C.c_int32), ("eps", C.c_float)]
 
 
+class BnBwdIn(C.Structure):
+    """Mirror of `sg_bn_bwd_in` (include/segengine.h): a BatchNormalization's backward apply evaluated inside a pointwise dgrad."""
+
+    _fields_ = [("x", C.c_void_p), ("mean", C.c_void_p), ("invstd", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p), ("dz", C.c_void_p), ("relu", C.c_int32), ("rows", C.c_int64)]
+
+
 _vp, _i, _i64, _f, _sz = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
 _dp = C.POINTER(ConvDesc)
 _pp = C.POINTER(C.c_void_p)
@@ -83,6 +90,8 @@ _SIGNATURES = {
     "sg_conv2d_bn_in_supported": (_i, [_vp, _i, _dp]),
     "sg_conv2d_fwd_stats_bn": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, C.POINTER(C.c_int), C.POINTER(BnIn)]),
     "sg_conv2d_wgrad_bn": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _vp, _sz, C.POINTER(BnIn)]),
+    "sg_conv2d_dgrad_bnb_supported": (_i, [_vp, _i, _dp]),
+    "sg_conv2d_dgrad_bnb": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _sz, C.POINTER(BnBwdIn)]),
     "sg_split_planes": (_i, [_vp, _vp, _vp, _i64, _i, _i, _vp]),
     "sg_conv2d_planes_in": (_i, [_dp, _i]),
     "sg_conv2d_fwd_stats_ap": (_i, [_vp, _vp, _i, _dp, _vp, _vp, _vp, _vp, _i, _vp, _sz, _vp, C.POINTER(C.c_int), _vp]),

@@ -62,6 +62,20 @@ __device__ __forceinline__ float bn_in_one(float x, float m, float is, float g, 
   return relu ? fmaxf(t, 0.f) : t;
 }
 
+// pw_wide_kernel<3, float, BN, true> (conv_pw.h): the BatchNormalization backward apply evaluated in the dgrad's A path
+struct BnBwdIn {
+  const float* x;        // the BatchNormalization's raw input (= the pointwise convolution's forward output), same layout as dy
+  const float* mean;
+  const float* invstd;
+  const float* gamma;
+  const float* beta;     // null: no fused ReLU
+  const float* dgamma;   // finished column sums
+  const float* dbeta;
+  float* dz;             // out: the applied gradient (for the filter gradient)
+  int relu;
+  float inv_n;
+};
+
 struct IgemmParams {
   const float* __restrict__ x;
   const float* __restrict__ w;
@@ -101,6 +115,7 @@ struct IgemmParams {
   // planes-in kernel (conv_x6w.h) reads them instead of splitting x itself; ignored by every other kernel; null: none
   const unsigned short* a_planes;
   BnIn bn;   // conv_x6p_kernel only: the BatchNormalization applied in the patch loader (mean == nullptr: none)
+  BnBwdIn bnb;   // pw_wide_kernel<.., BNB> only (x == nullptr: none)
   // host side only: bytes of workspace that start at the weight planes (the planes, then scratch of a split-K launch:
   // conv_b16w.h); SIZE_MAX = prepared planes, whose arena slot sg_conv2d_planes_job sized for both
   size_t ws_room;
@@ -1273,10 +1288,21 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
         SG_LAUNCH_CHECK("split3_weights_kernel");
       }
       if constexpr (NPL == 3) {
+        if (p.bnb.x) {   // the BatchNormalization backward in the A path (sg_conv2d_dgrad_bnb)
+          if (wbn == 512) {
+            sg_set_error("pw_wide: no BatchNormalization-backward form of the 512-wide tile");
+            return SG_EUNSUPPORTED;
+          }
+          return wbn == 256 ? launch_pw_wide<NPL, TA, 256, true>(p, st) : launch_pw_wide<NPL, TA, 384, true>(p, st);
+        }
         if (wbn == 512) return launch_pw_wide<NPL, TA, 512>(p, st);
       }
       return wbn == 256 ? launch_pw_wide<NPL, TA, 256>(p, st) : launch_pw_wide<NPL, TA, 384>(p, st);
     }
+  }
+  if (p.bnb.x) {   // only the wide pointwise kernel above evaluates the BatchNormalization backward in its A path
+    sg_set_error("sg_conv2d_dgrad_bnb: this launch does not take the wide pointwise kernel");
+    return SG_EUNSUPPORTED;
   }
   const int Ck = p.C;
   int Ckp = Ck;
@@ -1857,6 +1883,7 @@ void fill_fwd_params(IgemmParams& p, const sg_conv_desc* d, const void* x, const
   p.res = nullptr;
   p.a_planes = nullptr;
   p.bn.mean = nullptr;
+  p.bnb.x = nullptr;
   p.ws_room = 0;
 }
 
@@ -1885,6 +1912,7 @@ void fill_dgrad_params(IgemmParams& p, const sg_conv_desc* d, const void* dy, co
   p.res = nullptr;
   p.a_planes = nullptr;
   p.bn.mean = nullptr;
+  p.bnb.x = nullptr;
   p.ws_room = 0;
 }
 
@@ -2377,7 +2405,40 @@ size_t sg_conv2d_dgrad_ws_bytes(const sg_conv_desc* d) {
 
 static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
                             const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* res,
-                            const void* dy_planes = nullptr);
+                            const void* dy_planes = nullptr, const sg_bn_bwd_in* bnb = nullptr);
+
+// the input gradient of a pointwise convolution with the BatchNormalization backward apply in its A path (conv_pw.h, BNB form)
+static bool dgrad_bnb_geom(const sg_ctx* ctx, int dtype, const sg_conv_desc* d) {
+  if ((dtype & 0xff) != SG_F32 || (dtype & (SG_HEAD_F32 | SG_X_UP2)) || x6_mode() != 1) return false;
+  if (d->KH != 1 || d->KW != 1 || d->stride != 1 || (d->x_ld && d->x_ld != d->Cin) || (d->y_ld && d->y_ld != d->Cout)) return false;
+  if (images_per_2gib(d, 4) < d->N || d->Cout + 16 > PW_BNB_MAXK) return false;
+  static const int var = getenv("SG_PW_VAR") ? atoi(getenv("SG_PW_VAR")) : 1;
+  if (var != 1 || getenv("SG_PW_ABLATE")) return false;
+  static const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+  IgemmParams q;
+  fill_dgrad_params(q, d, dummy, dummy, nullptr, nullptr, 0, 4);
+  q.x = (const float*)(uintptr_t)16;
+  const int wbn = pw_wide_bn(q, 4);
+  return wbn == 384 || wbn == 256;
+}
+
+int sg_conv2d_dgrad_bnb_supported(const sg_ctx* ctx, int dtype, const sg_conv_desc* d) {
+  return (ctx && d && check_desc(d, "sg_conv2d_dgrad_bnb_supported") == 0 && dgrad_bnb_geom(ctx, dtype, d)) ? 1 : 0;
+}
+
+int sg_conv2d_dgrad_bnb(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w, void* dx,
+                        void* ws, size_t ws_bytes, const sg_bn_bwd_in* bnb) {
+  SG_CHECK_ARG(ctx && d && bnb, "sg_conv2d_dgrad_bnb: null argument");
+  SG_CHECK_ARG(bnb->x && bnb->mean && bnb->invstd && bnb->gamma && bnb->dgamma && bnb->dbeta && bnb->dz && bnb->rows > 0,
+               "sg_conv2d_dgrad_bnb: null BatchNormalization operand");
+  SG_CHECK_ARG(!bnb->relu || bnb->beta, "sg_conv2d_dgrad_bnb: a fused ReLU needs beta (the mask is recomputed from x)");
+  if (check_desc(d, "sg_conv2d_dgrad_bnb") || !dgrad_bnb_geom(ctx, dtype, d) || !aligned16(bnb->x) || !aligned16(bnb->dz)) {
+    sg_set_error("sg_conv2d_dgrad_bnb: not a launch of the wide pointwise kernel (1x1, stride 1, dense fp32 operands, >= 6144 rows, "
+                 "x6 arithmetic, default schedule)");
+    return SG_EUNSUPPORTED;
+  }
+  return conv2d_dgrad_impl(ctx, stream, dtype, d, dy, w, nullptr, dx, 0, ws, ws_bytes, nullptr, nullptr, bnb);
+}
 
 int sg_conv2d_dgrad(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
                     const void* bias, void* dx, int flags, void* ws, size_t ws_bytes) {
@@ -2397,7 +2458,8 @@ int sg_conv2d_dgrad_acc(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc
 }
 
 static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w,
-                            const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* res, const void* dy_planes) {
+                            const void* bias, void* dx, int flags, void* ws, size_t ws_bytes, const void* res, const void* dy_planes,
+                            const sg_bn_bwd_in* bnb) {
   SG_CHECK_ARG(ctx != nullptr, "sg_conv2d_dgrad: null ctx");
   SG_CHECK_ARG(dt_ok(dtype), "sg_conv2d_dgrad: dtype %d", dtype);
   int rc = check_desc(d, "sg_conv2d_dgrad");
@@ -2493,6 +2555,16 @@ static int conv2d_dgrad_impl(sg_ctx* ctx, void* stream, int dtype, const sg_conv
   fill_dgrad_params(p, d, dy, wt, bias, dx, flags, eb);
   p.res = (const float*)res;
   if (!b16 && p.x_ld == d->Cout) p.a_planes = (const unsigned short*)dy_planes;
+  if (bnb) {
+    p.bnb.x = (const float*)bnb->x; p.bnb.mean = (const float*)bnb->mean; p.bnb.invstd = (const float*)bnb->invstd;
+    p.bnb.gamma = (const float*)bnb->gamma; p.bnb.beta = (const float*)bnb->beta; p.bnb.dgamma = (const float*)bnb->dgamma;
+    p.bnb.dbeta = (const float*)bnb->dbeta; p.bnb.dz = (float*)bnb->dz; p.bnb.relu = bnb->relu ? 1 : 0;
+    {
+      static const int abl = getenv("SG_BNB_ABLATE") ? atoi(getenv("SG_BNB_ABLATE")) : 0;   // timing only: 2 = no dz store, 4 = no x load
+      p.bnb.relu |= abl & 6;
+    }
+    p.bnb.inv_n = 1.0f / (float)bnb->rows;
+  }
   const int ch = b16 ? 8 : 4;
   const bool vec = (d->Cout % ch == 0) && (p.x_ld % ch == 0) && (d->Cin % 4 == 0) && aligned16(dy);
   const bool vpad_safe = (p.C % BK == 0) || (p.K == p.C) || (p.x_ld == p.C);

@@ -45,11 +45,21 @@ __device__ __forceinline__ void pw_lds_dma16(const __amdgpu_buffer_rsrc_t rsrc, 
 
 // BN: columns of the tile - 384 (8 waves of 64 x 96) or 256 (64 x 64: the 1024- and 2048-wide layers of the exit flow and the
 // 256-wide ones at many rows, whose last 384-wide tile would be two thirds / one third empty; round 4)
-template <int NPL, typename TA, int BN = 384>
+// BNB (round 5; fp32 x6 form, barrier in the middle of the k-step): the launch is the input gradient of a pointwise convolution
+// whose OUTPUT feeds a training-mode BatchNormalization, and the A operand is that layer's backward apply evaluated on the fly:
+//     a[m][c] = gamma invstd ((g - dbeta / n) - xhat dgamma / n),  xhat = (x - mean) invstd,  g = dy [where the fused ReLU passed]
+// from dy (the gradient of the BatchNormalization's output, p.x) and x (its raw input = this convolution's forward output,
+// p.bnb.x), with the finished column sums dgamma / dbeta.  The per-channel constants sit in a table in LDS behind the two stages
+// (seven float4 per four channels, built in the prologue); a thread's chunk is transformed in the MFMA gaps right before it is
+// split, and the workgroups of column tile 0 also store it (p.bnb.dz): the filter gradient reads the applied gradient from there.
+// The 47-microsecond bn_bwd_apply launch in front of every such dgrad (three passes over the tensor) is gone; its bytes ride in
+// a kernel that is bound by the matrix pipe.
+template <int NPL, typename TA, int BN = 384, bool BNB = false>
 __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
   static_assert((NPL == 3 && std::is_same<TA, float>::value) || (NPL == 1 && !std::is_same<TA, float>::value),
                 "x6 on fp32 storage, one plane on bf16 storage");
   static_assert(BN == 384 || BN == 256 || BN == 512, "tile width");
+  static_assert(!BNB || (NPL == 3 && BN != 512), "the BatchNormalization backward rides in the fp32 form with the barrier in the middle");
   using G = PwGeom<NPL, BN>;
   constexpr int KS = G::KS, BKW = G::BKW, RB = G::RB, CPR = G::CPR;
   constexpr int WGM = 2, WGN = 4, WM = 64, WN = BN / WGN, TM = 2, TN = WN / 32;
@@ -117,8 +127,49 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
   }
   const bool ktail = (p.K % BKW) != 0;
   u32x4_t ra = {0u, 0u, 0u, 0u};
+  u32x4_t rx = {0u, 0u, 0u, 0u};   // BNB: the BatchNormalization's raw input beside its output gradient (ra)
+  const __amdgpu_buffer_rsrc_t rsrc_x2 =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(BNB ? p.bnb.x : p.x), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_dz =
+      __builtin_amdgcn_make_buffer_rsrc(BNB ? p.bnb.dz : const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+  char* const tbl = smem + 2 * G::STAGE;   // BNB: [channel / 4][mean, invstd, gamma, beta, gamma invstd, dbeta / n, dgamma] x float4
   auto load_A = [&](int ks) {   // x6: registers
     ra = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff, ks * BKW * 4, 0);
+    if constexpr (BNB) rx = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x2, (int)((p.bnb.relu & 4) ? OOB : a_voff), ks * BKW * 4, 0);   // (bit 2: timing experiment, no x load)
+  };
+  // BNB: the constants of this thread's four channels of k-step ks -> registers; the transform of ra (in place); the store
+  f32x4 tq[7];
+  auto bnb_consts = [&](int ks) {
+    const f32x4* tp = reinterpret_cast<const f32x4*>(tbl + (ks * 4 + a_kq) * 112);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) tq[i] = tp[i];
+  };
+  auto bnb_apply = [&](int e0, int ne = 2) {   // elements e0 .. e0 + ne - 1 of the chunk
+    f32x4 g = __builtin_bit_cast(f32x4, ra);
+    const f32x4 xv = __builtin_bit_cast(f32x4, rx);
+#pragma unroll
+    for (int e = e0; e < e0 + ne; ++e) {
+      const float xh = (xv[e] - tq[0][e]) * tq[1][e];
+      float gg = g[e];
+      if (p.bnb.relu & 1) gg = fmaf(xh, tq[2][e], tq[3][e]) > 0.f ? gg : 0.f;   // bn_apply's own expression decides the mask
+      float o = tq[4][e] * ((gg - tq[5][e]) - (xh * tq[6][e]) * p.bnb.inv_n);
+      // the ROUNDED fp32 value is what the unfused pair multiplies: without this fence the compiler contracts this product into
+      // the split's residual (a - bf16(a) as an fma of the unrounded product), the planes then carry more bits than the stored
+      // dz and the input gradient differs from sg_bn_train_bwd_apply + sg_conv2d_dgrad in the last place (measured: 3e-7)
+      asm volatile("" : "+v"(o));
+      g[e] = o;
+    }
+    ra = __builtin_bit_cast(u32x4_t, g);
+  };
+  auto bnb_store = [&](int ks) {   // column tile 0 keeps the applied gradient for the filter gradient (others: out of range, dropped)
+    const bool keep = tile_n == 0 && (ks * BKW + 4 * a_kq) < p.K && !(p.bnb.relu & 2);   // (bit 1 of relu: timing experiment, no store)
+    __builtin_amdgcn_raw_buffer_store_b128(ra, rsrc_dz, (int)(keep ? a_voff : OOB), ks * BKW * 4, 0);
+  };
+  auto bnb_xform = [&](int ks) {
+    bnb_consts(ks);
+    bnb_apply(0);
+    bnb_apply(2);
+    bnb_store(ks);
   };
   auto store_A = [&](int stage) {
     const f32x4 f = __builtin_bit_cast(f32x4, ra);
@@ -307,6 +358,15 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
     // second half, in this order: the DMA pieces of B(s+2) (longest flight), the six prefetch reads of stage s+1 (the next k-step
     // opens with them), split + stores of A(s+2), the fp32 load of A(s+3)
     auto piece = [&](int w) {
+      if constexpr (BNB) {
+        // the constants of chunk A(s+2) are requested FIRST (their LDS round trip runs under the next MFMAs; right in front of
+        // their use the wave waited for it: +21 us per launch), the transform follows the prefetch reads one element per gap
+        if (w == 0) {
+          if (MODE >= 2) bnb_consts(s + 2);
+          return;
+        }
+        w -= 1;
+      }
       if (w < NBW) {
         if (MODE >= 2) {
           const int i = w, g = wave + 8 * i;
@@ -320,7 +380,12 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
       } else if (w < NBW + 6) {
         if (MODE >= 1) nb0[w - NBW - 3] = *reinterpret_cast<const bf16x8_t*>(sn + b_lane + (w - NBW - 3) * G::B_PLANE + ko);
       } else if (MODE >= 2) {
-        const int v = w - (NBW + 6);
+        int v = w - (NBW + 6);
+        if constexpr (BNB) {   // five more pieces in front of the split: the chunk A(s+2) becomes the BatchNormalization's dx
+          if (v < 4) { bnb_apply(v, 1); return; }
+          if (v == 4) { bnb_store(s + 2); return; }
+          v -= 5;
+        }
         if (v < 2) {
           const f32x4 f = __builtin_bit_cast(f32x4, ra);
           split3_pair(f[2 * v], f[2 * v + 1], hh[v], mm[v], ll[v]);
@@ -331,11 +396,11 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
         } else if (v == 4) {
           *reinterpret_cast<u32x2_t*>(adst + 2 * G::A_PLANE) = (u32x2_t){ll[0], ll[1]};
         } else if (v == 5) {
-          if (MODE == 3) ra = __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)a_voff, (s + 3) * BKW * 4, 0);
+          if (MODE == 3) load_A(s + 3);
         }
       }
     };
-    constexpr int NPIECE = NBW + 6 + 6, NGAP = 6 * TN;   // the pieces are spread over the half's MFMA gaps (two in some at BN = 256)
+    constexpr int NPIECE = NBW + 6 + 6 + (BNB ? 6 : 0), NGAP = 6 * TN;   // the pieces are spread over the half's MFMA gaps (two in some at BN = 256)
     static_assert(NPIECE <= 2 * NGAP && NREST <= NGAP, "pieces per MFMA gap");
     constexpr int PA_[6] = {2, 0, 1, 1, 0, 0}, PB_[6] = {0, 2, 1, 0, 1, 0};   // smallest terms first (conv_x6_kernel's order)
     int q = 0;
@@ -352,8 +417,11 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
     }
     if (MODE >= 1) {
       // B(s+1) is older than the fp32 load of A(s+2) in the queue: vmcnt(1) retires it and leaves that load in flight
-      if (MODE >= 2) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      // (BNB: behind B(s+1) the queue holds the store of dz(s+1) and TWO loads of A(s+2): vmcnt(3))
+      if (MODE >= 2) {
+        if constexpr (BNB) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
     }
@@ -382,9 +450,28 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
     if constexpr (NPL == 3) {
       load_A(0);
       issue_B(0, 0);
+      if constexpr (BNB) {
+        // the constants table: channel c -> slot (c / 4) * 28 + param * 4 + c % 4; channels past K (the ragged last k-step) get
+        // zeros, so that whatever the chunk holds there becomes 0 x (finite) = 0
+        float* tf = reinterpret_cast<float*>(tbl);
+        for (int c = t; c < nk * BKW; c += 512) {
+          float v7[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          if (c < p.K) {
+            const float iv = p.bnb.invstd[c], gm = p.bnb.gamma[c];
+            v7[0] = p.bnb.mean[c]; v7[1] = iv; v7[2] = gm; v7[3] = p.bnb.beta ? p.bnb.beta[c] : 0.f;
+            v7[4] = gm * iv; v7[5] = p.bnb.dbeta[c] * p.bnb.inv_n; v7[6] = p.bnb.dgamma[c];
+          }
+#pragma unroll
+          for (int i = 0; i < 7; ++i) tf[(c >> 2) * 28 + i * 4 + (c & 3)] = v7[i];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        bnb_xform(0);
+      }
       store_A(0);                    // (the compiler waits for ra here)
       if (nk > 1) load_A(1);
-      asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // B(0) has landed; A(1) may still fly
+      if constexpr (BNB) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // B(0), dz(0) done; the two loads of A(1) may fly
+      else asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");   // B(0) has landed; A(1) may still fly
       if (nk == 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       if (p.ablate == 0 && p.stagger == 1 && BN != 512) {   // the woven step with the barrier in the middle of the k-step (512-wide
@@ -393,6 +480,7 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
         // stage 1 is staged before the loop (the loop stages s + 2 during k-step s), A(2) goes into flight
         if (nk > 1) {
           issue_B(1, 1);
+          if constexpr (BNB) bnb_xform(1);
           store_A(1);                // (the compiler waits for ra = A(1) here)
           if (nk > 2) load_A(2);
         }
@@ -629,17 +717,20 @@ __global__ __launch_bounds__(512, 2) void pw_wide_kernel(const IgemmParams p) {
   }
 }
 
-template <int NPL, typename TA, int BN = 384>
+constexpr int PW_BNB_MAXK = 2048;   // channels the constants table of the BNB form is sized for (28 bytes each)
+
+template <int NPL, typename TA, int BN = 384, bool BNB = false>
 int launch_pw_wide(const IgemmParams& p, hipStream_t st) {
   using G = PwGeom<NPL, BN>;
-  constexpr size_t stage_lds = 2 * (size_t)G::STAGE;
+  constexpr size_t stage_lds = 2 * (size_t)G::STAGE + (BNB ? (size_t)PW_BNB_MAXK * 28 : 0);
   constexpr size_t tile_lds = NPL == 1 ? (size_t)PW_BM * (BN * 2 + 16) : 0;
   constexpr size_t stat_lds = (size_t)3 * BN * sizeof(float);
   constexpr size_t m1 = stage_lds > tile_lds ? stage_lds : tile_lds;
   constexpr size_t lds = m1 > stat_lds ? m1 : stat_lds;
+  static_assert(lds <= 160 * 1024, "LDS");
   static bool attr_done = false;
   if (!attr_done) {
-    int rc = set_dyn_lds(pw_wide_kernel<NPL, TA, BN>, lds);
+    int rc = set_dyn_lds(pw_wide_kernel<NPL, TA, BN, BNB>, lds);
     if (rc) return rc;
     attr_done = true;
   }
@@ -660,7 +751,14 @@ int launch_pw_wide(const IgemmParams& p, hipStream_t st) {
     static const int var = getenv("SG_PW_VAR") ? atoi(getenv("SG_PW_VAR")) : 1;
     q.stagger = var;   // (the field is free in this kernel) 1: barrier in the middle of the k-step, 0: at its end
   }
-  hipLaunchKernelGGL((pw_wide_kernel<NPL, TA, BN>), dim3((unsigned)tiles), dim3(512), lds, st, q);
+  if constexpr (BNB) {
+    if (q.ablate != 0 || q.stagger != 1 || p.K + 16 > PW_BNB_MAXK || p.x_ld != p.K) {
+      sg_set_error("pw_wide: the BatchNormalization-backward form needs the default schedule (SG_PW_VAR=1, no ablation), a dense "
+                   "operand and at most %d channels", PW_BNB_MAXK - 16);
+      return SG_EUNSUPPORTED;
+    }
+  }
+  hipLaunchKernelGGL((pw_wide_kernel<NPL, TA, BN, BNB>), dim3((unsigned)tiles), dim3(512), lds, st, q);
   SG_LAUNCH_CHECK("pw_wide_kernel");
   return 0;
 }

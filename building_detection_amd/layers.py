@@ -268,12 +268,20 @@ class _SepConvNode(Node):
         (x,) = xs
         e = rt.eng
         t = rt.saved(self)["t"]
-        dz = e.act_bwd(y, dy, _lib.SG_ACT_RELU) if self.activation == "relu" else dy
         dpw = e.conv_desc(tuple(t.shape), self.filters, 1, 1)
         want_b = not getattr(self, "bias_grad_zero", False)
-        dt = e.conv2d_dgrad(dz, rt.param(self.pw), dpw, planes=rt.planes(self, "d"))
+        keep = ()
+        if isinstance(dy, BnBackwardDeferred):
+            # the BatchNormalization behind this layer left its backward apply to this dgrad (y = its raw input): one launch gives
+            # the input gradient of the pointwise convolution AND the applied gradient dz the filter gradient reads
+            q = dy
+            dt, dz = e.conv2d_dgrad_bnb(q.dy, y, rt.param(self.pw), dpw, q.gamma, q.beta, q.mean, q.invstd, q.dgamma, q.dbeta, q.relu,
+                                        planes=rt.planes(self, "d"))
+        else:
+            dz = e.act_bwd(y, dy, _lib.SG_ACT_RELU) if self.activation == "relu" else dy
+            dt = e.conv2d_dgrad(dz, rt.param(self.pw), dpw, planes=rt.planes(self, "d"))
         gpw, gb = rt.grad(self.pw), (rt.grad(self.b) if want_b else None)
-        e.side_run(None, (t, dz), lambda: e.conv2d_wgrad(t, dz, dpw, want_b, dw=gpw, db=gb))
+        e.side_run(None, (t, dz) + keep, lambda: e.conv2d_wgrad(t, dz, dpw, want_b, dw=gpw, db=gb))
         ddw = e.conv_desc(tuple(x.shape), x.shape[-1], 3, 3, self.stride, 1, "same")
         dx = None
         if rt.needs_grad(self.inputs[0]):
@@ -444,6 +452,20 @@ class Dense(Layer):
 
 
 # ======================================================================================== normalisation
+class BnBackwardDeferred:
+    """What a BatchNormalization hands its producer instead of dx when that producer - a pointwise convolution on the wide
+    kernel - evaluates the backward apply in its own dgrad (csrc/conv_pw.h, BNB form; Engine.conv2d_dgrad_bnb): the gradient of
+    the layer's output and everything the apply needs.  The column sums dgamma / dbeta are finished (sums_done)."""
+
+    def __init__(self, dy, gamma, beta, mean, invstd, dgamma, dbeta, relu):
+        self.dy, self.gamma, self.beta, self.mean, self.invstd = dy, gamma, beta, mean, invstd
+        self.dgamma, self.dbeta, self.relu = dgamma, dbeta, relu
+        self.dtype, self.shape = dy.dtype, dy.shape
+
+    def tensors(self):
+        return (self.dy, self.gamma, self.beta, self.mean, self.invstd, self.dgamma, self.dbeta)
+
+
 class _BNNode(Node):
     op = "batch_normalization"
 
@@ -455,6 +477,7 @@ class _BNNode(Node):
         self.defer_add = None  # fused by the optimisation pass: the two-operand Add that applies this layer while it sums
         self.sums_from = None  # fused by the optimisation pass: the SeparableConv2D whose depthwise dgrad sums this layer's dgamma / dbeta
         self.defer_conv = None  # fused by the optimisation pass: the Conv2D whose loaders apply this layer (thin 1x1 / patch kernels)
+        self.bnb_to = None  # fused by the optimisation pass: the SeparableConv2D / 1x1 Conv2D whose dgrad evaluates this layer's backward apply
 
     def build(self, x):
         c = x.shape[-1]
@@ -495,6 +518,10 @@ class _BNNode(Node):
     def backward(self, rt, xs, y, dy):
         (x,) = xs
         s = rt.saved(self)
+        if s.get("sums_done") and self.bnb_to is not None and rt.bnb_on(self, x):
+            # ... and that pass rides in the A path of the producer's pointwise dgrad: hand the pieces over
+            return [BnBackwardDeferred(dy, rt.param(self.gamma), rt.param(self.beta), s["mean"], s["invstd"], rt.grad(self.gamma),
+                                       rt.grad(self.beta), self.relu)]
         if s.get("sums_done"):   # dgamma / dbeta came out of the consumer's depthwise dgrad (sums_from): only the apply pass is left
             return [rt.eng.bn_train_bwd_apply(x, dy, rt.param(self.gamma), rt.param(self.beta), s["mean"], s["invstd"],
                                               rt.grad(self.gamma), rt.grad(self.beta), relu=self.relu)]

@@ -463,6 +463,30 @@ class Engine:
                                                flags, wsp, wsn), "sg_conv2d_dgrad")
         return dx
 
+    def conv2d_dgrad_bnb_ok(self, d: ConvDesc, dtype=torch.float32) -> bool:
+        """Does the input gradient of pointwise convolution `d` take the wide kernel's BatchNormalization-backward form
+        (sg_conv2d_dgrad_bnb)?  Depends on the batch (the wide kernel wants >= 6144 rows)."""
+        return dtype == torch.float32 and bool(self.lib.sg_conv2d_dgrad_bnb_supported(self.h, SG_F32, C.byref(d)))
+
+    def conv2d_dgrad_bnb(self, dy_bn, x_bn, w, d: ConvDesc, gamma, beta, mean, invstd, dgamma, dbeta, relu, planes=None):
+        """dx of pointwise convolution `d` AND the BatchNormalization's applied gradient dz, from the gradient dy_bn of that
+        layer's output and its raw input x_bn (= the convolution's forward output): sg_conv2d_dgrad_bnb.  -> (dx, dz)"""
+        _chk32(dy_bn, "dy"); _chk32(x_bn, "x"); _chk32(w, "w")
+        assert dy_bn.shape == x_bn.shape and dy_bn.is_contiguous() and x_bn.is_contiguous()
+        dx = self.empty(d.N, d.H, d.W, d.Cin)
+        dz = torch.empty_like(dy_bn)
+        rows = dy_bn.numel() // dy_bn.shape[-1]
+        q = _lib.BnBwdIn(x_bn.data_ptr(), mean.data_ptr(), invstd.data_ptr(), gamma.data_ptr(), beta.data_ptr() if (relu and beta is not None) else None,
+                         dgamma.data_ptr(), dbeta.data_ptr(), dz.data_ptr(), int(bool(relu)), rows)
+        if planes is not None:
+            wsp, wsn = C.c_void_p(planes), C.c_size_t(_lib.SG_WS_PREPARED)
+        else:
+            wsp, wsn = self.ws(self.lib.sg_conv2d_dgrad_ws_bytes(C.byref(d)))
+        with self.timed(self._gemm_tag()):
+            check(self.lib.sg_conv2d_dgrad_bnb(self.h, self.stream, SG_F32, C.byref(d), _ptr(dy_bn), _ptr(w), _ptr(dx), wsp, wsn, C.byref(q)),
+                  "sg_conv2d_dgrad_bnb")
+        return dx, dz
+
     def conv2d_wgrad(self, x, dy, d: ConvDesc, want_bias=True, dw=None, db=None, x_up2=False, bn_in=None):
         """x_up2: x is the SOURCE [N, H/2, W/2, Cin] of the nearest 2x up-sampling the conv `d` read (SG_X_UP2: the patch
         kernel gathers x[n, h >> 1, w >> 1]; the bits of the filter gradient on the materialised tensor)."""

@@ -239,6 +239,14 @@ class Model:
                 if sc.stride == 1 and not sc.pre_relu and sc.bn_src is None and w % 4 == 0 and c % 4 == 0:
                     n.defer_to, sc.bn_src = sc, n
         self._fuse_bn_conv(outs)
+        # SeparableConv2D -> BatchNormalization whose backward column sums come from elsewhere (sums_from): the backward APPLY can
+        # ride in the A path of the pointwise dgrad (csrc/conv_pw.h, BNB form; _Runtime.bnb_on decides per runtime and batch)
+        for n in self.nodes:
+            if isinstance(n, L._BNNode) and n.sums_from is not None and len(n.output.shape) == 4:
+                prod = n.inputs[0].node
+                if (isinstance(prod, L._SepConvNode) and prod.activation in (None, "linear") and len(n.inputs[0].consumers) == 1
+                        and id(n.inputs[0]) not in outs):
+                    n.bnb_to = prod
 
     # (continued in _fuse_bn_conv, called at the end of _fuse)
     def _fuse_bn_conv(self, outs):
@@ -926,6 +934,7 @@ class _Runtime:
         e = self.eng
         self._up2: Dict[tuple, bool] = {}   # up_sampling2d node -> fused with its convolution on this runtime (up2_on)
         self._bn_conv: Dict[tuple, bool] = {}        # (batch_normalization node, arithmetic) -> applied by its consumer convolution
+        self._bnb: Dict[tuple, bool] = {}            # (batch_normalization node, batch, arithmetic) -> backward apply in the producer's dgrad
         self._act_planes: Dict[int, tuple] = {}      # id(symbolic tensor) -> (fp32 activation, its bf16 planes) of this step
         self._act_planes_use: Dict[int, bool] = {}   # id(conv node) -> its forward reads planes (geometry)
         self.w_train = e.zeros(max(model._n_train, ALIGN))
@@ -997,6 +1006,25 @@ class _Runtime:
             _lib.check(self.eng.lib.sg_prepare_planes(self.eng.h, self.eng.stream, C.c_void_p(self.w_train.data_ptr()),
                                                       C.c_void_p(arena.data_ptr()), C.c_void_p(jobs.data_ptr()), launch[0],
                                                       launch[1]), "sg_prepare_planes")
+
+    def bnb_on(self, bn_node, x) -> bool:
+        """Does THIS runtime leave BatchNormalization `bn_node`'s backward apply to the dgrad of the pointwise convolution that
+        produced its input (Model._fuse: bnb_to)?  fp32 storage, a launch the wide pointwise kernel takes at this batch (asked of
+        the library), SG_BN_PW=1.  OFF by default: built, bit-identical to the unfused pair, and a LOSS in the step - the 56
+        bn_bwd_apply launches it removes (47 us each in the profile) ran beside the side stream's filter gradients for free,
+        while the 25 us it adds to every dgrad sit on the matrix pipe, which is what bounds the step (71.13 / 71.43 ms without,
+        71.58 / 71.69 with, alternating runs on one box: gpurun_out/r5x; stand-alone 123 us against 22.5 + 96.8)."""
+        key = (id(bn_node), int(x.shape[0]), int(self.eng.lib.sg_get_conv_x6()))
+        got = self._bnb.get(key)
+        if got is None:
+            p = bn_node.bnb_to
+            got = False
+            if p is not None and os.environ.get("SG_BN_PW", "0") == "1" and self.model.compute_dtype == "float32" and x.dtype == self.torch.float32:
+                n, h, w, c = x.shape
+                cin = p.inputs[0].shape[-1]
+                got = bool(self.eng.conv2d_dgrad_bnb_ok(self.eng.conv_desc((n, h, w, cin), c, 1, 1, 1, 1, "same")))
+            self._bnb[key] = got
+        return got
 
     def bn_conv_on(self, bn_node) -> bool:
         """Does THIS runtime apply BatchNormalization `bn_node` in the loaders of its consumer convolution (Model._fuse: defer_conv /

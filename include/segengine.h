@@ -187,6 +187,31 @@ int sg_conv2d_fwd_stats_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_d
 int sg_conv2d_wgrad_bn(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* x, const void* dy,
                        void* dw, void* dbias, void* ws, size_t ws_bytes, const sg_bn_in* bn);
 
+/* The input gradient of a pointwise convolution whose forward output feeds a training-mode BatchNormalization, with that layer's
+ * backward APPLY evaluated in the kernel's A path (round 5; csrc/conv_pw.h, BNB form; SeparableConv2D -> BatchNormalization,
+ * train_model/DeepLabv3plus.py:323-416).  dy is the gradient of the BatchNormalization's OUTPUT, bnb->x its raw input (= this
+ * convolution's output), dgamma / dbeta its FINISHED column sums (sg_dwconv2d_dgrad_bnsums / sg_bn_train_bwd), rows the pixels
+ * it normalises over.  The kernel computes dz = gamma invstd ((g - dbeta / rows) - xhat dgamma / rows) on the fly (g = dy where the
+ * fused ReLU passed: the mask is bn_apply's own expression on x), multiplies it with the kernel and also stores it to bnb->dz for
+ * the filter gradient - what sg_bn_train_bwd_apply + sg_conv2d_dgrad do in two launches and three more tensor passes.
+ * Launches of the wide pointwise kernel only (sg_conv2d_dgrad_bnb_supported: 1x1, stride 1, dense fp32, >= 6144 rows, wide
+ * enough); same order of products as sg_conv2d_dgrad, the applied gradient within rounding of sg_bn_train_bwd_apply's. */
+typedef struct sg_bn_bwd_in {
+  const void* x;
+  const void* mean;
+  const void* invstd;
+  const void* gamma;
+  const void* beta;     /* null without a fused ReLU */
+  const void* dgamma;
+  const void* dbeta;
+  void* dz;
+  int32_t relu;
+  int64_t rows;
+} sg_bn_bwd_in;
+int sg_conv2d_dgrad_bnb_supported(const sg_ctx* ctx, int dtype, const sg_conv_desc* d);
+int sg_conv2d_dgrad_bnb(sg_ctx* ctx, void* stream, int dtype, const sg_conv_desc* d, const void* dy, const void* w, void* dx,
+                        void* ws, size_t ws_bytes, const sg_bn_bwd_in* bnb);
+
 /* Planes-in filter gradient (round 5).  The fp32 ("x6") filter gradient splits BOTH of its operands into three bf16 planes on
  * the VALU in every launch; where the planes already exist - the forward's activation planes of a long-K convolution, kept - the
  * kernel can take them as they are:

@@ -752,6 +752,41 @@ def test_batchnorm_applied_by_the_consuming_convolution_gives_the_same_bits(engi
     assert np.array_equal(pa, mb.predict(x))
 
 
+def test_batchnorm_backward_apply_left_to_the_pointwise_dgrad_gives_the_same_bits(engine, monkeypatch):
+    """SG_BN_PW=1 (off by default, see _Runtime.bnb_on): the BatchNormalization layers whose column sums come from the consumer's
+    depthwise dgrad hand dy and their parameters to the producing SeparableConv2D (layers.BnBackwardDeferred), whose pointwise
+    dgrad applies them (csrc/conv_pw.h, BNB form).  Six 512 x 512 tiles: the middle flow's layers bring 6 x 32 x 32 = 6144 rows, the
+    fewest the wide pointwise kernel takes.
+    Loss, gradients and weights after two steps: bit-identical to the default graph; some layer must really take the fused form."""
+    from building_detection_amd import zoo
+    from building_detection_amd import layers as L
+    from building_detection_amd.data import synthetic_batch
+    from building_detection_amd.losses import edge_focal_loss
+    ma = zoo.Xception_DeepLabV3_Plus((512, 512, 3), 2)
+    mb = zoo.Xception_DeepLabV3_Plus((512, 512, 3), 2)
+    assert sum(1 for n in mb.nodes if isinstance(n, L._BNNode) and n.bnb_to is not None) >= 40
+    mb.set_weights(ma.get_weights())
+    x, y = synthetic_batch(6, 512, 512, seed=81)
+    for m in (ma, mb):
+        m.compile(optimizer="adam", loss=edge_focal_loss, metrics=[])
+    calls = []
+    orig = engine.conv2d_dgrad_bnb
+    monkeypatch.setattr(engine, "conv2d_dgrad_bnb", lambda *a, **k: (calls.append(tuple(a[0].shape)), orig(*a, **k))[1])
+    for step in range(2):
+        monkeypatch.setenv("SG_BN_PW", "0")
+        la = ma.train_on_batch(x, y)
+        assert not calls
+        monkeypatch.setenv("SG_BN_PW", "1")
+        lb = mb.train_on_batch(x, y)
+        assert la["loss"] == lb["loss"], (step, la, lb)
+        for ga, gb in zip(ma.get_gradients(), mb.get_gradients()):
+            assert np.array_equal(ga, gb)
+        assert len(calls) >= 40, len(calls)   # the 48 middle-flow layers at 6 x 32 x 32 = 6144 rows and the entry flow's
+        calls.clear()
+    for wa, wb in zip(ma.get_weights(), mb.get_weights()):
+        assert np.array_equal(wa, wb)
+
+
 def test_activation_planes_once_per_step_give_the_same_bits(engine, monkeypatch):
     """Round 5 (_Runtime.act_planes, layers._ConvNode): in training the activation planes of the long-K 3x3 layers are made once
     per tensor and step - the five consumers of the ASPP input share one split, each layer's filter gradient takes the kept

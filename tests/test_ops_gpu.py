@@ -1018,6 +1018,41 @@ def test_batchnorm_applied_in_the_convolution_loaders(engine, case, infer):
         engine.conv2d_fwd(x, (rnd(g, k, k, cin, 8 if k == 1 else cout)).cuda(), None, desc=d_bad, bn_in=bn)
 
 
+@pytest.mark.parametrize("case", [(6, 32, 32, 728, 728, True), (6, 32, 32, 728, 728, False), (7, 32, 32, 728, 1016, True), (3, 64, 64, 1024, 728, True)],
+                         ids=["middle_flow", "no_relu", "ragged_k_1016", "tiles_256_wide"])
+def test_batchnorm_backward_apply_in_the_pointwise_dgrad(engine, case):
+    """Round 5 (csrc/conv_pw.h, BNB form; sg_conv2d_dgrad_bnb): SeparableConv2D -> BatchNormalization, backward - the layer's
+    backward APPLY evaluated in the A path of the pointwise dgrad, the applied gradient also stored for the filter gradient.  Both
+    outputs must have the BITS of sg_bn_train_bwd_apply + sg_conv2d_dgrad (the transformed value is fenced before the x6 split:
+    left to the compiler, the split's residual was an fma of the unrounded product and the input gradient differed in the last
+    place).  Off in the step by default (a loss there: _Runtime.bnb_on), kept correct."""
+    n, h, w_, cin, cout, relu = case
+    g = torch.Generator().manual_seed(cin + cout)
+    t = rnd(g, n, h, w_, cin).cuda()
+    wt = (rnd(g, 1, 1, cin, cout) * (1.0 / np.sqrt(cin))).cuda()
+    d = engine.conv_desc(tuple(t.shape), cout, 1, 1, 1, 1, "same")
+    assert engine.conv2d_dgrad_bnb_ok(d), "a launch of the wide pointwise kernel"
+    y = engine.conv2d_fwd(t, wt, None, desc=d)
+    gam, bet = (rnd(g, cout) + 1.5).cuda(), (rnd(g, cout) * 0.3).cuda()
+    z, mean, inv = engine.bn_train_fwd(y, gam, bet, torch.zeros(cout).cuda(), torch.ones(cout).cuda(), relu=relu)
+    dyb = rnd(g, n, h, w_, cout).cuda()
+    dz_ref, dgam, dbet = engine.bn_train_bwd(y, z, dyb, gam, mean, inv, relu=relu, beta=bet)
+    dx_ref = engine.conv2d_dgrad(dz_ref, wt, d)
+    dx, dz = engine.conv2d_dgrad_bnb(dyb, y, wt, d, gam, bet, mean, inv, dgam, dbet, relu)
+    assert torch.equal(dz, dz_ref), f"applied gradient: max diff {float((dz - dz_ref).abs().max())}"
+    assert torch.equal(dx, dx_ref), f"input gradient: max diff {float((dx - dx_ref).abs().max())}"
+    # fp64: BatchNormalization backward through autograd, then the pointwise dgrad
+    yr = y.cpu().double().requires_grad_()
+    zr = T.batch_norm(yr, gam.cpu().double(), bet.cpu().double(), torch.zeros(cout).double(), torch.ones(cout).double(), True)[0]
+    (torch.relu(zr) if relu else zr).backward(dyb.cpu().double())
+    close(dz, yr.grad, rtol=2e-5, what="applied gradient vs fp64 autograd")
+    from building_detection_amd._lib import SgError
+    small = engine.conv_desc((1, 32, 32, cin), cout, 1, 1, 1, 1, "same")   # 1024 rows: the narrow kernels' launch
+    assert not engine.conv2d_dgrad_bnb_ok(small)
+    with pytest.raises(SgError):
+        engine.conv2d_dgrad_bnb(dyb[:1].contiguous(), y[:1].contiguous(), wt, small, gam, bet, mean, inv, dgam, dbet, relu)
+
+
 def test_sub_batch_paths_of_oversized_tensors(engine):
     """activations beyond 2 GiB run as sub-batches of whole images (forward, dgrad) / as chunks with one reduce
     (wgrad).  SG_CONV_MAX_BYTES (read once per process) lowers that limit, so a child process runs a 5-image convolution
