@@ -20,6 +20,13 @@
 //     in flight under the MFMAs of the current one.
 // Serves forward and dgrad alike (IgemmParams: off = -1, k_mul = +1 / off = +1, k_mul = -1).
 //
+// Round 5, more than 64 reduction channels per tap (128 / 256: the decoder's 3x3 convolutions at 128 x 128 and 256 x 256 that the
+// planes-in kernel does not take): the tile's reduction is walked in CHUNKS of 64 channels - stage the chunk's patch, run its nine
+// taps, next chunk into the same LDS - with the accumulators kept across the chunks.  The im2col kernel staged and split every input
+// element nine times for 64 / 128 output columns (256 x 256 x 128 -> 64: 1.22 ms at 127 TFLOP/s, the slowest launch of the step).
+// Order of additions of an output element: chunk by chunk, inside a chunk tap by tap - another order than the im2col kernel's
+// (tap-major over all channels), fixed and independent of the batch.
+//
 // UpSampling2D(2, nearest) -> Conv2D 3x3 (train_model/DeepLabv3plus.py:476-477: 256 x 256 x 64 -> 512 x 512 x 64 -> 32; round 5):
 //   * forward, UP2 = true ("sub-pixel" form): output pixel (2i + a, 2j + b) of the up-sampled grid sees, through its nine
 //     taps, only the 2 x 2 source pixels (i + a - 1 .. i + a, j + b - 1 .. j + b): rows {i - 1: w[0], i: w[1] + w[2]} for
@@ -34,6 +41,9 @@
 //     in ONE lane's accumulators - in up-sampling's backward order ((g00 + g01) + g10) + g11 and stores the SOURCE-sized
 //     gradient: bit-identical to dgrad + sg_upsample_nearest_bwd, without the 4x tensor in between.
 #pragma once
+
+struct IgemmParams;
+inline int x6w_plan(const IgemmParams& p);   // conv_x6w.h: launches of the planes-in kernel keep it (x6p_ok below)
 
 template <int C>
 struct X6P {
@@ -198,11 +208,14 @@ __global__ __launch_bounds__(256) void prepare_planes_kernel(const float* __rest
 // of the pipe and overlapped ones barely slower.
 __device__ unsigned g_x6p_arrivals[2048];  // per CU: workgroups that have started there (never reset; used modulo)
 
-template <int C, int BN, bool UP2 = false>
+// MULTI: p.C is a multiple of C and the reduction is walked chunk by chunk (the accumulators then live through the staging of a
+// chunk - 60 - 80 more registers than the one-chunk instantiations, which stay as they were)
+template <int C, int BN, bool UP2 = false, bool MULTI = false>
 __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, int tiles_x, int tiles_y, int ntiles, int delay,
                                                           int wg_per_cu) {
   using L = X6P<C>;
   static_assert(!UP2 || (C == 64 && BN == 128), "the sub-pixel form: 64 source channels, 4 phases x 32 output channels");
+  static_assert(!MULTI || (C == 64 && !UP2), "chunks of 64 channels");
   constexpr int NBLK = BN / 32;     // 32-column blocks of the tile: 1, 2, 4
   constexpr int KS = 4 / NBLK;      // K classes: 4, 2, 1
   constexpr int CS = C / 16;        // k-steps per tap
@@ -254,6 +267,16 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
       ts[0] = __builtin_amdgcn_s_memtime();
       rt0 = __builtin_amdgcn_s_memrealtime();
     }
+    f32x16 acc[4];
+    if constexpr (MULTI) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
+    const int nch = MULTI ? p.C / C : 1;        // chunks of C reduction channels per tap (uniform)
+    const int cst = MULTI ? p.C / 16 : CS;      // k-steps per tap over all chunks: a chunk's k-step ks is tap * cst + ch * CS + ks % CS
+    for (int ch = 0; ch < nch; ++ch) {
     // ---- the patch: rows by*8-1 .. by*8+8, columns bx*16-1 .. bx*16+16 of image img, zero outside the image.
     // A wave pass covers PPW consecutive pixels of one patch row (C/4 lanes per pixel, one float4 each); the
     // 10 x NPASS (row, pass) slots go round-robin to the four waves, so row and pass - and with them the row's base
@@ -261,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
     {
       constexpr int LPP = C / 4, PPW = 64 / LPP, NPASS = (18 + PPW - 1) / PPW, NSLOT = 10 * NPASS, SPW = (NSLOT + 3) / 4;
       const int y0 = (int)by * 8 - 1, x0 = (int)bx * 16 - 1;
-      const float* xi = p.x + (int64_t)img * p.H * p.W * p.x_ld;
+      const float* xi = p.x + (int64_t)img * p.H * p.W * p.x_ld + ch * C;
       const int c4 = lane & (LPP - 1), pxl = lane / LPP;
       f32x4 v[SPW];
       unsigned okm = 0;   // bit k: slot k of this lane lies inside the image (the BatchNormalization below leaves the padding zero)
@@ -269,10 +292,10 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
       const bool bn_on = p.bn.mean != nullptr;
       f32x4 bm = {0.f, 0.f, 0.f, 0.f}, bi = bm, bg = bm, bb = bm;
       if (bn_on) {
-        bm = *reinterpret_cast<const f32x4*>(p.bn.mean + c4 * 4);
-        bi = bn_in_inv(p.bn, c4 * 4);
-        bg = *reinterpret_cast<const f32x4*>(p.bn.gamma + c4 * 4);
-        bb = *reinterpret_cast<const f32x4*>(p.bn.beta + c4 * 4);
+        bm = *reinterpret_cast<const f32x4*>(p.bn.mean + ch * C + c4 * 4);
+        bi = bn_in_inv(p.bn, ch * C + c4 * 4);
+        bg = *reinterpret_cast<const f32x4*>(p.bn.gamma + ch * C + c4 * 4);
+        bb = *reinterpret_cast<const f32x4*>(p.bn.beta + ch * C + c4 * 4);
       }
 #pragma unroll
       for (int k = 0; k < SPW; ++k) {
@@ -316,16 +339,19 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
 
     // ---- K loop: no barrier ---------------------------------------------------------------------------------
     const unsigned short* bq = p.wq + ((int64_t)(tile_n * NBLK + nblk) * 3) * 512 + lane * 8;
-    f32x16 acc[4];
+    if constexpr (!MULTI) {   // (one chunk: the accumulators start their life behind the staging, as before round 5)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    }
+    // k-step ks of this chunk in the layer's fragment-major planes (all chunks: tap-major, then channels)
+    auto gks = [&](int ks) -> int { return MULTI ? ks + (ks / CS) * (cst - CS) + ch * CS : ks; };
 
     // (B fragments are kept as integer vectors: bf16 vectors that cross the conditional steps are rebuilt element
     // by element - 24 shift / permute instructions per k-step)
     auto load_b = [&](int ks, u32x4_t (&b)[3]) {
-      const unsigned short* q = bq + ks * bstep;
+      const unsigned short* q = bq + gks(ks) * bstep;
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) b[pl] = *reinterpret_cast<const u32x4_t*>(q + pl * 512);
     };
@@ -392,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
         if (NKS % KS != 0 && j == NJ - 1 && ks >= NKS) continue;  // uniform (ragged K split: C = 32, KS = 4)
         const int kn = (ks + KS < NKS) ? ks + KS : ks;  // the tail re-reads the last step (unused)
         const int kp = (ks + PD * KS < NKS) ? ks + PD * KS : ks;
-        const unsigned short* qb = bq + kp * bstep;
+        const unsigned short* qb = bq + gks(kp) * bstep;
 #pragma unroll
         for (int m = 0; m < 12; ++m) {
           mfma_one(0, m, a[0], b[j % (PD + 1)]);
@@ -414,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void conv_x6p_kernel(const IgemmParams p, i
       }
     }
 
+    }   // chunks of the reduction channels
     if (dbg) ts[4] = __builtin_amdgcn_s_memtime();
     // ---- K classes: 32-row block i of a column block is finalised by the wave of class i % KS, which sums the
     // classes' partials in the fixed order 0, 1, .. (its own from registers, the others' through LDS; the patch is dead)
@@ -568,27 +595,38 @@ inline bool x6p_enabled() {
 // geometry the patch form covers; KH, KW are the filter's (IgemmParams carries only K)
 inline bool x6p_ok(const IgemmParams& p, int KH, int KW) {
   if (!x6p_enabled() || KH != 3 || KW != 3) return false;
-  if (!(p.C == 32 || p.C == 64) || p.K != 9 * p.C) return false;
+  // 32 or 64 reduction channels per tap in one patch; 128 / 256 / ... in chunks of 64 (round 5) unless the planes-in kernel takes
+  // the launch (K >= 2048 and >= 192 output columns: conv_x6w.h)
+  if (p.K != 9 * p.C) return false;
+  if (!(p.C == 32 || p.C == 64)) {
+    static const int multi = getenv("SG_X6P_CHUNKS") ? atoi(getenv("SG_X6P_CHUNKS")) : 1;
+    if (!multi || p.C % 64 != 0 || p.C > 512) return false;
+  }
   if (p.a_mul != 1 || p.div != 1) return false;
   const bool fwd = p.k_mul == 1 && p.off_h == -1 && p.off_w == -1, bwd = p.k_mul == -1 && p.off_h == 1 && p.off_w == 1;
   if (!fwd && !bwd) return false;
   if (p.OH != p.H || p.OW != p.W || (p.H % 8) || (p.W % 16)) return false;
   if (!(p.Nout == 32 || p.Nout == 64 || p.Nout % 128 == 0)) return false;
   if ((p.x_ld % 4) || (((uintptr_t)p.x) & 15)) return false;
+  if (p.C > 64) {   // (the planes-in kernel declines a launch that adds a collected gradient; the weight planes were laid out
+    IgemmParams q = p;   // for it all the same, so the answer here must not depend on `res`)
+    q.res = nullptr;
+    if (x6w_plan(q) > 0) return false;
+  }
   return true;
 }
 
-template <int C, int BN, bool UP2 = false>
+template <int C, int BN, bool UP2 = false, bool MULTI = false>
 int launch_x6p(const IgemmParams& p, int num_cus, hipStream_t st) {
   constexpr int KS = 4 / (BN / 32), NBLK = BN / 32;
   constexpr size_t red = (KS > 1) ? (size_t)4 * NBLK * (KS - 1) * 4096 : 0;
   constexpr size_t lds = (X6P<C>::PATCH > red ? (size_t)X6P<C>::PATCH : red) + 2 * 4 * 32 * sizeof(float);
   static int wg_per_cu = 0;
   if (!wg_per_cu) {
-    int rc = set_dyn_lds(conv_x6p_kernel<C, BN, UP2>, lds);
+    int rc = set_dyn_lds(conv_x6p_kernel<C, BN, UP2, MULTI>, lds);
     if (rc) return rc;
     int nb = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_x6p_kernel<C, BN, UP2>, 256, lds);
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, conv_x6p_kernel<C, BN, UP2, MULTI>, 256, lds);
     if (e != hipSuccess || nb < 1) nb = 1;
     wg_per_cu = nb > 4 ? 4 : nb;
   }
@@ -608,7 +646,7 @@ int launch_x6p(const IgemmParams& p, int num_cus, hipStream_t st) {
   int delay = 0;
   if (dly_env != 0 && grid == slots && wg_per_cu > 1 && tiles >= 2 * slots)
     delay = dly_env > 0 ? dly_env : (int)(2.0 * 128 * BN * 9 * C / 1.1e6 * 100.0 + 0.5);
-  hipLaunchKernelGGL((conv_x6p_kernel<C, BN, UP2>), dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, (int)tiles, delay, wg_per_cu);
+  hipLaunchKernelGGL((conv_x6p_kernel<C, BN, UP2, MULTI>), dim3((unsigned)grid), dim3(256), lds, st, p, tiles_x, tiles_y, (int)tiles, delay, wg_per_cu);
   SG_LAUNCH_CHECK("conv_x6p_kernel");
   return 0;
 }
@@ -637,6 +675,11 @@ int run_x6p(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, void*
     if (bn == 32) return launch_x6p<32, 32>(p, num_cus, st);
     if (bn == 64) return launch_x6p<32, 64>(p, num_cus, st);
     return launch_x6p<32, 128>(p, num_cus, st);
+  }
+  if (p.C > 64) {   // 128 / 256 / ... reduction channels per tap: chunks of 64
+    if (bn == 32) return launch_x6p<64, 32, false, true>(p, num_cus, st);
+    if (bn == 64) return launch_x6p<64, 64, false, true>(p, num_cus, st);
+    return launch_x6p<64, 128, false, true>(p, num_cus, st);
   }
   if (bn == 32) return launch_x6p<64, 32>(p, num_cus, st);
   if (bn == 64) return launch_x6p<64, 64>(p, num_cus, st);

@@ -327,9 +327,16 @@ def test_fit_generator_tracks_the_oracle_over_several_steps(engine):
     # luck - the one-step gradient of two correct fp32 evaluations is 2e-4 ... 3e-2 from fp64 depending on the tiles
     # (scripts/diag_mf16.py, round 3: five seeds, two MFMA shapes, neither systematically better) - and a flip moves the next
     # loss by up to ~1e-3 of its value; the fp32 oracle's own 3e-5 at step 1 is the lucky end of that range.
+    # The floor grows with the step, a factor 4 per step as the trajectories themselves do (the fp32 oracle leaves fp64 by
+    # 3e-5 / 3.5e-3 / 1.5e-2): round 5, two builds that differ ONLY in the summation order of two layers (256 -> 32 and 128 -> 64
+    # at 3x3: im2col slab vs 64-channel chunks of the patch kernel, both within 1e-6 of the oracle per op and both green in the
+    # one-step gradient test on this model) end step 3 at 0.26947 and 0.28297 - fp64 0.26567, fp32 oracle 0.27052
+    # (gpurun_out/r5D/fit.txt).  What this test is for - a stale learning rate, a step counter, moving statistics on the wrong layer -
+    # moves the loss by tens of per cent from step 1 on; the exact loop is held to 1e-5 on a flip-free block in
+    # test_block_chains_gpu.py::test_fit_loop_on_a_flip_free_block_tracks_fp64_at_1e_5.
     K = 3.0
     for i, (a, c, b) in enumerate(zip(losses_gpu, l32, l64)):
-        floor = 1e-5 if i == 0 else 2e-3
+        floor = 1e-5 if i == 0 else 2e-3 * 4 ** (i - 1)
         assert abs(a - b) <= K * abs(c - b) + floor * abs(b), f"step {i}: gpu {a} cpu-fp32 {c} fp64 {b}"
     w0 = [w.astype(np.float64) for w, prm in zip(ws0, model.params) if prm.trainable]
     w_gpu = [w.astype(np.float64) for w, prm in zip(model.get_weights(), model.params) if prm.trainable]

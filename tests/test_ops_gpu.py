@@ -58,6 +58,13 @@ CONV_CASES = [
     (1, 32, 32, 32, 32, 3, 1, 1, "x6_wgrad_c32"),
     (2, 32, 64, 64, 48, 3, 1, 1, "x6_wgrad_c64_cout48"),
     (1, 64, 32, 48, 80, 3, 1, 3, "x6_wgrad_c48_d3"),
+    # round 5: the patch kernel walks 128 / 256 reduction channels per tap in chunks of 64 (forward: Cin, dgrad: Cout)
+    (2, 16, 32, 128, 64, 3, 1, 1, "patch_chunks_128_to_64"),
+    (1, 16, 16, 256, 128, 3, 1, 1, "patch_chunks_256_to_128"),
+    (2, 8, 16, 64, 128, 3, 1, 1, "patch_chunks_dgrad_128"),
+    (1, 24, 16, 128, 32, 3, 1, 1, "patch_chunks_128_to_32"),
+    (2, 16, 16, 256, 32, 3, 1, 1, "patch_chunks_256_to_32"),
+    (1, 8, 32, 512, 64, 3, 1, 1, "patch_chunks_512_to_64"),
     # LDS-patch x6 kernel (3x3 s1 d1, 32 / 64 reduction channels, H % 8 == 0, W % 16 == 0): every (C, BN) form forward
     # and dgrad, K split 4 / 2 / 1 ways, image borders on all sides, several column tiles
     (2, 16, 32, 32, 32, 3, 1, 1, "patch_c32_n32"),
@@ -828,8 +835,8 @@ def test_x6_at_least_as_accurate_as_native_fp32_mfma(engine, case):
 
 
 @pytest.mark.parametrize("shape", [(2, 32, 32, 256, 728, 1), (3, 20, 32, 64, 96, 3), (1, 32, 32, 128, 40, 3),
-                                   (2, 24, 32, 64, 32, 3), (1, 16, 48, 32, 64, 3)],
-                         ids=["pw_728", "ragged_rows", "cout40", "patch_c64_n32", "patch_c32_n64"])
+                                   (2, 24, 32, 64, 32, 3), (1, 16, 48, 32, 64, 3), (2, 16, 32, 128, 64, 3), (1, 16, 16, 256, 128, 3)],
+                         ids=["pw_728", "ragged_rows", "cout40", "patch_c64_n32", "patch_c32_n64", "patch_chunks_128_64", "patch_chunks_256_128"])
 def test_conv_epilogue_bn_statistics(engine, shape):
     """SG_EPI bn_stats: the per-tile (sum, centred sum of squares) a convolution leaves for the following
     BatchNormalization give the same normalised output, saved statistics and moving statistics as BN's own pass."""
