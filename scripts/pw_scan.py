@@ -29,16 +29,19 @@ def timed(fn):
     return a.elapsed_time(b) / iters * 1e3  # microseconds
 
 
-print(f"SG_X6_VARIANT={os.environ.get('SG_X6_VARIANT', 'auto')}  M={N * h * h}")
+bf = os.environ.get("DTYPE", "f32") == "bf16"   # DTYPE=bf16: bf16 storage (pw_wide_kernel<1, bf16, ..>, 64-deep stages)
+print(f"SG_X6_VARIANT={os.environ.get('SG_X6_VARIANT', 'auto')}  M={N * h * h}  dtype={'bf16' if bf else 'f32'}")
 for cout in (256, 728, 1024):
     pts = []
     for cin in (128, 256, 512, 728, 1024, 1456, 2048):
         x = (torch.rand(N, h, h, cin, generator=g) * 2 - 1).cuda()
+        if bf:
+            x = x.to(torch.bfloat16)
         w = ((torch.rand(1, 1, cin, cout, generator=g) * 2 - 1) * 0.02).cuda()
         d = e.conv_desc(tuple(x.shape), cout, 1, 1, 1, 1, "same")
         y = e.conv2d_fwd(x, w, None, desc=d)
-        dy = (torch.rand(*y.shape, generator=g) * 2 - 1).cuda()
-        dx, dw = e.empty(*x.shape), e.empty(*w.shape)
+        dy = (torch.rand(*y.shape, generator=g) * 2 - 1).cuda().to(y.dtype)
+        dx, dw = e.empty(*x.shape, dtype=x.dtype), e.empty(*w.shape)
         tf_ = timed(lambda: e.conv2d_fwd(x, w, None, desc=d, out=y))
         td = timed(lambda: e.conv2d_dgrad(dy, w, d, out=dx))
         tw = timed(lambda: e.conv2d_wgrad(x, dy, d, want_bias=False, dw=dw))

@@ -16,6 +16,10 @@ g = torch.Generator().manual_seed(2)
 SHAPES = [(32, 2048, 256, 3, 6), (32, 2048, 256, 3, 12), (32, 2048, 256, 3, 18), (32, 2048, 256, 3, 1), (32, 256, 256, 3, 6), (32, 256, 256, 3, 1),
           (32, 512, 256, 3, 1), (64, 512, 256, 3, 1), (64, 256, 256, 3, 1), (128, 256, 128, 3, 1), (128, 128, 128, 3, 1), (256, 128, 64, 3, 1),
           (32, 1280, 256, 1, 1), (32, 2048, 256, 1, 1)]
+if os.environ.get("SHAPES") == "pw":   # the wide pointwise layers: an experiment of round 5 (LAB_NOTEBOOK 12.8, not in the tree) - the
+    # library declines them (conv2d_wgrad_planes_ok false) and the loop below prints so
+    SHAPES = [(32, 728, 728, 1, 1), (32, 728, 1024, 1, 1), (32, 1024, 1536, 1, 1), (32, 1536, 1536, 1, 1), (32, 1536, 2048, 1, 1),
+              (64, 728, 728, 1, 1), (32, 1024, 1024, 1, 1), (32, 1280, 256, 1, 1), (32, 2048, 256, 1, 1), (64, 256, 728, 1, 1)]
 
 
 def timed(fn, reps=5):
