@@ -26,6 +26,10 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC: without this RCCL's peer mappings fail in hipIpcGetMemHandle.  Exported on
+# the image already; set here too so that a launcher with a scrubbed environment still gets working ranks (read at HSA start-up,
+# i.e. before torch touches the GPU)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 FP32_MFMA_PEAK_TFLOPS = 157.3
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md
