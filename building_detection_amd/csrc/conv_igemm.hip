@@ -1260,12 +1260,16 @@ int run_x6(IgemmParams& p, const float* w, bool dgrad, int Cin, int Cout, int KH
            hipStream_t st, bool prepared = false) {
   // prepared: `ws` already holds this launch's weight planes (sg_prepare_planes, once per optimiser step), no split here
   if (p.res) {  // only the slab kernels below add a collected gradient (callers ask sg_conv2d_planes_job: kind 1)
-    bool other = false;
-    if constexpr (NPL == 3) other = x6p_ok(p, KH, KW);
+    bool patch = false, wide = false;
+    if constexpr (NPL == 3) patch = x6p_ok(p, KH, KW);
     if constexpr ((NPL == 3 && std::is_same<TA, float>::value) || (NPL == 1 && !std::is_same<TA, float>::value))
-      other = other || pw_wide_ok(p, EL<TA>::BYTES);
-    if (other) {
-      sg_set_error("sg_conv2d_dgrad_acc: this launch takes the patch / wide pointwise kernel, which do not add a collected gradient");
+      wide = pw_wide_ok(p, EL<TA>::BYTES);
+    if (patch || wide) {
+      IgemmParams q = p;
+      q.res = nullptr;
+      sg_set_error("sg_conv2d_dgrad_acc: this launch takes the %s kernel, which does not add a collected gradient "
+                   "(reduction channels per tap %d, K %d, output columns %d, %d x %d outputs per image; planes-in plan without res: %d)",
+                   patch ? "patch" : "wide pointwise", p.C, p.K, p.Nout, p.OH, p.OW, x6w_plan(q));
       return SG_EUNSUPPORTED;
     }
   }

@@ -448,6 +448,52 @@ def test_conv_dgrad_adds_a_collected_gradient(engine, case, dtype):
         assert float((got.float() - exact).abs().max()) <= 2 ** -7 * float(exact.abs().max())
 
 
+@pytest.mark.parametrize("case,kind_wanted,same_kernel", [
+    # the decoder's 64^2 x 512 -> 256: 256 reduction channels in the dgrad, but the planes-in kernel's shape.  Without `res` the launch
+    # takes conv_x6w_kernel, with it conv_x6_kernel (the planes-in kernel has no such epilogue; both read kind-1 planes): same
+    # products, another order of summation over K = 2304
+    ((1, 64, 64, 512, 256, 3, 1), 1, False),
+    ((2, 16, 32, 64, 96, 3, 2), 1, True),       # dilated, 96 reduction channels: the slab kernel with and without `res`
+    ((2, 16, 32, 64, 128, 3, 1), 2, None),      # 128 reduction channels in the dgrad: the patch kernel in two chunks
+    ((2, 16, 32, 64, 64, 3, 1), 2, None),       # one chunk
+    ((6, 32, 32, 728, 728, 1, 1), 3, None),     # the wide pointwise kernel (6144 rows)
+], ids=["long_k_256ch", "slab_dilated", "patch_two_chunks", "patch_one_chunk", "wide_pointwise"])
+def test_dgrad_kernel_choice_does_not_depend_on_a_collected_gradient(engine, case, kind_wanted, same_kernel):
+    """include/segengine.h, sg_conv2d_dgrad_acc: a launch adds `res` exactly when sg_conv2d_planes_job (which knows no `res`) says
+    kind 1 for it - the weight planes of a step are laid out from that answer, so the launch must come to the same one with `res` as
+    without.  Round 5: x6p_ok asked x6w_plan, which declines a launch that carries `res`; the decoder's 64^2 x 512 -> 256 dgrad then took
+    the patch kernel on planes laid out for the slab kernel's family and refused (loudly) in the training step - no op test saw it
+    (scripts/regress_kernel_choice.sh rebuilds with that form: `long_k_256ch` then fails with the step's rc=-3, profiles/r05_regress_kernel_choice.txt).
+    Kind 1: accepted, and dgrad + res - bit for bit where the launch takes the same kernel with and without `res`, within the
+    rounding of two fp32 summation orders where it does not.  Kinds 2 / 3: SG_EUNSUPPORTED and nothing launched (dx untouched)."""
+    import ctypes as C
+    from building_detection_amd import _lib
+    n, h, w, cin, cout, k, dil = case
+    g = torch.Generator().manual_seed(7 * cin + cout + k)
+    wt = (rnd(g, k, k, cin, cout) * (1.0 / np.sqrt(k * k * cin))).cuda()
+    d = engine.conv_desc((n, h, w, cin), cout, k, k, 1, dil, "same")
+    job, nbytes = _lib.PlanesJob(), C.c_size_t(0)
+    _lib.check(engine.lib.sg_conv2d_planes_job(engine.h, _lib.SG_F32, C.byref(d), 1, C.byref(job), C.byref(nbytes)), "sg_conv2d_planes_job")
+    assert int(job.kind) == kind_wanted, f"this case no longer covers kind {kind_wanted} (planes job says {job.kind})"
+    dy = rnd(g, n, d.Ho, d.Wo, cout).cuda()
+    res = rnd(g, n, h, w, cin).cuda()
+    plain = engine.conv2d_dgrad(dy, wt, d)
+    if kind_wanted == 1:
+        got = engine.conv2d_dgrad(dy, wt, d, res=res)
+        ref = engine.add_n([res, plain])
+        if same_kernel:
+            assert torch.equal(got, ref)
+        else:   # |dx| ~ 0.6 here; two correct fp32 sums of 2304 x6 products differ by a few ulp of the largest partial sum
+            assert float((got - ref).abs().max()) <= 4e-6 * float(ref.abs().max())
+            assert not torch.equal(got, ref), "same bits: this case no longer crosses from the planes-in to the slab kernel"
+    else:
+        buf = torch.full_like(res, 123.0)
+        with pytest.raises(_lib.SgError, match=r"rc=-3"):
+            engine.conv2d_dgrad(dy, wt, d, res=res, out=buf)
+        torch.cuda.synchronize()
+        assert bool((buf == 123.0).all()), "a refused launch wrote into dx"
+
+
 @pytest.mark.parametrize("pre_relu", [False, True])
 def test_depthwise_dgrad_adds_a_collected_gradient(engine, pre_relu):
     """sg_dwconv2d_dgrad_acc: dx = dgrad(dy) [masked by x > 0] + res inside the kernel - the bits of the dgrad followed by
