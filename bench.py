@@ -377,6 +377,11 @@ def main():
     fam = {}
     if jit:
         model.jit_compile = False   # the two bracketed steps below run eagerly
+        # ... after one eager step that is neither timed nor bracketed: the replays ran on private buffers, and the first eager
+        # step behind them re-grows the shared workspaces - bracketed, it read 54 - 59 ms for the family instead of 52.5 and 6.3
+        # instead of 6.15 ms for the dilated set (gpurun_out/r5L; the default one-GPU line tries both forms first and never
+        # showed it, but every N > 1 line runs the replay)
+        model.train_on_batch(xd, yd, return_device_scalars=True)
     if rank == 0:
         eng.profile_begin(all_convs=True)
     for _ in range(2):
